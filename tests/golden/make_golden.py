@@ -1,0 +1,245 @@
+"""Mint golden vectors by running the REFERENCE ITSELF (see ref_shim.py) on seeded inputs.
+
+Run once in the build container (where /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+Outputs (committed, small):
+    boxes.npz            utils.bbox_iou / bbox_ious cases
+    dconv.npz            dynamic_conv.dynamic_conv2d(is_first=True) forward
+    mini.weights         darknet weight stream written by the reference's save_weights
+    mini_forward.npz     darknet_meta.Darknet forward (train + eval), reweighting vectors, BN stats
+    mini_yolo.weights / mini_yolo_forward.npz   darknet.Darknet (non-meta twin) forward
+    region_v2_*.npz      RegionLossV2 forward + autograd gradient + build_targets tensors
+    region_v1.npz        RegionLoss (v1) forward + gradient
+    decode_v2.npz        utils.get_region_boxes_v2 + utils.nms
+
+The GPU box has no /root/reference; tests there read only these files.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ANCH = [1.3221, 1.73145, 3.19275, 4.00944, 5.05587, 8.09892, 9.47112, 4.84053, 11.2364, 10.0071]
+ANCH_V1 = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
+
+
+def synth_targets(rng, bs, cs, max_per_img=5, same_cell=True):
+    """(bs, cs, 250) float64 targets laid out like image.py:144-192 packs them."""
+    tgt = np.zeros((bs, cs, 250), np.float64)
+    fill = np.zeros((bs, cs), np.int64)
+    for b in range(bs):
+        for _ in range(rng.randint(1, max_per_img + 1)):
+            n = rng.randint(0, cs)
+            w, h = rng.uniform(0.05, 0.5, 2)
+            cx = float(np.clip(rng.uniform(0.1, 0.9), w / 2, 0.999 - w / 2))
+            cy = float(np.clip(rng.uniform(0.1, 0.9), h / 2, 0.999 - h / 2))
+            t = fill[b, n]
+            tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+            fill[b, n] += 1
+    if same_cell and bs > 1 and cs > 1:
+        # two classes of image 0 claim the same (anchor, cell): the class mask must drop it
+        tgt[0, 0, :5] = [0, 0.52, 0.52, 0.30, 0.40]
+        tgt[0, 1, :5] = [1, 0.53, 0.51, 0.31, 0.41]
+        # two boxes of the same row in the same cell: the later one wins
+        tgt[1, 1, :10] = [1, 0.30, 0.70, 0.20, 0.25, 1, 0.31, 0.71, 0.21, 0.24]
+    return tgt
+
+
+def gold_boxes(u):
+    rng = np.random.RandomState(1)
+    a = rng.uniform(0.1, 5, (64, 4))
+    b = rng.uniform(0.1, 5, (64, 4))
+    a[0] = [1, 1, 2, 2]; b[0] = [5, 5, 1, 1]          # disjoint
+    a[1] = [1, 1, 2, 2]; b[1] = [1, 1, 2, 2]          # identical
+    a[2] = [1, 1, 2, 2]; b[2] = [2, 1, 2, 2]          # half overlap
+    a[3] = [1, 1, 2, 2]; b[3] = [3, 1, 2, 2]          # touching edge -> 0
+    sc = np.array([u.bbox_iou(list(map(float, a[i])), list(map(float, b[i])), x1y1x2y2=False)
+                   for i in range(64)])
+    ta = torch.from_numpy(a.astype(np.float32)).t().contiguous()
+    tb = torch.from_numpy(b.astype(np.float32)).t().contiguous()
+    vec = u.bbox_ious(ta, tb, x1y1x2y2=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "boxes.npz"), a=a, b=b, scalar=sc, vector=vec)
+
+
+def gold_dconv(dc):
+    torch.manual_seed(2)
+    x = torch.randn(3, 8, 5, 5)
+    w = torch.randn(4, 8, 1, 1)
+    layer = dc.dynamic_conv2d(True)(8, 8, 1, 1, 0)
+    out = layer((x, w))
+    np.savez_compressed(os.path.join(HERE, "dconv.npz"), x=x.numpy(), w=w.numpy(), out=out.detach().numpy())
+
+
+def gold_mini_forward(dm):
+    torch.manual_seed(3)
+    net = dm.Darknet(os.path.join(HERE, "mini_dynamic.cfg"), os.path.join(HERE, "mini_reweight.cfg"))
+    # non-trivial BN affine + running stats so every field of the weight stream matters
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    net.seen = 4242
+    net.save_weights(os.path.join(HERE, "mini.weights"))
+    x = torch.rand(2, 3, 64, 64)
+    metax = torch.rand(3, 3, 64, 64)
+    mask = torch.zeros(3, 1, 64, 64)
+    mask[0, 0, 10:40, 5:30] = 1; mask[1, 0, 0:20, 30:64] = 1; mask[2, 0, 25:60, 20:50] = 1
+    net.eval()
+    with torch.no_grad():
+        dyn_eval = net.meta_forward(metax, mask)[0]
+        out_eval = net.detect_forward(x, [dyn_eval])
+    net.train()
+    dyn_train = net.meta_forward(metax, mask)[0]
+    out_train = net.detect_forward(x, [dyn_train])
+    g = torch.randn(out_train.shape, generator=torch.Generator().manual_seed(33))
+    out_train.backward(g)
+    sd = net.state_dict()
+    grads = {k: p.grad.numpy() for k, p in net.named_parameters()
+             if k in ("models.0.conv1.weight", "models.0.bn1.weight", "models.0.bn1.bias",
+                      "models.21.conv17.weight", "models.23.conv19.weight", "models.23.conv19.bias",
+                      "learnet_models.0.conv1.weight", "learnet_models.10.conv6.weight",
+                      "learnet_models.10.bn6.weight")}
+    np.savez_compressed(os.path.join(HERE, "mini_forward.npz"), x=x.numpy(), metax=metax.numpy(), mask=mask.numpy(),
+             dyn_eval=dyn_eval.numpy(), out_eval=out_eval.numpy(),
+             dyn_train=dyn_train.detach().numpy(), out_train=out_train.detach().numpy(),
+             grad_out=g.numpy(),
+             bn1_mean_after=sd["models.0.bn1.running_mean"].numpy(),
+             bn1_var_after=sd["models.0.bn1.running_var"].numpy(),
+             lbn6_mean_after=sd["learnet_models.10.bn6.running_mean"].numpy(),
+             lbn6_var_after=sd["learnet_models.10.bn6.running_var"].numpy(),
+             **{"grad:" + k: v for k, v in grads.items()})
+
+
+def gold_mini_yolo(dk):
+    torch.manual_seed(4)
+    net = dk.Darknet(os.path.join(HERE, "mini_tiny_yolo.cfg"))
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    net.save_weights(os.path.join(HERE, "mini_yolo.weights"))
+    x = torch.rand(2, 3, 64, 64)
+    net.eval()
+    with torch.no_grad():
+        out_eval = net(x)
+    net.train()
+    out_train = net(x)
+    np.savez_compressed(os.path.join(HERE, "mini_yolo_forward.npz"), x=x.numpy(), out_eval=out_eval.numpy(),
+             out_train=out_train.detach().numpy())
+
+
+def _run_loss(rl, module, out, tgt):
+    captured = {}
+    orig = rl.build_targets
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        captured["bt"] = r
+        return r
+
+    rl.build_targets = spy
+    try:
+        out = out.clone().requires_grad_(True)
+        loss = module(out, tgt)
+        loss.backward()
+    finally:
+        rl.build_targets = orig
+    names = ["nGT", "nCorrect", "coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"]
+    res = {"loss": np.float32(loss.item()), "grad": out.grad.numpy()}
+    for n, v in zip(names, captured["bt"]):
+        res[n] = v.numpy() if torch.is_tensor(v) else np.int64(v)
+    return res
+
+
+def gold_region_v2(rl, cfgmod):
+    rng = np.random.RandomState(5)
+    bs, cs, g = 3, 4, 13
+    dense = synth_targets(rng, bs, cs)
+    torch.manual_seed(5)
+    out = torch.randn(bs * cs, 30, g, g) * 0.7
+    # make a few predictions overlap their ground truth strongly so the silence rule fires
+    out[:, 2::6] *= 0.3
+    out[:, 3::6] *= 0.3
+    mod = rl.RegionLossV2()
+    mod.anchors, mod.num_anchors, mod.num_classes, mod.anchor_step = ANCH, 5, 1, 2
+    cases = [("full_seen0", "full", 0), ("full_seen20000", "full", 20000),
+             ("neg0_seen20000", 0, 20000), ("neg1_seen20000", 1, 20000)]
+    sparse = synth_targets(np.random.RandomState(55), bs, cs, max_per_img=1, same_cell=False)
+    for name, neg, seen in cases:
+        cfgmod.cfg.neg_ratio = neg
+        mod.seen = seen
+        random.seed(77)
+        tgt = sparse if name.startswith("neg1") else dense   # few positives -> the random drop path runs
+        res = _run_loss(rl, mod, out, torch.from_numpy(tgt))
+        np.savez_compressed(os.path.join(HERE, "region_v2_%s.npz" % name), output=out.numpy(), target=tgt,
+                 neg_ratio=str(neg), seen=seen, py_seed=77, **res)
+    cfgmod.cfg.neg_ratio = "full"
+
+
+def gold_region_v1(rl, cfgmod):
+    rng = np.random.RandomState(6)
+    bs, nc, g = 2, 3, 13
+    tgt = synth_targets(rng, bs, 1, same_cell=False)[:, 0]
+    tgt[:, 0::5] = np.where(tgt[:, 1::5] != 0, rng.randint(0, nc, tgt[:, 0::5].shape), 0)
+    torch.manual_seed(6)
+    out = torch.randn(bs, 5 * (5 + nc), g, g) * 0.7
+    mod = rl.RegionLoss(nc, ANCH_V1, 5)
+    cfgmod.cfg.neg_ratio = "full"
+    for name, meta, seen in [("seen0", False, 0), ("seen20000", False, 20000), ("metayolo", True, 20000)]:
+        cfgmod.cfg.metayolo = meta
+        mod.seen = seen
+        res = _run_loss(rl, mod, out, torch.from_numpy(tgt))
+        np.savez_compressed(os.path.join(HERE, "region_v1_%s.npz" % name), output=out.numpy(), target=tgt,
+                 metayolo=meta, seen=seen, **res)
+    cfgmod.cfg.metayolo = True
+
+
+def gold_decode(u):
+    torch.manual_seed(7)
+    bs, cs, g = 2, 3, 13
+    out = torch.randn(bs * cs, 30, g, g)
+    boxes = u.get_region_boxes_v2(out, cs, 0.3, 1, ANCH, 5)
+    flat = []
+    for r, bl in enumerate(boxes):
+        for bx in bl:
+            flat.append([r] + [float(v) for v in bx])
+    kept = []
+    for r, bl in enumerate(boxes):
+        for bx in u.nms(bl, 0.45):
+            kept.append([r] + [float(v) for v in bx])
+    np.savez_compressed(os.path.join(HERE, "decode_v2.npz"), output=out.numpy(), n_models=cs, conf_thresh=0.3,
+             nms_thresh=0.45, boxes=np.array(flat, np.float64), kept=np.array(kept, np.float64))
+
+
+def main():
+    assert ref_shim.available(), "needs /root/reference"
+    u = ref_shim.load("utils")
+    cfgmod = ref_shim.load("cfg")
+    rl = ref_shim.load("region_loss")
+    dc = ref_shim.load("dynamic_conv")
+    dm = ref_shim.load("darknet_meta")
+    dk = ref_shim.load("darknet")
+    gold_boxes(u)
+    gold_dconv(dc)
+    gold_mini_forward(dm)
+    gold_mini_yolo(dk)
+    gold_region_v2(rl, cfgmod)
+    gold_region_v1(rl, cfgmod)
+    gold_decode(u)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
