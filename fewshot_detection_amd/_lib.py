@@ -1,0 +1,70 @@
+"""ctypes binding of libfsdet_hip.so (include/fsdet.h).  Loaded lazily; fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsdet_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_ll = C.c_longlong
+_f = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/fsdet.h declares (tests check)
+PROTOTYPES = {
+    "fsd_region_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "fsd_region_loss_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p,
+                                     _f, _f, _f, _f, _f, _ll, _i, _i, _i, _p, _p]),
+    "fsd_packed_weight_elems": (_sz, [_i, _i, _i]),
+    "fsd_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "fsd_conv_row_tiles": (_i, [_ll, _i]),
+    "fsd_conv2d_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_bn_finalize_workspace_bytes": (_sz, [_i]),
+    "fsd_bn_finalize": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
+    "fsd_bn_act_pool_fwd": (_i, [_p, _ll, _p, _p, _f, _i, _p, _ll, _i, _i, _i, _i, _p]),
+    "fsd_transpose_batched": (_i, [_p, _ll, _ll, _p, _ll, _ll, _i, _i, _i, _p]),
+    "fsd_fill": (_i, [_p, _f, _ll, _p]),
+    "fsd_reorg_fwd": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
+    "fsd_global_maxpool_fwd": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_dynamic_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_fold_reweight_head": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fsd_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class FsdetLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises FsdetLibraryError (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise FsdetLibraryError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fewshot_detection_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise FsdetLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise FsdetLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+_ERR = {-1: "FSD_ERR_ARG (bad argument)", -2: "FSD_ERR_UNSUPPORTED", -3: "FSD_ERR_WORKSPACE (too small)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

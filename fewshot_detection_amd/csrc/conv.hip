@@ -1,0 +1,332 @@
+// Convolution (3x3 / 1x1, stride 1, "same" padding) as an im2col-free implicit GEMM on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s chip peak).
+//
+//   M = B*H*W output pixels, N = Cout, K = taps * Cin.   Activations are NHWC, weights are
+//   pre-packed [Cout][tap][Cin] ("K-major" on both sides), so every 16-byte global load is a
+//   run of 4 input channels of one filter tap and both operands land in LDS as [row][k] tiles.
+//   LDS rows are padded 32 -> 36 floats: the ds_read_b128 fragment reads (lane = row, 16 B at a
+//   144-B stride) then touch 16 distinct 16-B slots per lane group, i.e. conflict-free.
+//   A lane feeds 4 consecutive k of its row to 4 MFMAs (lanes 0-31: k..k+3, lanes 32-63:
+//   k+4..k+7), so one b128 read per operand tile supplies four matrix instructions.
+//
+// The same kernel produces: forward convs (+bias, + per-tile BatchNorm partial sums in the
+// epilogue), data gradients (weights packed flipped/transposed), and the fused
+// reweighting (x) 1x1 detection head with an NCHW store (operands swapped in the MFMA so the
+// accumulator comes out transposed and the store stays coalesced).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsdet.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBK = 32;      // k-chunk (floats) staged per LDS buffer
+constexpr int kLd = 36;      // padded LDS row stride (floats)
+constexpr int kThreads = 256;
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  float* bn_partial;
+  long long x_ld, y_ld;
+  int H, W, HW, M;
+  int Cout, ks, pad;
+  int cpg;       // 16-byte channel groups per tap  (Cin/4)
+  int kgroups;   // taps * cpg
+  int nk;        // k-chunks
+  int Kpad;      // packed weight row length (floats)
+  int m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  // consecutive logical tiles on one XCD (own L2): dispatch places block b on XCD b % 8
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT>
+__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
+  static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves");
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int A_PER_T = BM / 32;   // float4 loads per thread per chunk
+  constexpr int B_PER_T = BN / 32;
+  constexpr int STAGE = (BM + BN) * kLd;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int kq = tid & 7, r0 = tid >> 3;
+
+  int a_y[A_PER_T], a_x[A_PER_T];
+  long long a_base[A_PER_T];
+#pragma unroll
+  for (int j = 0; j < A_PER_T; ++j) {
+    const int pix = m0 + r0 + 32 * j;
+    const int b = pix / p.HW;
+    const int rem = pix - b * p.HW;
+    const int yy = rem / p.W;
+    a_y[j] = pix < p.M ? yy : -(1 << 20);       // out-of-range rows fail the bounds test below
+    a_x[j] = rem - yy * p.W;
+    a_base[j] = (long long)b * p.HW;
+  }
+  const float* wrow = p.w + (long long)(n0 + r0) * p.Kpad + kq * 4;
+
+  f32x4 ra[A_PER_T], rb[B_PER_T];
+  auto gload = [&](int kc) {
+    const int kg = kc * 8 + kq;
+    const int tap = kg / p.cpg;
+    const int c4 = kg - tap * p.cpg;
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int dy = ky - p.pad, dx = kx - p.pad;
+    const bool kvalid = kg < p.kgroups;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const int iy = a_y[j] + dy, ix = a_x[j] + dx;
+      const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      // unconditional load from a clamped address + select: keeps the loads branch-free and in flight
+      const long long off = ok ? (a_base[j] + (long long)iy * p.W + ix) * p.x_ld + c4 * 4 : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
+      ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j)
+      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+  };
+  auto sstore = [&](float* st) {
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j)
+      *reinterpret_cast<f32x4*>(st + (r0 + 32 * j) * kLd + kq * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j)
+      *reinterpret_cast<f32x4*>(st + (BM + r0 + 32 * j) * kLd + kq * 4) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_off = (lane & 31) * kLd + (lane >> 5) * 4;
+  auto compute = [&](const float* st) {
+    const float* sa = st + (wm * TM * 32) * kLd + frag_off;
+    const float* sb = st + (BM + wn * TN * 32) * kLd + frag_off;
+#pragma unroll
+    for (int k8 = 0; k8 < kBK / 8; ++k8) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * kLd + k8 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * kLd + k8 * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = NCHW_OUT
+                            ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: register-staged double buffer, one barrier per k-chunk
+  gload(0);
+  sstore(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int kc = 0; kc < p.nk; ++kc) {
+    const bool more = kc + 1 < p.nk;
+    if (more) gload(kc + 1);
+    compute(smem + cur * STAGE);
+    if (more) sstore(smem + (cur ^ 1) * STAGE);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+  if constexpr (!NCHW_OUT) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + c_lane;
+      const bool n_ok = n < p.Cout;
+      const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          if (n_ok && m < p.M) p.y[(long long)m * p.y_ld + n] = acc[i][j][r] + bv;
+        }
+      }
+    }
+    if (p.bn_partial != nullptr) {
+      // per-tile column sums of the raw outputs (rows past M hold exact zeros)
+      float* s_stat = smem;    // [WAVES_M][BN][2]; the main loop's last barrier freed the staging LDS
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32) {
+          const int col = (wn * TN + j) * 32 + c_lane;
+          s_stat[(wm * BN + col) * 2 + 0] = s;
+          s_stat[(wm * BN + col) * 2 + 1] = q;
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s += s_stat[(w * BN + tid) * 2 + 0];
+          q += s_stat[(w * BN + tid) * 2 + 1];
+        }
+        const int n = n0 + tid;
+        if (n < p.Cout) {
+          float* dst = p.bn_partial + ((long long)mt * p.Cout + n) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
+      }
+    }
+  } else {
+    // transposed accumulator: rows = output channels, cols = pixels -> NCHW store, pixel-contiguous
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + c_lane;
+      const int b = m / p.HW;
+      const int hw = m - b * p.HW;
+      const bool m_ok = m < p.M;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wn * TN + j) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          if (m_ok && n < p.Cout) {
+            const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+            p.y[((long long)b * p.Cout + n) * p.HW + hw] = acc[i][j][r] + bv;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
+                                   int ks, int mode, int rows_pad, int red4, int kpad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows_pad * kpad) return;
+  const int row = (int)(idx / kpad), k = (int)(idx - (long long)row * kpad);
+  const int taps = ks * ks;
+  const int tap = k / red4, r = k - tap * red4;
+  const int rows = mode == 0 ? cout : cin, red = mode == 0 ? cin : cout;
+  float v = 0.f;
+  if (row < rows && tap < taps && r < red) {
+    const int ky = tap / ks, kx = tap - ky * ks;
+    if (mode == 0)
+      v = w[(((long long)row * cin + r) * ks + ky) * ks + kx];
+    else   // data gradient: correlate dy with the 180-degree rotated filter, channels swapped
+      v = w[(((long long)r * cin + row) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+  }
+  out[idx] = v;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// tile shape by output width: narrow layers get tall tiles so the MFMA work per staged byte stays high
+inline int tile_cfg(int cout) { return cout <= 32 ? 2 : (cout <= 64 ? 1 : 0); }
+inline int tile_bm(int cfg) { return cfg == 0 ? 128 : 256; }
+inline int tile_bn(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(BM + BN) * kLd * sizeof(float);
+  const int grid = a.m_tiles * a.n_tiles;
+  if (nchw) {
+    auto k = conv_gemm_kernel<BM, BN, WM, WN, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, stream, a);
+  } else {
+    auto k = conv_gemm_kernel<BM, BN, WM, WN, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t fsd_packed_weight_elems(int rows, int red, int ksize) {
+  return (size_t)round_up(rows, 128) * (size_t)round_up(ksize * ksize * round_up(red, 4), kBK);
+}
+
+extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ksize,
+                                    int mode, hipStream_t stream) {
+  if (!w_oihw || !w_packed || cout < 1 || cin < 1 || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1))
+    return FSD_ERR_ARG;
+  const int rows = mode == 0 ? cout : cin, red = mode == 0 ? cin : cout;
+  const int rows_pad = round_up(rows, 128), red4 = round_up(red, 4);
+  const int kpad = round_up(ksize * ksize * red4, kBK);
+  const long long total = (long long)rows_pad * kpad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw,
+                     w_packed, cout, cin, ksize, mode, rows_pad, red4, kpad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_conv_row_tiles(long long pixels, int cout) {
+  const int bm = tile_bm(tile_cfg(cout));
+  return (int)((pixels + bm - 1) / bm);
+}
+
+extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const float* bias,
+                              float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
+                              int cin, int cout, int ksize, int out_nchw, hipStream_t stream) {
+  if (!x || !w_packed || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
+  if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
+  if (cin < 4 || (cin & 3) || (x_ld & 3) || x_ld < cin) return FSD_ERR_ARG;
+  if (!out_nchw && y_ld < cout) return FSD_ERR_ARG;
+  if (out_nchw && bn_partial) return FSD_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15)) return FSD_ERR_ARG;
+  const long long pixels = (long long)batch * height * width;
+  if (pixels > 0x7fffffffLL - 512) return FSD_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.bn_partial = bn_partial;
+  a.x_ld = x_ld; a.y_ld = y_ld;
+  a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
+  a.Cout = cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
+  a.cpg = cin / 4;
+  a.kgroups = ksize * ksize * a.cpg;
+  a.Kpad = round_up(ksize * ksize * cin, kBK);
+  a.nk = a.Kpad / kBK;
+  const int cfg = tile_cfg(cout);
+  const int bm = tile_bm(cfg), bn = tile_bn(cfg);
+  a.m_tiles = (int)((pixels + bm - 1) / bm);
+  a.n_tiles = (cout + bn - 1) / bn;
+  switch (cfg) {
+    case 0: return launch<128, 128, 2, 2>(a, out_nchw != 0, stream);
+    case 1: return launch<256, 64, 4, 1>(a, out_nchw != 0, stream);
+    default: return launch<256, 32, 4, 1>(a, out_nchw != 0, stream);
+  }
+}

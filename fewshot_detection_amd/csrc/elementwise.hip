@@ -1,0 +1,303 @@
+// HBM-bound companions of the conv kernel: BatchNorm statistics finalisation, the fused
+// affine + leaky + maxpool pass, layout transposes, reorg, global max pool and the
+// channel-reweighting helpers.  All NHWC / float4-vectorised where the layout allows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsdet.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBnSlots = 64;
+
+inline unsigned blocks_for(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---- BN statistics -----------------------------------------------------------------------
+// stage 1: fold the [tiles][C][2] float partials of the conv epilogue into [64][C][2] doubles
+__global__ void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ slots, int tiles,
+                                 int two_c) {
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  const int s = blockIdx.x;
+  if (e >= two_c) return;
+  double acc = 0.0;
+  for (int t = s; t < tiles; t += kBnSlots) acc += (double)partial[(long long)t * two_c + e];
+  slots[(long long)s * two_c + e] = acc;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   int training, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < n_slots; ++k) {
+      s += slots[((long long)k * channels + c) * 2 + 0];
+      q += slots[((long long)k * channels + c) * 2 + 1];
+    }
+    mean = s / count;
+    var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+  scale[c] = (float)(g * invstd);
+  shift[c] = (float)(b - mean * g * invstd);
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_invstd) save_invstd[c] = (float)invstd;
+}
+
+// ---- affine + activation + pool ------------------------------------------------------------
+__device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 sc, f32x4 sh, float slope) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = v[k] * sc[k] + sh[k];
+    r[k] = t > 0.f ? t : t * slope;
+  }
+  return r;
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restrict__ y, long long y_ld,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          float* __restrict__ z, long long z_ld, int H, int W,
+                                                          int OH, int OW, int cg, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % cg);
+  const long long opix = idx / cg;
+  const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + g * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 out;
+  if constexpr (POOL == 0) {
+    out = affine_act(*reinterpret_cast<const f32x4*>(y + opix * y_ld + g * 4), sc, sh, slope);
+  } else {
+    const int ox = (int)(opix % OW);
+    const long long t = opix / OW;
+    const int oy = (int)(t % OH);
+    const long long b = t / OH;
+    const int y0 = POOL == 1 ? 2 * oy : oy, x0 = POOL == 1 ? 2 * ox : ox;
+    const int y1 = (y0 + 1 < H) ? y0 + 1 : H - 1, x1 = (x0 + 1 < W) ? x0 + 1 : W - 1;   // replicate pad (stride 1)
+    const float* base = y + (b * H * (long long)W) * y_ld + g * 4;
+    const f32x4 v00 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * y_ld), sc, sh, slope);
+    const f32x4 v01 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x1) * y_ld), sc, sh, slope);
+    const f32x4 v10 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * y_ld), sc, sh, slope);
+    const f32x4 v11 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * y_ld), sc, sh, slope);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+  }
+  *reinterpret_cast<f32x4*>(z + opix * z_ld + g * 4) = out;
+}
+
+// ---- batched 2-D transpose through LDS (NCHW <-> NHWC) ---------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long long sbs, long long srs,
+                                                        float* __restrict__ dst, long long dbs, long long drs,
+                                                        int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const float* s = src + (long long)b * sbs;
+  float* d = dst + (long long)b * dbs;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = s[(long long)r * srs + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < rows && c < cols) d[(long long)c * drs + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+__global__ void fill_kernel(float* dst, float v, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) dst[i] = v;
+}
+
+// ---- reorg (space to depth), NHWC ------------------------------------------------------------
+__global__ void reorg_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ out, long long out_ld,
+                             int H, int W, int C, int s, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C / 4;
+  const int g = (int)(idx % cg);
+  long long t = idx / cg;
+  const int ix = (int)(t % W); t /= W;
+  const int iy = (int)(t % H);
+  const long long b = t / H;
+  const int OH = H / s, OW = W / s;
+  const int oi = iy / s, di = iy - oi * s, oj = ix / s, dj = ix - oj * s;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4);
+  *reinterpret_cast<f32x4*>(out + ((b * OH + oi) * (long long)OW + oj) * out_ld + (di * s + dj) * C + g * 4) = v;
+}
+
+// ---- global max pool: (B, HW, C) -> (B, C) -----------------------------------------------------
+__global__ void global_max_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ out,
+                                  int* __restrict__ argmax, int HW, int C, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long b = idx / C;
+  const float* p = x + b * HW * x_ld + c;
+  float best = p[0];
+  int arg = 0;
+  for (int i = 1; i < HW; ++i) {
+    const float v = p[(long long)i * x_ld];
+    if (v > best || v != v) { best = v; arg = i; }
+  }
+  out[idx] = best;
+  if (argmax) argmax[idx] = arg;
+}
+
+// ---- channel reweighting ------------------------------------------------------------------
+__global__ void dynamic_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
+                                    int n_cls, int C, int hw, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, n, c, hw)
+  if (idx >= total) return;
+  const int p = (int)(idx % hw);
+  long long t = idx / hw;
+  const int c = (int)(t % C); t /= C;
+  const int n = (int)(t % n_cls);
+  const long long b = t / n_cls;
+  out[idx] = x[(b * C + c) * hw + p] * w[(long long)n * C + c];
+}
+
+__global__ void fold_head_kernel(const float* __restrict__ head_w, const float* __restrict__ head_b,
+                                 const float* __restrict__ dyn, float* __restrict__ w_eff, float* __restrict__ b_eff,
+                                 int n_cls, int O, int C, int rows_pad, int kpad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows_pad * kpad) return;
+  const int row = (int)(idx / kpad), k = (int)(idx - (long long)row * kpad);
+  float v = 0.f;
+  if (row < n_cls * O && k < C) {
+    const int n = row / O, o = row - n * O;
+    v = head_w[(long long)o * C + k] * dyn[(long long)n * C + k];
+  }
+  w_eff[idx] = v;
+  if (k == 0 && row < n_cls * O && b_eff) b_eff[row] = head_b ? head_b[row % O] : 0.f;
+}
+
+}  // namespace
+
+extern "C" size_t fsd_bn_finalize_workspace_bytes(int channels) {
+  return (size_t)kBnSlots * channels * 2 * sizeof(double);
+}
+
+extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long count, int channels,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, int training, float* scale, float* shift,
+                               float* save_mean, float* save_invstd, void* workspace, hipStream_t stream) {
+  if (!scale || !shift || channels < 1 || !running_mean || !running_var) return FSD_ERR_ARG;
+  int n_slots = 0;
+  if (training) {
+    if (!bn_partial || !workspace || row_tiles < 1 || count < 1) return FSD_ERR_ARG;
+    n_slots = row_tiles < kBnSlots ? row_tiles : kBnSlots;
+    const int two_c = 2 * channels;
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, bn_partial,
+                       reinterpret_cast<double*>(workspace), row_tiles, two_c);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
+                     reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_invstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, const float* shift,
+                                   float slope, int pool, float* z, long long z_ld, int batch, int height,
+                                   int width, int channels, hipStream_t stream) {
+  if (!y || !z || batch < 1 || channels < 4 || (channels & 3) || (y_ld & 3) || (z_ld & 3)) return FSD_ERR_ARG;
+  if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
+  const int OH = pool == 1 ? height / 2 : height, OW = pool == 1 ? width / 2 : width;
+  if (OH < 1 || OW < 1) return FSD_ERR_ARG;
+  const int cg = channels / 4;
+  const long long total = (long long)batch * OH * OW * cg;
+  const dim3 grid(blocks_for(total, 256)), block(256);
+  if (pool == 0)
+    hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+  else if (pool == 1)
+    hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+  else
+    hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
+                                     float* dst, long long dst_batch_stride, long long dst_row_stride, int batch,
+                                     int rows, int cols, hipStream_t stream) {
+  if (!src || !dst || batch < 1 || rows < 1 || cols < 1 || batch > 65535) return FSD_ERR_ARG;
+  const dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
+                     dst_batch_stride, dst_row_stride, rows, cols);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_fill(float* dst, float value, long long count, hipStream_t stream) {
+  if (!dst || count < 0) return FSD_ERR_ARG;
+  if (count == 0) return FSD_OK;
+  long long blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, value, count);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, int batch, int height,
+                             int width, int channels, int stride, hipStream_t stream) {
+  if (!x || !out || stride < 1 || height % stride || width % stride || (channels & 3) || (x_ld & 3) || (out_ld & 3))
+    return FSD_ERR_ARG;
+  const long long total = (long long)batch * height * width * (channels / 4);
+  hipLaunchKernelGGL(reorg_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, out_ld, height,
+                     width, channels, stride, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch, int height,
+                                      int width, int channels, hipStream_t stream) {
+  if (!x || !out || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
+  if (height != width) return FSD_ERR_UNSUPPORTED;   // pooling.py:23-27 assumes a square map
+  const long long total = (long long)batch * channels;
+  hipLaunchKernelGGL(global_max_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, argmax,
+                     height * width, channels, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,
+                                    int hw, hipStream_t stream) {
+  if (!x || !w || !out || batch < 1 || n_cls < 1 || channels < 1 || hw < 1) return FSD_ERR_ARG;
+  const long long total = (long long)batch * n_cls * channels * hw;
+  hipLaunchKernelGGL(dynamic_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, w, out, n_cls,
+                     channels, hw, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_fold_reweight_head(const float* head_w, const float* head_b, const float* dyn,
+                                      float* w_eff_packed, float* bias_eff, int n_cls, int out_ch, int channels,
+                                      hipStream_t stream) {
+  if (!head_w || !dyn || !w_eff_packed || n_cls < 1 || out_ch < 1 || channels < 4 || (channels & 3)) return FSD_ERR_ARG;
+  const int rows_pad = (n_cls * out_ch + 127) / 128 * 128;
+  const int kpad = (channels + 31) / 32 * 32;
+  const long long total = (long long)rows_pad * kpad;
+  hipLaunchKernelGGL(fold_head_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, head_w, head_b, dyn,
+                     w_eff_packed, bias_eff, n_cls, out_ch, channels, rows_pad, kpad);
+  return (int)hipGetLastError();
+}
+
+extern "C" const char* fsd_version(void) { return "fsdet-hip 0.1 (gfx950)"; }

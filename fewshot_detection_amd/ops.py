@@ -1,0 +1,173 @@
+"""Thin tensor-level wrappers over the C-ABI.  Every function launches on the current torch HIP
+stream and never synchronises.  Tensors are raw storage here: layouts are documented per op."""
+import torch
+
+from ._lib import check, lib
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fewshot_detection_amd ops need HIP device tensors (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+class View(object):
+    """NHWC activation: `t` is a 2-D (pixels, ld) buffer, channels [c0, c0+C) of each pixel."""
+    __slots__ = ("t", "B", "H", "W", "C", "c0")
+
+    def __init__(self, t, B, H, W, C, c0=0):
+        self.t, self.B, self.H, self.W, self.C, self.c0 = t, B, H, W, C, c0
+
+    @property
+    def ld(self):
+        return self.t.shape[1]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.c0
+
+    @property
+    def pixels(self):
+        return self.B * self.H * self.W
+
+    def dense(self):
+        return self.t[:, self.c0:self.c0 + self.C]
+
+
+def new_view(B, H, W, C, device, ld=None):
+    return View(torch.empty((B * H * W, ld or C), dtype=torch.float32, device=device), B, H, W, C)
+
+
+def nchw_to_nhwc(x, pad_to=4, out=None):
+    """(B,C,H,W) contiguous -> View with channels padded (zeros) to a multiple of `pad_to`."""
+    require_device(x)
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    Cp = (Cc + pad_to - 1) // pad_to * pad_to
+    if out is None:
+        out = new_view(B, H, W, Cp, x.device)
+        if Cp != Cc:
+            check(lib().fsd_fill(out.t.data_ptr(), 0.0, out.t.numel(), _stream()), "fsd_fill")
+    check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, out.ptr, H * W * out.ld, out.ld,
+                                      B, Cc, H * W, _stream()), "fsd_transpose_batched")
+    return out
+
+
+def write_channels(x, view, c_off):
+    """Scatter an NCHW tensor into channels [c_off, c_off+C) of an existing NHWC view."""
+    B, Cc, H, W = x.shape
+    x = x.contiguous()
+    check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, view.ptr + 4 * c_off, H * W * view.ld,
+                                      view.ld, B, Cc, H * W, _stream()), "fsd_transpose_batched")
+
+
+def nhwc_to_nchw(v):
+    out = torch.empty((v.B, v.C, v.H, v.W), dtype=torch.float32, device=v.t.device)
+    hw = v.H * v.W
+    check(lib().fsd_transpose_batched(v.ptr, hw * v.ld, v.ld, out.data_ptr(), v.C * hw, hw, v.B, hw, v.C,
+                                      _stream()), "fsd_transpose_batched")
+    return out
+
+
+def pack_weight(w, mode=0):
+    """(Cout,Cin,k,k) -> packed K-major operand of fsd_conv2d_fwd (mode 0) / its data gradient (mode 1)."""
+    require_device(w)
+    cout, cin, k, _ = w.shape
+    rows, red = (cout, cin) if mode == 0 else (cin, cout)
+    out = torch.empty(lib().fsd_packed_weight_elems(rows, red, k), dtype=torch.float32, device=w.device)
+    check(lib().fsd_pack_conv_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()),
+          "fsd_pack_conv_weight")
+    return out
+
+
+def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False):
+    """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out)."""
+    dev = xv.t.device
+    partial = None
+    if nchw_out:
+        y = torch.empty((xv.B, cout, xv.H, xv.W), dtype=torch.float32, device=dev)
+        y_ptr, y_ld = y.data_ptr(), 0
+    else:
+        y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
+        y_ptr, y_ld = y.ptr, y.ld
+    if bn_partial:
+        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout)
+        partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
+    check(lib().fsd_conv2d_fwd(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+                               xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()),
+          "fsd_conv2d_fwd")
+    return y, partial
+
+
+def bn_finalize(partial, count, bn, training):
+    """-> (scale, shift, save_mean, save_invstd) for nn.BatchNorm2d-like `bn` (updates running stats)."""
+    Cc = bn.num_features
+    dev = bn.weight.device
+    buf = torch.empty((4, Cc), dtype=torch.float32, device=dev)
+    ws = None
+    tiles = 0
+    if training:
+        ws = torch.empty(lib().fsd_bn_finalize_workspace_bytes(Cc) // 8, dtype=torch.float64, device=dev)
+        tiles = partial.shape[0]
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    check(lib().fsd_bn_finalize(_ptr(partial), tiles, count, Cc, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), momentum, bn.eps,
+                                1 if training else 0, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(),
+                                buf[3].data_ptr(), _ptr(ws), _stream()), "fsd_bn_finalize")
+    return buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_act_pool(yv, scale, shift, slope, pool, out=None):
+    OH, OW = (yv.H // 2, yv.W // 2) if pool == 1 else (yv.H, yv.W)
+    z = out if out is not None else new_view(yv.B, OH, OW, yv.C, yv.t.device)
+    check(lib().fsd_bn_act_pool_fwd(yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, z.ptr, z.ld,
+                                    yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_act_pool_fwd")
+    return z
+
+
+def reorg(xv, stride, out=None):
+    z = out if out is not None else new_view(xv.B, xv.H // stride, xv.W // stride, xv.C * stride * stride,
+                                             xv.t.device)
+    check(lib().fsd_reorg_fwd(xv.ptr, xv.ld, z.ptr, z.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()),
+          "fsd_reorg_fwd")
+    return z
+
+
+def global_maxpool(xv, want_argmax=False):
+    out = torch.empty((xv.B, xv.C), dtype=torch.float32, device=xv.t.device)
+    arg = torch.empty((xv.B, xv.C), dtype=torch.int32, device=xv.t.device) if want_argmax else None
+    check(lib().fsd_global_maxpool_fwd(xv.ptr, xv.ld, out.data_ptr(), _ptr(arg), xv.B, xv.H, xv.W, xv.C,
+                                       _stream()), "fsd_global_maxpool_fwd")
+    return out, arg
+
+
+def dynamic_conv(x, w):
+    """Materialising reweighting on NCHW tensors: out[b*N+n,c,h,w] = x[b,c,h,w] * w[n,c]."""
+    require_device(x, w)
+    B, Cc, H, W = x.shape
+    N = w.shape[0]
+    out = torch.empty((B * N, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(lib().fsd_dynamic_conv_fwd(x.contiguous().data_ptr(), w.contiguous().data_ptr(), out.data_ptr(),
+                                     B, N, Cc, H * W, _stream()), "fsd_dynamic_conv_fwd")
+    return out
+
+
+def fold_reweight_head(head_w, head_b, dyn):
+    """-> (w_eff_packed, bias_eff) for the fused reweighting (x) 1x1 head GEMM."""
+    O, Cc = head_w.shape[0], head_w.shape[1]
+    N = dyn.shape[0]
+    w_eff = torch.empty(lib().fsd_packed_weight_elems(N * O, Cc, 1), dtype=torch.float32, device=dyn.device)
+    b_eff = torch.empty(N * O, dtype=torch.float32, device=dyn.device)
+    check(lib().fsd_fold_reweight_head(head_w.contiguous().data_ptr(), _ptr(head_b), dyn.contiguous().data_ptr(),
+                                       w_eff.data_ptr(), b_eff.data_ptr(), N, O, Cc, _stream()),
+          "fsd_fold_reweight_head")
+    return w_eff, b_eff

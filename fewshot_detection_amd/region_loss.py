@@ -1,0 +1,174 @@
+"""RegionLoss / RegionLossV2 with the reference's interface (region_loss.py:134-366) on top of
+the fused HIP kernel fsd_region_loss_fwd_bwd: decode, IoU silence test, anchor assignment,
+objectness / box terms, the softmax over the N episode classes and the gradient are computed on
+the device in one pass; nothing is copied back to the host unless the stats line is printed.
+
+Globals read at call time, as in the reference: cfg.neg_ratio, cfg.metayolo, cfg.max_boxes.
+"""
+from numbers import Number
+from random import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import check, lib
+from .cfg import cfg
+
+
+def neg_filter_indices(target_rows):
+    """Host half of reference neg_filter (region_loss.py:15-34): which (image, class) rows keep
+    their box/objectness loss.  `target_rows`: (R, L) array on the host.  python's global
+    `random()` is consumed once per negative row, in row order, exactly like the reference."""
+    n_rows = target_rows.shape[0]
+    if cfg.neg_ratio == "full":
+        return list(range(n_rows))
+    if not isinstance(cfg.neg_ratio, Number):
+        raise NotImplementedError("neg_ratio not recognized")
+    pos = (np.asarray(target_rows, dtype=np.float64).sum(axis=1) != 0).tolist()
+    n_pos = sum(pos)
+    if n_pos == n_rows:
+        return list(range(n_rows))
+    ratio = cfg.neg_ratio * n_pos * 1.0 / (n_rows - n_pos)
+    if ratio >= 1:
+        return list(range(n_rows))
+    return [i for i, p in enumerate(pos) if p or not (random() > ratio)]
+
+
+def _validate_targets(rows):
+    """The reference raises (math.log domain error / bad index) on these; say why instead."""
+    cx = rows[:, 1::5]
+    w, h = rows[:, 3::5], rows[:, 4::5]
+    n = min(cx.shape[1], w.shape[1], h.shape[1])
+    live = np.cumprod(cx[:, :n] != 0, axis=1).astype(bool)
+    if np.any(live & ((w[:, :n] <= 0) | (h[:, :n] <= 0))):
+        raise ValueError("region loss target has a box with non-positive width/height")
+    cy = rows[:, 2::5][:, :n]
+    if np.any(live & ((cx[:, :n] < 0) | (cx[:, :n] >= 1) | (cy < 0) | (cy >= 1))):
+        raise ValueError("region loss target has a box centre outside [0, 1)")
+
+
+class _RegionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target_dev, keep_dev, mod, rows_per_image, softmax_over_rows, zero_tcls, dbg):
+        ops.require_device(output)
+        out = output.contiguous()
+        rows, chans, H, W = out.shape
+        A, Cn = mod.num_anchors, mod.num_classes
+        if chans != A * (5 + Cn):
+            raise ValueError("output has %d channels, expected %d" % (chans, A * (5 + Cn)))
+        L = lib()
+        ws_bytes = L.fsd_region_loss_workspace_bytes(rows, rows_per_image, A, H, W)
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=out.device)
+        grad = torch.empty_like(out)
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        anchors = (np.ctypeslib.as_ctypes(np.asarray(mod.anchors, dtype=np.float64)[:2 * A].copy())
+                   if int(mod.anchor_step) == 2 else None)
+        if anchors is None:
+            raise NotImplementedError("anchor_step != 2 is not used by any shipped cfg")
+        check(L.fsd_region_loss_fwd_bwd(
+            out.data_ptr(), target_dev.data_ptr(), keep_dev.data_ptr(), grad.data_ptr(), loss.data_ptr(),
+            ws.data_ptr(), ws_bytes, rows, rows_per_image, A, Cn, H, W, target_dev.shape[1], anchors,
+            float(mod.coord_scale), float(mod.noobject_scale), float(mod.object_scale), float(mod.class_scale),
+            float(mod.thresh), int(mod.seen), int(cfg.max_boxes), int(softmax_over_rows), int(zero_tcls),
+            0 if dbg is None else dbg.data_ptr(), torch.cuda.current_stream().cuda_stream),
+            "fsd_region_loss_fwd_bwd")
+        ctx.save_for_backward(grad)
+        mod._stats = ws[:16]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None, None
+
+
+class _RegionBase(nn.Module):
+    verbose = True       # print the reference's per-batch stats line (costs one device->host sync)
+
+    def __init__(self, num_classes=0, anchors=(), num_anchors=1):
+        super(_RegionBase, self).__init__()
+        self.num_classes = num_classes
+        self.anchors = list(anchors)
+        self.num_anchors = num_anchors
+        self.anchor_step = len(self.anchors) // num_anchors if num_anchors else 0
+        self.coord_scale = 1
+        self.noobject_scale = 1
+        self.object_scale = 5
+        self.class_scale = 1
+        self.thresh = 0.6
+        self.seen = 0
+        self._stats = None
+        self.debug_targets = False      # tests: also emit build_targets' nine tensors
+        self.last_targets = None
+        self.last_keep = None
+
+    def stats(self):
+        """(dict) loss parts + nGT / nCorrect / nProposals of the last call (synchronises)."""
+        s = self._stats.tolist()
+        if s[9] > 0:
+            raise ValueError("region loss: %d ground-truth entries had no matching anchor, left the grid or "
+                             "carried a class id outside the episode" % int(s[9]))
+        return dict(loss_x=s[0], loss_y=s[1], loss_w=s[2], loss_h=s[3], loss_conf=s[4], loss_cls=s[5],
+                    nGT=int(s[6]), nCorrect=int(s[7]), nProposals=int(s[8]))
+
+    def _run(self, output, target_rows_host, rows_per_image, softmax_over_rows, zero_tcls):
+        rows = output.shape[0]
+        tr = np.ascontiguousarray(target_rows_host, dtype=np.float64)
+        if tr.shape[0] != rows:
+            raise ValueError("target has %d rows, output has %d" % (tr.shape[0], rows))
+        _validate_targets(tr)
+        keep = neg_filter_indices(tr)
+        keep_map = np.full(rows, -1, np.int32)
+        keep_map[keep] = np.arange(len(keep), dtype=np.int32)
+        dev = output.device
+        target_dev = torch.from_numpy(tr).to(dev, non_blocking=True)
+        keep_dev = torch.from_numpy(keep_map).to(dev, non_blocking=True)
+        dbg = None
+        if self.debug_targets:
+            dbg = torch.zeros((9, rows, self.num_anchors, output.shape[2], output.shape[3]),
+                              dtype=torch.float32, device=dev)
+        loss = _RegionLossFn.apply(output, target_dev, keep_dev, self, rows_per_image, softmax_over_rows,
+                                   zero_tcls, dbg)
+        self.last_keep = keep
+        if dbg is not None:
+            self.last_targets = dbg[:, :len(keep)]
+        if self.verbose:
+            s = self.stats()
+            print("%d: nGT %d, recall %d, proposals %d, loss: x %f, y %f, w %f, h %f, conf %f, cls %f, total %f" % (
+                self.seen, s["nGT"], s["nCorrect"], s["nProposals"], s["loss_x"], s["loss_y"], s["loss_w"],
+                s["loss_h"], s["loss_conf"], s["loss_cls"], float(loss)))
+        return loss
+
+
+def _host_rows(target):
+    t = target.detach()
+    if t.is_cuda:
+        t = t.cpu()
+    return t.reshape(-1, t.shape[-1]).numpy()
+
+
+class RegionLoss(_RegionBase):
+    """YOLOv2 region loss with the per-cell softmax over `num_classes` (reference region_loss.py:134-232).
+    output (B, A*(5+C), H, W), target (B, 250) or (B, N, 250) -> scalar (sum over the batch)."""
+
+    def forward(self, output, target):
+        return self._run(output, _host_rows(target), 1, False, bool(cfg.metayolo))
+
+
+class RegionLossV2(_RegionBase):
+    """Region loss + softmax classification across the N meta-inputs (reference region_loss.py:234-366).
+    output (B*N, A*6, H, W) with rows ordered b*N+n, target (B, N, 250) -> scalar."""
+
+    def __init__(self, num_classes=0, anchors=(), num_anchors=1):
+        super(RegionLossV2, self).__init__(num_classes, anchors, num_anchors)
+        print("class_scale", self.class_scale)
+
+    def forward(self, output, target):
+        if target.dim() != 3:
+            raise ValueError("RegionLossV2 expects a (batch, n_classes, 250) target")
+        bs, cs = target.shape[0], target.shape[1]
+        if output.shape[0] != bs * cs:
+            raise ValueError("output rows %d != batch %d x classes %d" % (output.shape[0], bs, cs))
+        return self._run(output, _host_rows(target), cs, True, False)

@@ -1,0 +1,147 @@
+/* fsdet.h -- C ABI of libfsdet_hip.so: the MI355X (gfx950) kernels behind the few-shot
+ * detection hot path (Darknet-19 meta feature extractor -> reweighting net -> channel-wise
+ * reweighting -> RegionLoss).
+ *
+ * Boundary contract.  This is what a maintainer of the reference
+ * binds (ctypes stub shown in INTEGRATION.md) in place of the PyTorch-0.3.1 / cuDNN /
+ * python-loop implementations cited per entry point below.  Precedent for a native-operator
+ * boundary in the reference: layers/batchnorm/src/batchnorm.h:1-6 (`bn_forward_gpu`, ...),
+ * where the Python side pre-allocates every output and scratch tensor (layers/batchnorm/bn.py:16-53).
+ *
+ *   - plain pointers + sizes only; every pointer is DEVICE memory unless the name ends in _host
+ *   - the library never allocates or frees: outputs and workspaces are caller-allocated
+ *     (sizes via the *_bytes / *_elems queries)
+ *   - every launcher enqueues on the hipStream_t it is given and returns immediately;
+ *     re-entrant, no mutable global state
+ *   - return value: 0 on success, a negative FSD_ERR_* for argument problems, or a positive
+ *     hipError_t from the runtime.  Nothing aborts (the reference's cuda.c:27-49 did).
+ *
+ * Activation layout inside the path is NHWC fp32 ("pixel-major": channels contiguous) with an
+ * explicit pixel stride so a tensor can be a channel slice of a wider (concat) buffer.
+ * The public tensors of the reference API stay NCHW; fsd_transpose_batched converts.
+ */
+#ifndef FSDET_H_
+#define FSDET_H_
+
+#include <stddef.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSD_OK 0
+#define FSD_ERR_ARG (-1)
+#define FSD_ERR_UNSUPPORTED (-2)
+#define FSD_ERR_WORKSPACE (-3)
+
+/* ---- region loss ------------------------------------------------------------------------- */
+/* stats[] (doubles) at the start of the region-loss workspace */
+#define FSD_REGION_STATS 16
+#define FSD_STAT_LOSS_X 0
+#define FSD_STAT_LOSS_Y 1
+#define FSD_STAT_LOSS_W 2
+#define FSD_STAT_LOSS_H 3
+#define FSD_STAT_LOSS_CONF 4
+#define FSD_STAT_LOSS_CLS 5
+#define FSD_STAT_NGT 6
+#define FSD_STAT_NCORRECT 7
+#define FSD_STAT_NPROPOSALS 8
+#define FSD_STAT_BAD_TARGET 9 /* >0: a ground truth had no matching anchor / left the grid / bad class id */
+
+size_t fsd_region_loss_workspace_bytes(int rows, int rows_per_image, int num_anchors, int height, int width);
+
+/* Fused forward + gradient of RegionLossV2.forward (region_loss.py:252-366, softmax_over_rows=1,
+ * rows_per_image = N episode classes, rows ordered b*N+n) and RegionLoss.forward
+ * (region_loss.py:148-232, softmax_over_rows=0, rows_per_image=1), including build_targets
+ * (region_loss.py:37-132).  neg_filter (region_loss.py:15-34) runs on the host because it reads
+ * the host-resident target and python's RNG; its result arrives as `keep`.
+ *   output      (rows, A*(5+C), H, W) fp32 NCHW      target (rows, target_len) float64
+ *   keep        (rows) int32: compact index of a kept row, -1 if dropped
+ *   grad_output same shape as output: d loss / d output (every element is written)
+ *   loss_out    1 float: total loss (sum, not batch-normalised)
+ *   dbg_targets optional, 9 planes of (rows, A, H, W) floats indexed by keep[]: coord_mask,
+ *               conf_mask, cls_mask, tx, ty, tw, th, tconf, tcls (build_targets' return values)
+ */
+int fsd_region_loss_fwd_bwd(const float* output, const double* target, const int* keep,
+                            float* grad_output, float* loss_out, void* workspace, size_t workspace_bytes,
+                            int rows, int rows_per_image, int num_anchors, int num_classes,
+                            int height, int width, int target_len, const double* anchors_host,
+                            float coord_scale, float noobject_scale, float object_scale,
+                            float class_scale, float thresh, long long seen, int max_boxes,
+                            int softmax_over_rows, int zero_tcls, float* dbg_targets, hipStream_t stream);
+
+/* ---- convolution as implicit GEMM on the fp32 matrix cores -------------------------------- */
+/* Packed weight: [round_up(rows,128)][round_up(taps*round_up(red,4), 32)] floats, K-major,
+ * k = tap*red4 + r.  mode 0 (forward, replaces nn.Conv2d weight use, darknet_meta.py:236-250):
+ * rows = Cout, red = Cin, tap = ky*ks+kx.  mode 1 (data gradient): rows = Cin, red = Cout and
+ * taps flipped, so the same kernel computes dL/dx from dL/dy. */
+size_t fsd_packed_weight_elems(int rows, int red, int ksize);
+int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ksize, int mode,
+                         hipStream_t stream);
+
+/* Number of row tiles the conv kernel will use for `pixels` outputs and `cout` channels
+ * (= first dimension of the BN partial-sum buffer). */
+int fsd_conv_row_tiles(long long pixels, int cout);
+
+/* y[p, co] = sum_{tap, ci} x[p + tap, ci] * w[co, tap, ci] (+ bias[co]);  stride 1,
+ * pad = (ksize-1)/2, ksize in {1, 3}.  x: NHWC, cin % 4 == 0, pixel stride x_ld (floats).
+ * out_nchw = 0: y NHWC with pixel stride y_ld;  out_nchw = 1: y is (B, cout, H, W) contiguous.
+ * bn_partial (optional, out_nchw = 0 only): [row_tiles][cout][2] per-tile (sum, sum of squares)
+ * of the raw outputs -- the batch statistics nn.BatchNorm2d needs (darknet_meta.py:245-248)
+ * come out of the conv epilogue instead of a second pass over y. */
+int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const float* bias, float* y,
+                   long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
+                   int cout, int ksize, int out_nchw, hipStream_t stream);
+
+/* ---- batch norm (training statistics) + activation + pooling ------------------------------ */
+/* Reduce the per-tile partials, produce the per-channel affine (scale = gamma*invstd,
+ * shift = beta - mean*scale), save mean / invstd for the backward pass and update the running
+ * statistics like nn.BatchNorm2d(momentum) in training mode (biased variance normalises,
+ * unbiased variance feeds running_var).  training = 0: scale/shift from the running statistics. */
+size_t fsd_bn_finalize_workspace_bytes(int channels);
+int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long count, int channels,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int training, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, void* workspace, hipStream_t stream);
+
+/* z = pool(act(y*scale + shift)).  y: (B,H,W,C) NHWC stride y_ld.  slope: 0.1 leaky, 0 relu,
+ * 1 linear.  pool: 0 none, 1 = 2x2 stride 2 (floor), 2 = 2x2 stride 1 with replicate pad
+ * (MaxPoolStride1, darknet_meta.py:47-53).  z: NHWC with pixel stride z_ld (channel-slice writes
+ * implement [route] concatenation in place).  scale/shift may be NULL (identity). */
+int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, const float* shift,
+                        float slope, int pool, float* z, long long z_ld, int batch, int height,
+                        int width, int channels, hipStream_t stream);
+
+/* ---- data movement ------------------------------------------------------------------------ */
+/* dst[b][c][r] = src[b][r][c] for r < rows, c < cols; element strides given per matrix.
+ * NCHW -> NHWC: rows = C, cols = H*W;  NHWC -> NCHW: rows = H*W, cols = C. */
+int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
+                          float* dst, long long dst_batch_stride, long long dst_row_stride,
+                          int batch, int rows, int cols, hipStream_t stream);
+int fsd_fill(float* dst, float value, long long count, hipStream_t stream);
+
+/* Reorg (darknet_meta.py:55-74): out[b,i,j,(di*s+dj)*C + c] = x[b, s*i+di, s*j+dj, c], NHWC. */
+int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, int batch, int height,
+                  int width, int channels, int stride, hipStream_t stream);
+
+/* GlobalMaxPool2d (pooling.py:8-27): (B,H,W,C) -> (B,C).  argmax (optional) records the pixel. */
+int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch,
+                           int height, int width, int channels, hipStream_t stream);
+
+/* ---- channel-wise reweighting (dynamic_conv.py:125-164) ----------------------------------- */
+/* Materialising form, NCHW like the reference module: out[b*N+n, c, hw] = x[b, c, hw] * w[n, c]. */
+int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,
+                         int hw, hipStream_t stream);
+/* Fused form: fold the reweighting vectors into the 1x1 head so the (B*N, C, H, W) tensor never
+ * exists:  w_eff[(n*O + o), c] = head_w[o, c] * dyn[n, c], bias_eff[n*O + o] = head_b[o], written
+ * in the packed-weight layout of fsd_conv2d_fwd (rows = N*O, red = C, ksize = 1). */
+int fsd_fold_reweight_head(const float* head_w, const float* head_b, const float* dyn, float* w_eff_packed,
+                           float* bias_eff, int n_cls, int out_ch, int channels, hipStream_t stream);
+
+const char* fsd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSDET_H_ */

@@ -1,0 +1,192 @@
+"""Kernel-level parity (MI355X): each HIP op of include/fsdet.h against PyTorch-CPU fp32 / the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _conv_case(dev, B, H, W, cin, cout, k, bias, seed):
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, (k - 1) // 2).float()
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    wp = ops.pack_weight(w.to(dev))
+    yv, part = ops.conv2d(xv, wp, cout, k, bias=None if b is None else b.to(dev), bn_partial=not bias)
+    y = ops.nhwc_to_nchw(yv).cpu()
+    return ref, y, part, yv
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,bias", [
+    (2, 13, 13, 64, 128, 3, False),     # 128x128 tile config, ragged M (338 rows)
+    (1, 26, 26, 32, 64, 3, False),      # 256x64 config
+    (2, 20, 24, 3, 32, 3, False),       # first layer: Cin=3 padded to 4, K=36 (K tail), 256x32 config
+    (2, 13, 13, 256, 30, 1, True),      # 1x1 + bias, Cout tail
+    (1, 7, 9, 1280, 200, 3, False),     # Cin/4 not a power of two, Cout tail across 2 tiles
+    (3, 6, 6, 4, 8, 3, False),          # tiny everything
+])
+def test_conv_forward_matches_fp64_reference(dev, B, H, W, cin, cout, k, bias):
+    ref, y, part, _ = _conv_case(dev, B, H, W, cin, cout, k, bias, seed=B * 1000 + cin)
+    # exact-fp32 MFMA: error is fp32 round-off of a K-term dot product
+    assert torch.allclose(y, ref, rtol=1e-4, atol=2e-5), float((y - ref).abs().max())
+    if part is not None:
+        p = part.double().sum(0).cpu()
+        flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
+        assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
+
+
+def test_conv_nchw_store_and_asymmetric_weights(dev):
+    """Transposed-accumulator epilogue: identity-like input with an ASYMMETRIC weight catches row/col swaps."""
+    from fewshot_detection_amd import ops
+    B, H, W, cin, cout = 2, 5, 7, 8, 45
+    x = torch.randn(B, cin, H, W)
+    w = torch.arange(cout * cin, dtype=torch.float32).view(cout, cin, 1, 1) / 100.0
+    b = torch.arange(cout, dtype=torch.float32)
+    ref = F.conv2d(x, w, b)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    y, _ = ops.conv2d(xv, ops.pack_weight(w.to(dev)), cout, 1, bias=b.to(dev), nchw_out=True)
+    assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_data_gradient_packing(dev):
+    """mode-1 packing turns the forward kernel into dL/dx."""
+    from fewshot_detection_amd import ops
+    B, H, W, cin, cout = 2, 9, 9, 8, 12
+    x = torch.randn(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, dtype=torch.float64)
+    gy = torch.randn(B, cout, H, W, dtype=torch.float64)
+    F.conv2d(x, w, None, 1, 1).backward(gy)
+    gv = ops.nchw_to_nhwc(gy.float().to(dev))
+    dx, _ = ops.conv2d(gv, ops.pack_weight(w.float().to(dev), mode=1), cin, 3)
+    assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), x.grad.float(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("pool", [0, 1, 2])
+def test_bn_leaky_pool_matches_torch(dev, pool):
+    from fewshot_detection_amd import ops
+    torch.manual_seed(pool)
+    B, H, W, cin, cout = 3, 13, 13, 8, 16          # odd size: floor pooling 13 -> 6
+    x = torch.randn(B, cin, H, W)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(cout)
+    bn.weight.data.uniform_(-1, 1)                 # negative gammas: affine must precede the max
+    bn.bias.data.uniform_(-0.5, 0.5)
+    ref_bn = torch.nn.BatchNorm2d(cout)
+    ref_bn.load_state_dict(bn.state_dict())
+    z = F.leaky_relu(ref_bn(conv(x)), 0.1)
+    if pool == 1:
+        z = F.max_pool2d(z, 2, 2)
+    elif pool == 2:
+        z = F.max_pool2d(F.pad(z, (0, 1, 0, 1), mode="replicate"), 2, stride=1)
+    bn = bn.to(dev)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    yv, part = ops.conv2d(xv, ops.pack_weight(conv.weight.data.to(dev)), cout, 3, bn_partial=True)
+    scale, shift, mean, invstd = ops.bn_finalize(part, xv.pixels, bn, True)
+    out = ops.nhwc_to_nchw(ops.bn_act_pool(yv, scale, shift, 0.1, pool)).cpu()
+    assert torch.allclose(out, z.detach(), rtol=1e-4, atol=1e-5), float((out - z).abs().max())
+    assert torch.allclose(bn.running_mean.cpu(), ref_bn.running_mean, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    # eval mode: running statistics
+    ref_bn.eval()
+    z2 = F.leaky_relu(ref_bn(conv(x)), 0.1)
+    s2, h2, _, _ = ops.bn_finalize(None, xv.pixels, bn, False)
+    out2 = ops.nhwc_to_nchw(ops.bn_act_pool(yv, s2, h2, 0.1, 0)).cpu()
+    assert torch.allclose(out2, z2.detach(), rtol=1e-4, atol=1e-5)
+
+
+def test_reorg_globalmax_dynamic_conv(dev):
+    from fewshot_detection_amd import ops
+    from oracle.net import reorg, reweight
+    x = torch.randn(2, 8, 6, 6)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    assert torch.equal(ops.nhwc_to_nchw(ops.reorg(xv, 2)).cpu(), reorg(x, 2))
+    gm, arg = ops.global_maxpool(xv, want_argmax=True)
+    assert torch.equal(gm.cpu(), x.amax(dim=(2, 3)))
+    assert torch.equal(arg.cpu().long(), x.flatten(2).argmax(2))
+    d = np.load(os.path.join(GOLD, "dconv.npz"))          # reference dynamic_conv2d output
+    out = ops.dynamic_conv(torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["w"]).to(dev))
+    assert torch.equal(out.cpu(), torch.from_numpy(d["out"]))
+    assert torch.equal(out.cpu(), reweight(torch.from_numpy(d["x"]), torch.from_numpy(d["w"])))
+
+
+def test_fused_reweight_head_equals_materialised_path(dev):
+    from fewshot_detection_amd import ops
+    from oracle.net import reweight
+    torch.manual_seed(9)
+    B, C, G, N, O = 3, 64, 5, 4, 30
+    x = torch.randn(B, C, G, G)
+    dyn = torch.randn(N, C, 1, 1)
+    hw_, hb = torch.randn(O, C, 1, 1) / 8, torch.randn(O)
+    ref = F.conv2d(reweight(x, dyn), hw_, hb)                      # (B*N, 30, G, G)
+    w_eff, b_eff = ops.fold_reweight_head(hw_.to(dev), hb.to(dev), dyn.to(dev))
+    y, _ = ops.conv2d(ops.nchw_to_nhwc(x.to(dev)), w_eff, N * O, 1, bias=b_eff, nchw_out=True)
+    assert torch.allclose(y.view(B * N, O, G, G).cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+MASKS = ["coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"]
+ANCH = [1.3221, 1.73145, 3.19275, 4.00944, 5.05587, 8.09892, 9.47112, 4.84053, 11.2364, 10.0071]
+ANCH_V1 = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
+
+
+def _check_loss(mod, d, dev):
+    out = torch.from_numpy(d["output"]).to(dev).requires_grad_(True)
+    mod.debug_targets = True
+    loss = mod(out, torch.from_numpy(d["target"]))
+    loss.backward()
+    s = mod.stats()
+    assert s["nGT"] == int(d["nGT"]) and s["nCorrect"] == int(d["nCorrect"])
+    got = mod.last_targets.cpu().numpy()
+    for i, k in enumerate(MASKS):
+        if k in ("coord_mask", "conf_mask", "cls_mask", "tcls", "tx", "ty"):
+            assert np.array_equal(got[i], d[k]), k            # assignment: bit-exact
+        else:
+            assert np.allclose(got[i], d[k], rtol=1e-5, atol=1e-6), k
+    assert abs(float(loss) - float(d["loss"])) <= 1e-3, (float(loss), float(d["loss"]))
+    assert np.allclose(out.grad.cpu().numpy(), d["grad"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["full_seen0", "full_seen20000", "neg0_seen20000", "neg1_seen20000"])
+def test_region_loss_v2_vs_reference_golden(dev, case):
+    import random
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.region_loss import RegionLossV2
+    d = np.load(os.path.join(GOLD, "region_v2_%s.npz" % case))
+    neg = str(d["neg_ratio"])
+    cfg.neg_ratio = neg if neg == "full" else int(neg)
+    random.seed(int(d["py_seed"]))
+    try:
+        mod = RegionLossV2(1, ANCH, 5)
+        mod.seen = int(d["seen"])
+        _check_loss(mod, d, dev)
+    finally:
+        cfg.neg_ratio = "full"
+
+
+@pytest.mark.parametrize("case", ["seen0", "seen20000", "metayolo"])
+def test_region_loss_v1_vs_reference_golden(dev, case):
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.region_loss import RegionLoss
+    d = np.load(os.path.join(GOLD, "region_v1_%s.npz" % case))
+    cfg.neg_ratio = "full"
+    cfg.metayolo = bool(d["metayolo"])
+    try:
+        mod = RegionLoss(3, ANCH_V1, 5)
+        mod.seen = int(d["seen"])
+        _check_loss(mod, d, dev)
+    finally:
+        cfg.metayolo = True
