@@ -1,0 +1,312 @@
+"""`Darknet(darknet_cfg, learnet_cfg)`: the meta detector with the reference's interface
+(darknet_meta.py:86-482) -- attributes blocks / learnet_blocks / models / learnet_models / loss /
+width / height / anchors / num_anchors / anchor_step / num_classes / header / seen; methods forward,
+meta_forward, detect_forward, print_network, create_network, load_weights, save_weights, is_dynamic.
+
+The nn.Module tree only OWNS the parameters (same names and shapes as the reference, so
+state_dicts and darknet .weights files interchange); the arithmetic runs in engine.Network on
+the HIP kernels.  Gradients flow through two autograd nodes (reweighting net, detector) whose
+backward replays the engine tape.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cfg import (cfg, load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, save_conv, save_conv_bn,
+                  save_fc)
+from .dynamic_conv import dynamic_conv2d
+from .engine import Network, is_dynamic
+from .pooling import GlobalAvgPool2d, GlobalMaxPool2d, Split
+from .region_loss import RegionLossV2
+
+
+class ConvBlock(nn.Sequential):
+    """conv(+bn)(+activation) container.  Standalone call: NCHW in, NCHW out, forward only."""
+
+    def forward(self, x):
+        conv = self[0]
+        if getattr(conv, "is_first", None) is not None:          # dynamic conv: x is (features, vectors)
+            return conv(x)
+        bn = self[1] if len(self) > 1 and isinstance(self[1], nn.BatchNorm2d) else None
+        act = self[len(self) - 1]
+        slope = 0.1 if isinstance(act, nn.LeakyReLU) else 0.0 if isinstance(act, nn.ReLU) else 1.0
+        k = conv.kernel_size[0]
+        with torch.no_grad():
+            xv = ops.nchw_to_nhwc(x)
+            wp = ops.pack_weight(conv.weight)
+            training = self.training and bn is not None
+            y, part = ops.conv2d(xv, wp, conv.out_channels, k, bias=conv.bias, bn_partial=training)
+            if bn is not None:
+                scale, shift, _, _ = ops.bn_finalize(part, xv.pixels, bn, training)
+                y = ops.bn_act_pool(y, scale, shift, slope, 0)
+            elif slope != 1.0:
+                y = ops.bn_act_pool(y, None, None, slope, 0)
+            return ops.nhwc_to_nchw(y)
+
+
+class _Pool2x2(nn.Module):
+    def __init__(self, mode):
+        super(_Pool2x2, self).__init__()
+        self.mode = mode
+
+    def forward(self, x):
+        with torch.no_grad():
+            return ops.nhwc_to_nchw(ops.bn_act_pool(ops.nchw_to_nhwc(x), None, None, 1.0, self.mode))
+
+
+class MaxPoolStride1(_Pool2x2):
+    """2x2 max, stride 1, replicate padding right/bottom (darknet_meta.py:47-53)."""
+
+    def __init__(self):
+        super(MaxPoolStride1, self).__init__(2)
+
+
+class MaxPool2x2(_Pool2x2):
+    """nn.MaxPool2d(2, 2) equivalent (floor mode)."""
+
+    def __init__(self):
+        super(MaxPool2x2, self).__init__(1)
+
+
+class Reorg(nn.Module):
+    """Space to depth: out[b,(di*s+dj)*C+c,i,j] = x[b,c,s*i+di,s*j+dj]  (darknet_meta.py:55-74)."""
+
+    def __init__(self, stride=2):
+        super(Reorg, self).__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        assert x.dim() == 4 and x.shape[2] % self.stride == 0 and x.shape[3] % self.stride == 0
+        with torch.no_grad():
+            return ops.nhwc_to_nchw(ops.reorg(ops.nchw_to_nhwc(x), self.stride))
+
+
+class EmptyModule(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def maybe_repeat(x1, x2):
+    """Batch-align two tensors by repeating the smaller one per class (darknet_meta.py:16-35)."""
+    n1, n2 = x1.size(0), x2.size(0)
+    if n1 == n2:
+        return x1, x2
+    if n1 < n2:
+        assert n2 % n1 == 0
+        return x1.repeat_interleave(n2 // n1, dim=0), x2
+    assert n1 % n2 == 0
+    return x1, x2.repeat_interleave(n1 // n2, dim=0)
+
+
+def _flat_params(models):
+    return [p for p in models.parameters()]
+
+
+def build_modules(blocks, region_cls):
+    """cfg blocks -> nn.ModuleList owning the parameters (reference create_network, darknet_meta.py:208-353)."""
+    models = nn.ModuleList()
+    prev_filters = 3
+    out_filters = []
+    conv_id = 0
+    dynamic_count = 0
+    for block in blocks:
+        kind = block["type"]
+        if kind in ("net", "learnet"):
+            prev_filters = int(block["channels"])
+            continue
+        if kind == "convolutional":
+            conv_id += 1
+            bn_on = int(block["batch_normalize"])
+            filters = int(block["filters"])
+            k = int(block["size"])
+            pad = (k - 1) // 2 if int(block["pad"]) else 0
+            want_bias = bool(int(block["bias"])) if "bias" in block else True
+            groups = int(block["groups"]) if "groups" in block else 1
+            if groups != 1:
+                raise NotImplementedError("grouped convolution")
+            if is_dynamic(block):
+                partial = int(block["partial"]) if "partial" in block else None
+                conv = dynamic_conv2d(dynamic_count == 0, partial=partial)(
+                    prev_filters, filters, k, int(block["stride"]), pad, groups=groups, bias=False)
+                dynamic_count += 1
+            else:
+                conv = nn.Conv2d(prev_filters, filters, k, int(block["stride"]), pad,
+                                 bias=False if bn_on else want_bias)
+            seq = ConvBlock()
+            seq.add_module("conv{0}".format(conv_id), conv)
+            if bn_on:
+                seq.add_module("bn{0}".format(conv_id), nn.BatchNorm2d(filters))
+            if block["activation"] == "leaky":
+                seq.add_module("leaky{0}".format(conv_id), nn.LeakyReLU(0.1, inplace=True))
+            elif block["activation"] == "relu":
+                seq.add_module("relu{0}".format(conv_id), nn.ReLU(inplace=True))
+            prev_filters = filters
+            models.append(seq)
+        elif kind == "maxpool":
+            if int(block["size"]) != 2:
+                raise NotImplementedError("maxpool size %s" % block["size"])
+            models.append(MaxPool2x2() if int(block["stride"]) > 1 else MaxPoolStride1())
+        elif kind == "reorg":
+            stride = int(block["stride"])
+            prev_filters = stride * stride * prev_filters
+            models.append(Reorg(stride))
+        elif kind == "route":
+            ind = len(models)
+            layers = [int(i) if int(i) > 0 else int(i) + ind for i in block["layers"].split(",")]
+            prev_filters = sum(out_filters[i] for i in layers)
+            models.append(EmptyModule())
+        elif kind == "shortcut":
+            prev_filters = out_filters[len(models) - 1]
+            models.append(EmptyModule())
+        elif kind == "region":
+            loss = region_cls()
+            loss.anchors = [float(i) for i in block["anchors"].split(",")]
+            loss.num_classes = int(block["classes"])
+            loss.num_anchors = int(block["num"])
+            loss.anchor_step = len(loss.anchors) // loss.num_anchors
+            loss.object_scale = float(block["object_scale"])
+            loss.noobject_scale = float(block["noobject_scale"])
+            loss.class_scale = float(block["class_scale"])
+            loss.coord_scale = float(block["coord_scale"])
+            models.append(loss)
+        elif kind == "globalmax":
+            models.append(GlobalMaxPool2d())
+        elif kind in ("globalavg", "avgpool"):
+            models.append(GlobalAvgPool2d())
+        elif kind == "split":
+            splits = [int(sz) for sz in block["splits"].split(",")]
+            prev_filters = splits[-1]
+            models.append(Split(splits))
+        else:
+            raise NotImplementedError("block type %r is outside the MI355X hot path" % kind)
+        out_filters.append(prev_filters)
+    return models
+
+
+
+class _NetFn(torch.autograd.Function):
+    """One engine.Network as a single autograd node: inputs (activations, optional reweighting
+    vectors, parameters) -> output; backward replays the tape on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, net, training, n_inputs, has_dyn, *tensors):
+        inputs = list(tensors[:n_inputs])
+        dyn = [tensors[n_inputs]] if has_dyn else None
+        out, tape = net.forward(inputs, dyn=dyn, training=training)
+        ctx.net, ctx.tape, ctx.n_inputs, ctx.has_dyn = net, tape, n_inputs, has_dyn
+        ctx.params = tensors[n_inputs + (1 if has_dyn else 0):]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import backward as bw
+        grads = bw.run(ctx.net, ctx.tape, grad_out.contiguous(), ctx.params)
+        head = [None] * ctx.n_inputs + ([grads["dyn"]] if ctx.has_dyn else [])
+        return (None, None, None, None) + tuple(head) + tuple(grads["params"])
+
+
+class Darknet(nn.Module):
+    def __init__(self, darknet_file, learnet_file):
+        super(Darknet, self).__init__()
+        self.blocks = darknet_file if isinstance(darknet_file, list) else parse_cfg(darknet_file)
+        self.learnet_blocks = learnet_file if isinstance(learnet_file, list) else parse_cfg(learnet_file)
+        self.models = self.create_network(self.blocks)
+        self.learnet_models = self.create_network(self.learnet_blocks)
+        self.loss = self.models[len(self.models) - 1]
+        self.width = int(self.blocks[0]["width"])
+        self.height = int(self.blocks[0]["height"])
+        if self.blocks[len(self.blocks) - 1]["type"] == "region":
+            self.anchors = self.loss.anchors
+            self.num_anchors = self.loss.num_anchors
+            self.anchor_step = self.loss.anchor_step
+            self.num_classes = self.loss.num_classes
+        self.header = torch.IntTensor([0, 0, 0, 0])
+        self.seen = 0
+        self._det = Network(self.blocks, self.models)
+        self._meta = Network(self.learnet_blocks, self.learnet_models)
+
+    # ---- forward ---------------------------------------------------------------------------
+    def meta_forward(self, metax, mask):
+        """Support images (+ masks) -> list of reweighting vectors [(N, C, 1, 1)]."""
+        if int(self.learnet_blocks[0]["feat_layer"]) != 0:
+            raise NotImplementedError("feat_layer != 0 is not used by any shipped cfg")
+        inputs = [metax, mask] if cfg.metain_type in (2, 3) else [metax]
+        params = _flat_params(self.learnet_models)
+        out = _NetFn.apply(self._meta, self.training, len(inputs), False, *(inputs + params))
+        return [out]
+
+    def detect_forward(self, x, dynamic_weights):
+        """Query images + reweighting vectors -> (B*N, A*(5+C), G, G), rows ordered b*N+n."""
+        self.loss = None       # the reference clears it here too (darknet_meta.py:134)
+        params = _flat_params(self.models)
+        return _NetFn.apply(self._det, self.training, 1, True, x, dynamic_weights[0], *params)
+
+    def forward(self, x, metax, mask, ids=None):
+        return self.detect_forward(x, self.meta_forward(metax, mask))
+
+    def print_network(self):
+        print_cfg(self.blocks)
+        print("---------------------------------------------------------------------")
+        print_cfg(self.learnet_blocks)
+
+    # ---- construction ------------------------------------------------------------------------
+    def is_dynamic(self, block):
+        return is_dynamic(block)
+
+    def create_network(self, blocks):
+        return build_modules(blocks, RegionLossV2)
+
+    # ---- darknet .weights files (byte-compatible with the reference) ------------------------
+    def _streams(self):
+        return [(self.blocks, self.models), (self.learnet_blocks, self.learnet_models)]
+
+    def load_weights(self, weightfile):
+        with open(weightfile, "rb") as fp:
+            header = np.fromfile(fp, count=4, dtype=np.int32)
+            buf = np.fromfile(fp, dtype=np.float32)
+        self.header = torch.from_numpy(header)
+        self.seen = self.header[3]
+        start = 0
+        for blocks, models in self._streams():
+            for ind, block in enumerate(blocks[1:]):
+                if start >= buf.size:        # partial files (e.g. darknet19_448.conv.23) stop here
+                    break
+                if block["type"] == "convolutional":
+                    model = models[ind]
+                    if self.is_dynamic(block) and model[0].weight is None:
+                        continue
+                    if int(block["batch_normalize"]):
+                        start = load_conv_bn(buf, start, model[0], model[1])
+                    else:
+                        start = load_conv(buf, start, model[0])
+                elif block["type"] == "connected":
+                    model = models[ind]
+                    start = load_fc(buf, start, model if block["activation"] == "linear" else model[0])
+
+    def save_weights(self, outfile, cutoff=0):
+        if cutoff <= 0:
+            cutoff = len(self.blocks) - 1 + len(self.learnet_blocks)
+        with open(outfile, "wb") as fp:
+            self.header[3] = int(self.seen)
+            self.header.numpy().tofile(fp)
+            done = 0
+            for blocks, models in self._streams():
+                # the reference counts the [learnet] header block as one step of `cutoff`
+                if blocks is self.learnet_blocks:
+                    done += 1
+                for ind, block in enumerate(blocks[1:]):
+                    done += 1
+                    if done > cutoff:
+                        return
+                    if block["type"] == "convolutional":
+                        model = models[ind]
+                        if self.is_dynamic(block) and model[0].weight is None:
+                            continue
+                        if int(block["batch_normalize"]):
+                            save_conv_bn(fp, model[0], model[1])
+                        else:
+                            save_conv(fp, model[0])
+                    elif block["type"] == "connected":
+                        model = models[ind]
+                        save_fc(fp, model if block["activation"] == "linear" else model[0])

@@ -1,0 +1,249 @@
+"""Executes a parsed darknet .cfg network on the HIP kernels, in NHWC, with layer fusion.
+
+The reference walks `self.blocks` and calls one PyTorch module per block (darknet_meta.py:130-195).
+Here the same walk drives a small set of fused device ops:
+
+  [convolutional](+BN)(+leaky)(+[maxpool])  ->  implicit-GEMM conv (BN partial sums in its epilogue)
+                                                 -> statistics finalise -> affine+leaky+pool pass
+  [route] a            ->  alias;   [route] a,b  ->  producers write channel slices of one buffer
+  [reorg]              ->  space-to-depth straight into its slice of the concat buffer
+  dynamic [convolutional] + 1x1 head  ->  ONE GEMM with the reweighting vectors folded into the
+                                          head weights (the (B*N,1024,H,W) tensor never exists)
+  [globalmax]          ->  per-channel max over the support feature map
+
+A forward pass records a tape (views + per-channel statistics) that `backward` replays in reverse.
+"""
+import torch
+
+from . import ops
+from .ops import View
+
+
+def is_dynamic(block):
+    return "dynamic" in block and int(block["dynamic"]) == 1
+
+
+def _slope(activation):
+    if activation == "leaky":
+        return 0.1
+    if activation == "relu":
+        return 0.0
+    if activation == "linear":
+        return 1.0
+    raise NotImplementedError("activation %r" % activation)
+
+
+class _WeightCache(object):
+    """Packed (K-major) copies of conv weights, refreshed when the parameter changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, w, mode=0):
+        key = (id(w), mode)
+        tag = (w.data_ptr(), w._version)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, ops.pack_weight(w.detach(), mode))
+            self._store[key] = hit
+        return hit[1]
+
+
+class Network(object):
+    """One cfg network (detector or reweighting net) bound to its nn.ModuleList of parameters."""
+
+    def __init__(self, blocks, models):
+        self.blocks = blocks
+        self.models = models
+        self.layers = blocks[1:]
+        self.cache = _WeightCache()
+        # static analysis: who is read by a [route], and which producers write into a concat buffer
+        self.route_src = {}
+        self.concat_of = {}
+        widths = []
+        width = int(blocks[0].get("channels", 3))
+        for ind, blk in enumerate(self.layers):
+            kind = blk["type"]
+            if kind == "convolutional":
+                width = int(blk["filters"])
+            elif kind == "reorg":
+                width *= int(blk["stride"]) ** 2
+            elif kind == "route":
+                src = [int(v) if int(v) > 0 else int(v) + ind for v in blk["layers"].split(",")]
+                self.route_src[ind] = src
+                width = sum(widths[s] for s in src)
+                if len(src) == 2:
+                    off = 0
+                    for s in src:
+                        if s in self.concat_of:
+                            raise NotImplementedError("a layer feeding two concatenating routes")
+                        self.concat_of[s] = (ind, off, width)
+                        off += widths[s]
+                elif len(src) != 1:
+                    raise NotImplementedError("route with %d inputs" % len(src))
+            widths.append(width)
+        self.widths = widths
+        self.tapped = set(s for src in self.route_src.values() for s in src)
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _dest(self, ind, B, H, W, C, dev, bufs):
+        """Output view for layer `ind`: a slice of its route's concat buffer, or a fresh tensor."""
+        if ind in self.concat_of:
+            route, off, total = self.concat_of[ind]
+            if route not in bufs:
+                bufs[route] = ops.new_view(B, H, W, total, dev)
+            big = bufs[route]
+            if (big.B, big.H, big.W) != (B, H, W):
+                raise NotImplementedError("route over feature maps of different size (maybe_repeat)")
+            return View(big.t, B, H, W, C, off)
+        return ops.new_view(B, H, W, C, dev)
+
+    def _conv(self, ind, blk, xv, training, pool, bufs, tape):
+        seq = self.models[ind]
+        conv = seq[0]
+        bn = seq[1] if int(blk["batch_normalize"]) else None
+        k = int(blk["size"])
+        if int(blk["stride"]) != 1:
+            raise NotImplementedError("strided convolution")
+        if k not in (1, 3) or (k == 3 and not int(blk["pad"])):
+            raise NotImplementedError("conv size=%d pad=%s" % (k, blk["pad"]))
+        cout = int(blk["filters"])
+        slope = _slope(blk["activation"])
+        wp = self.cache.get(conv.weight)
+        dev = xv.t.device
+        cin_true = conv.weight.shape[1]
+        rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool)
+        if bn is None and slope == 1.0 and pool == 0:
+            z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
+            ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
+            rec.update(y=z, z=z, z_full=None)
+            tape.append(rec)
+            return z, None
+        y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
+                                bn_partial=bn is not None and training, cin_true=cin_true)
+        scale = shift = mean = invstd = None
+        if bn is not None:
+            scale, shift, mean, invstd = ops.bn_finalize(partial, xv.pixels, bn, training)
+        z_full = None
+        if pool and ind in self.tapped:      # a [route] reads the activation before its maxpool
+            z_full = ops.bn_act_pool(y, scale, shift, slope, 0,
+                                     out=self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs))
+        OH, OW = (xv.H // 2, xv.W // 2) if pool == 1 else (xv.H, xv.W)
+        z = ops.bn_act_pool(y, scale, shift, slope, pool,
+                            out=self._dest(ind + 1 if pool else ind, xv.B, OH, OW, cout, dev, bufs))
+        rec.update(y=y, z=z, z_full=z_full, scale=scale, shift=shift, mean=mean, invstd=invstd,
+                   training=training)
+        tape.append(rec)
+        return z, z_full
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, inputs, dyn=None, training=False, tape=None):
+        """inputs: list of NCHW tensors concatenated along channels (e.g. [metax, mask]).
+        Returns an NCHW tensor (detector: (B*N, A*(5+C), G, G)) or (N, C, 1, 1) after [globalmax]."""
+        if tape is None:
+            tape = []
+        ops.require_device(*inputs)
+        B, _, H, W = inputs[0].shape
+        ctot = sum(t.shape[1] for t in inputs)
+        if len(inputs) == 1:
+            x = ops.nchw_to_nhwc(inputs[0])
+        else:
+            x = ops.new_view(B, H, W, (ctot + 3) // 4 * 4, inputs[0].device)
+            if x.C != ctot:
+                ops.fill(x.t, 0.0)
+            off = 0
+            for t in inputs:
+                ops.write_channels(t, x, off)
+                off += t.shape[1]
+        tape.append(dict(kind="input", x=x, n_in=ctot))
+        outs = {}
+        bufs = {}
+        n_dyn = 0
+        result = None
+        skip = -1
+        n_layers = len(self.layers)
+        for ind, blk in enumerate(self.layers):
+            if ind <= skip:
+                continue
+            kind = blk["type"]
+            if kind == "convolutional" and is_dynamic(blk):
+                nxt = self.layers[ind + 1] if ind + 1 < n_layers else None
+                fusable = (nxt is not None and nxt["type"] == "convolutional" and not is_dynamic(nxt)
+                           and int(nxt["size"]) == 1 and not int(nxt["batch_normalize"])
+                           and nxt["activation"] == "linear" and blk["activation"] == "linear"
+                           and not int(blk["batch_normalize"])
+                           and all(b["type"] in ("region", "cost") for b in self.layers[ind + 2:])
+                           and ind not in self.tapped and (ind + 1) not in self.tapped)
+                if dyn is None or n_dyn >= len(dyn):
+                    raise ValueError("dynamic convolution without reweighting vectors")
+                if not fusable:
+                    raise NotImplementedError("a dynamic conv that is not directly followed by the 1x1 "
+                                              "detection head is outside the fused path")
+                head = self.models[ind + 1][0]
+                vec = dyn[n_dyn]
+                n_dyn += 1
+                if vec.shape[1] != x.C or tuple(vec.shape[2:]) != (1, 1):
+                    raise ValueError("reweighting vectors %s do not match %d feature channels"
+                                     % (tuple(vec.shape), x.C))
+                n_cls, o_ch = vec.shape[0], head.weight.shape[0]
+                w_eff, b_eff = ops.fold_reweight_head(head.weight.detach(), None if head.bias is None
+                                                      else head.bias.detach(), vec.detach())
+                y, _ = ops.conv2d(x, w_eff, n_cls * o_ch, 1, bias=b_eff, nchw_out=True)
+                result = y.view(x.B * n_cls, o_ch, x.H, x.W)
+                tape.append(dict(kind="head", x=x, head=head, dyn=vec, w_eff=w_eff, n_cls=n_cls, o_ch=o_ch))
+                skip = ind + 1
+                x = None
+                continue
+            if kind == "convolutional":
+                pool = 0
+                nxt = self.layers[ind + 1] if ind + 1 < n_layers else None
+                if nxt is not None and nxt["type"] == "maxpool" and int(nxt["size"]) == 2:
+                    pool = 1 if int(nxt["stride"]) == 2 else (2 if int(nxt["stride"]) == 1 else 0)
+                z, z_full = self._conv(ind, blk, x, training, pool, bufs, tape)
+                if pool:
+                    outs[ind] = z_full
+                    outs[ind + 1] = z
+                    skip = ind + 1
+                else:
+                    outs[ind] = z
+                x = z
+            elif kind == "maxpool":
+                size, stride = int(blk["size"]), int(blk["stride"])
+                if size != 2 or stride not in (1, 2):
+                    raise NotImplementedError("maxpool %dx%d/%d" % (size, size, stride))
+                pool = 1 if stride == 2 else 2
+                OH, OW = (x.H // 2, x.W // 2) if pool == 1 else (x.H, x.W)
+                z = ops.bn_act_pool(x, None, None, 1.0, pool,
+                                    out=self._dest(ind, x.B, OH, OW, x.C, x.t.device, bufs))
+                tape.append(dict(kind="pool", x=x, z=z, pool=pool))
+                outs[ind] = x = z
+            elif kind == "reorg":
+                s = int(blk["stride"])
+                z = ops.reorg(x, s, out=self._dest(ind, x.B, x.H // s, x.W // s, x.C * s * s, x.t.device, bufs))
+                tape.append(dict(kind="reorg", x=x, z=z, stride=s))
+                outs[ind] = x = z
+            elif kind == "route":
+                src = self.route_src[ind]
+                if len(src) == 1:
+                    x = outs[src[0]]
+                    if x is None:
+                        raise RuntimeError("route reads layer %d whose output was fused away" % src[0])
+                else:
+                    big = bufs[ind]
+                    x = View(big.t, big.B, big.H, big.W, self.widths[ind], 0)
+                tape.append(dict(kind="route", src=src, z=x))
+                outs[ind] = x
+            elif kind == "globalmax":
+                vals, arg = ops.global_maxpool(x, want_argmax=True)
+                tape.append(dict(kind="globalmax", x=x, arg=arg))
+                result = vals.view(x.B, x.C, 1, 1)
+                x = None
+            elif kind in ("region", "cost"):
+                continue
+            else:
+                raise NotImplementedError("block type %r is outside the MI355X hot path" % kind)
+        if result is None:
+            if x is None:
+                raise RuntimeError("network produced no output")
+            result = ops.nhwc_to_nchw(x)
+        return result, tape

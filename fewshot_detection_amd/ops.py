@@ -47,6 +47,11 @@ def new_view(B, H, W, C, device, ld=None):
     return View(torch.empty((B * H * W, ld or C), dtype=torch.float32, device=device), B, H, W, C)
 
 
+def fill(t, value):
+    check(lib().fsd_fill(t.data_ptr(), float(value), t.numel(), _stream()), "fsd_fill")
+    return t
+
+
 def nchw_to_nhwc(x, pad_to=4, out=None):
     """(B,C,H,W) contiguous -> View with channels padded (zeros) to a multiple of `pad_to`."""
     require_device(x)
@@ -56,7 +61,7 @@ def nchw_to_nhwc(x, pad_to=4, out=None):
     if out is None:
         out = new_view(B, H, W, Cp, x.device)
         if Cp != Cc:
-            check(lib().fsd_fill(out.t.data_ptr(), 0.0, out.t.numel(), _stream()), "fsd_fill")
+            fill(out.t, 0.0)
     check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, out.ptr, H * W * out.ld, out.ld,
                                       B, Cc, H * W, _stream()), "fsd_transpose_batched")
     return out
@@ -89,7 +94,10 @@ def pack_weight(w, mode=0):
     return out
 
 
-def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False):
+PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per conv launch
+
+
+def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None):
     """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out)."""
     dev = xv.t.device
     partial = None
@@ -102,9 +110,15 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if bn_partial:
         tiles = lib().fsd_conv_row_tiles(xv.pixels, cout)
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().fsd_conv2d_fwd(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
                                xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()),
           "fsd_conv2d_fwd")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels))
     return y, partial
 
 
