@@ -88,9 +88,9 @@ def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
     from oracle.net import OracleDarknet
     from oracle.region import region_loss_v2
     from fewshot_detection_amd.cfg import parse_cfg
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    Bs, Ns = 2, min(args.classes, 3)
+    Bs, Ns = 1, min(args.classes, 2)
     ora = OracleDarknet(dyn_cfg, rw_cfg).train()
     x, metax, mask, tgt = synth_episode(123, Bs, Ns, args.size, args.support)
     blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
@@ -106,8 +106,7 @@ def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
         return time.time() - t0
 
     once()
-    ts = sorted(once() for _ in range(2))
-    t = ts[0]
+    t = once()
     eps = 1.0 / (t * (full_flops * mult) / (sample_flops * mult))
     return {"value": eps, "unit": "episodes/s", "cores": cores, "kind": "port",
             "sample": "oracle (PyTorch-CPU fp32) %s of B=%d queries %dx%d + N=%d supports %dx%d in %.2f s, "
@@ -128,6 +127,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "forward"], default=None)
     ap.add_argument("--neg", default="1", help="cfg.neg_ratio ('full' or a number; metayolo.data uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,6 +206,12 @@ def main():
         conv_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
         conv_flops = sum(f for _, _, f in prof)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        if args.per_layer:
+            per = len(prof) // max(1, args.steps)
+            for i in range(per):
+                ms_i = sum(prof[s * per + i][0].elapsed_time(prof[s * per + i][1]) for s in range(args.steps)) / args.steps
+                fl = prof[i][2]
+                sys.stderr.write("conv launch %2d: %8.3f ms  %8.2f GFLOP  %6.1f TFLOP/s\n" % (i, ms_i, fl / 1e9, fl / ms_i / 1e9))
         blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
         det = conv_flops_per_image(blocks, args.size)
         full_flops = (args.batch * det + args.classes * conv_flops_per_image(lblocks, args.support)

@@ -2,6 +2,12 @@
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It MUST be in
+# the process before libfsdet_hip.so is opened so that both resolve to ONE runtime (one set of
+# contexts/streams); loading ours first would bind it to /opt/rocm's copy and every launch on a
+# torch pointer/stream then fails with hipErrorNoDevice.
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsdet_hip.so")
 
@@ -48,6 +54,9 @@ def lib():
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C fewshot_detection_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
         try:
+            hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.isfile(hip_rt):
+                C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
             handle = C.CDLL(LIB_PATH)
         except OSError as e:
             raise FsdetLibraryError("cannot load %s: %s" % (LIB_PATH, e))

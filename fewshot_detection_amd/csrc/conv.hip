@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   const float* wrow = p.w + (long long)(n0 + r0) * p.Kpad + kq * 4;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
+  unsigned a_mask = 0;     // bit j: ra[j] holds real data (else the tile row is zero padding)
   auto gload = [&](int kc) {
     const int kg = kc * 8 + kq;
     const int tap = kg / p.cpg;
@@ -87,14 +88,17 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
     const int ky = tap / p.ks, kx = tap - ky * p.ks;
     const int dy = ky - p.pad, dx = kx - p.pad;
     const bool kvalid = kg < p.kgroups;
+    a_mask = 0;
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const int iy = a_y[j] + dy, ix = a_x[j] + dx;
       const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      // unconditional load from a clamped address + select: keeps the loads branch-free and in flight
+      // Always load (from a clamped, valid address); the zero-select happens in sstore(), i.e.
+      // AFTER the MFMA block, so the loads stay in flight behind the matrix work instead of being
+      // waited for right here.
       const long long off = ok ? (a_base[j] + (long long)iy * p.W + ix) * p.x_ld + c4 * 4 : 0;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);
-      ra[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[j] = *reinterpret_cast<const f32x4*>(p.x + off);
+      a_mask |= ok ? (1u << j) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j)
@@ -102,8 +106,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   };
   auto sstore = [&](float* st) {
 #pragma unroll
-    for (int j = 0; j < A_PER_T; ++j)
-      *reinterpret_cast<f32x4*>(st + (r0 + 32 * j) * kLd + kq * 4) = ra[j];
+    for (int j = 0; j < A_PER_T; ++j) {
+      const f32x4 v = (a_mask >> j) & 1u ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(st + (r0 + 32 * j) * kLd + kq * 4) = v;
+    }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j)
       *reinterpret_cast<f32x4*>(st + (BM + r0 + 32 * j) * kLd + kq * 4) = rb[j];
@@ -148,7 +154,9 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   for (int kc = 0; kc < p.nk; ++kc) {
     const bool more = kc + 1 < p.nk;
     if (more) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);     // keep every use of the prefetched registers below the MFMAs
     compute(smem + cur * STAGE);
+    __builtin_amdgcn_sched_barrier(0);
     if (more) sstore(smem + (cur ^ 1) * STAGE);
     __syncthreads();
     cur ^= 1;
@@ -284,6 +292,7 @@ extern "C" size_t fsd_packed_weight_elems(int rows, int red, int ksize) {
 
 extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ksize,
                                     int mode, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!w_oihw || !w_packed || cout < 1 || cin < 1 || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1))
     return FSD_ERR_ARG;
   const int rows = mode == 0 ? cout : cin, red = mode == 0 ? cin : cout;
@@ -296,6 +305,7 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
 }
 
 extern "C" int fsd_conv_row_tiles(long long pixels, int cout) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   const int bm = tile_bm(tile_cfg(cout));
   return (int)((pixels + bm - 1) / bm);
 }
@@ -303,6 +313,7 @@ extern "C" int fsd_conv_row_tiles(long long pixels, int cout) {
 extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const float* bias,
                               float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
                               int cin, int cout, int ksize, int out_nchw, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !w_packed || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
   if (cin < 4 || (cin & 3) || (x_ld & 3) || x_ld < cin) return FSD_ERR_ARG;

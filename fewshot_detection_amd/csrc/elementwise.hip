@@ -205,6 +205,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
                                const float* gamma, const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int training, float* scale, float* shift,
                                float* save_mean, float* save_invstd, void* workspace, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!scale || !shift || channels < 1 || !running_mean || !running_var) return FSD_ERR_ARG;
   int n_slots = 0;
   if (training) {
@@ -223,6 +224,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
 extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, const float* shift,
                                    float slope, int pool, float* z, long long z_ld, int batch, int height,
                                    int width, int channels, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!y || !z || batch < 1 || channels < 4 || (channels & 3) || (y_ld & 3) || (z_ld & 3)) return FSD_ERR_ARG;
   if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
   const int OH = pool == 1 ? height / 2 : height, OW = pool == 1 ? width / 2 : width;
@@ -242,6 +244,7 @@ extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* 
 extern "C" int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
                                      float* dst, long long dst_batch_stride, long long dst_row_stride, int batch,
                                      int rows, int cols, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!src || !dst || batch < 1 || rows < 1 || cols < 1 || batch > 65535) return FSD_ERR_ARG;
   const dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
@@ -251,6 +254,7 @@ extern "C" int fsd_transpose_batched(const float* src, long long src_batch_strid
 }
 
 extern "C" int fsd_fill(float* dst, float value, long long count, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!dst || count < 0) return FSD_ERR_ARG;
   if (count == 0) return FSD_OK;
   long long blocks = (count + 255) / 256;
@@ -261,6 +265,7 @@ extern "C" int fsd_fill(float* dst, float value, long long count, hipStream_t st
 
 extern "C" int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, int batch, int height,
                              int width, int channels, int stride, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !out || stride < 1 || height % stride || width % stride || (channels & 3) || (x_ld & 3) || (out_ld & 3))
     return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * (channels / 4);
@@ -271,6 +276,7 @@ extern "C" int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long lo
 
 extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch, int height,
                                       int width, int channels, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !out || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
   if (height != width) return FSD_ERR_UNSUPPORTED;   // pooling.py:23-27 assumes a square map
   const long long total = (long long)batch * channels;
@@ -281,6 +287,7 @@ extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out
 
 extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,
                                     int hw, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !w || !out || batch < 1 || n_cls < 1 || channels < 1 || hw < 1) return FSD_ERR_ARG;
   const long long total = (long long)batch * n_cls * channels * hw;
   hipLaunchKernelGGL(dynamic_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, w, out, n_cls,
@@ -291,6 +298,7 @@ extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, 
 extern "C" int fsd_fold_reweight_head(const float* head_w, const float* head_b, const float* dyn,
                                       float* w_eff_packed, float* bias_eff, int n_cls, int out_ch, int channels,
                                       hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!head_w || !dyn || !w_eff_packed || n_cls < 1 || out_ch < 1 || channels < 4 || (channels & 3)) return FSD_ERR_ARG;
   const int rows_pad = (n_cls * out_ch + 127) / 128 * 128;
   const int kpad = (channels + 31) / 32 * 32;

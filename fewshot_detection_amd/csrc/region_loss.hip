@@ -301,6 +301,7 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
                                        float class_scale, float thresh, long long seen,
                                        int max_boxes, int softmax_over_rows, int zero_tcls,
                                        float* dbg_targets, hipStream_t stream) {
+  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!output || !target || !keep || !grad_output || !loss_out || !workspace || !anchors_host)
     return FSD_ERR_ARG;
   if (num_anchors < 1 || num_anchors > kMaxAnchors || rows_per_image < 1 || rows % rows_per_image)
