@@ -35,6 +35,19 @@ PROTOTYPES = {
     "fsd_global_maxpool_fwd": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_dynamic_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_fold_reweight_head": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fsd_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "fsd_conv2d_wgrad": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_act_bwd_rows": (_i, [_ll]),
+    "fsd_reduce_workspace_bytes": (_sz, [_i]),
+    "fsd_bn_act_pool_bwd": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _p, _p, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_bn_bwd_finalize": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _p, _p]),
+    "fsd_bn_bwd_apply": (_i, [_p, _p, _ll, _p, _p, _p, _ll, _i, _p]),
+    "fsd_colsum_partials": (_i, [_p, _ll, _p, _ll, _i, _p]),
+    "fsd_reorg_bwd": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
+    "fsd_global_maxpool_bwd": (_i, [_p, _p, _p, _ll, _i, _i, _i, _i, _p]),
+    "fsd_add_inplace": (_i, [_p, _ll, _p, _ll, _ll, _i, _p]),
+    "fsd_head_unfold_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
     "fsd_version": (C.c_char_p, []),
 }
 

@@ -1,5 +1,116 @@
-"""Reverse sweep over an engine tape (gradients of the detector / reweighting net)."""
+"""Reverse sweep over an engine tape: gradients of a cfg network (detector or reweighting net)
+w.r.t. its parameters and its reweighting vectors, entirely on the HIP kernels.
+
+Per fused conv block (reverse of engine.Network._conv):
+    dz (+ dz_full) --fsd_bn_act_pool_bwd--> dt, partial sums     (maxpool argmax recomputed from y)
+    partial sums   --fsd_bn_bwd_finalize--> dgamma, dbeta, coefficients
+    dt             --fsd_bn_bwd_apply-----> dy                  (in place)
+    dy, x          --fsd_conv2d_wgrad-----> dW                  (split-K MFMA GEMM over pixels)
+    dy, W flipped  --fsd_conv2d_fwd-------> dx                  (same implicit-GEMM kernel as the forward)
+"""
+import torch
+
+from . import ops
+from .ops import View
+
+AVAILABLE = True
+
+
+def _accumulate(grads, view, g):
+    key = id(view)
+    if key in grads:
+        ops.add_inplace(grads[key], g)
+    else:
+        grads[key] = g
+
+
+def _conv_backward(net, rec, grads, pgrads, first_input):
+    gz = grads.pop(id(rec["z"]), None)
+    gzf = grads.pop(id(rec["z_full"]), None) if rec.get("z_full") is not None else None
+    if gz is None and gzf is None:
+        return
+    conv, bn, xv, k, cout = rec["conv"], rec["bn"], rec["x"], rec["k"], rec["cout"]
+    cin = conv.weight.shape[1]
+    direct = bn is None and rec["slope"] == 1.0 and rec["pool"] == 0
+    if direct:
+        dy = gz
+        if conv.bias is not None:
+            pgrads[id(conv.bias)] = ops.colsum(dy, cout)
+    else:
+        yv = rec["y"]
+        pool = rec["pool"]
+        if gz is None:                       # only the un-pooled tap carries gradient
+            gz, gzf, pool = gzf, None, 0
+        dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, rec.get("scale"), rec.get("shift"), rec.get("mean"),
+                                          rec.get("invstd"), rec["slope"], pool)
+        s1, s2, coef = ops.reduce_partials(partial, yv.pixels, cout, scale=rec.get("scale"), want_coef=bn is not None)
+        if bn is not None:
+            pgrads[id(bn.bias)] = s1
+            pgrads[id(bn.weight)] = s2
+            if not rec["training"]:          # frozen statistics: dy = scale * dt
+                coef[1:].zero_()
+            ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
+        elif conv.bias is not None:
+            pgrads[id(conv.bias)] = s1
+        dy = dt
+    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k)
+    if xv is not first_input:
+        dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
+        wp = net.cache.get(conv.weight, mode=1)
+        dx, _ = ops.conv2d(dyv, wp, xv.C, k)
+        _accumulate(grads, xv, dx)
 
 
 def run(net, tape, grad_out, params):
-    raise NotImplementedError("backward pass lands in the next milestone")
+    """Returns {"params": [grad or None, ... in the order of `params`], "dyn": grad of the vectors}."""
+    ops.require_device(grad_out)
+    grads = {}
+    pgrads = {}
+    grad_dyn = None
+    first_input = tape[0]["x"]
+    for rec in reversed(tape):
+        kind = rec["kind"]
+        if kind == "output":
+            x = rec["x"]
+            g = ops.nchw_to_nhwc(grad_out.view(x.B, x.C, x.H, x.W), pad_to=4)
+            grads[id(x)] = View(g.t, x.B, x.H, x.W, x.C, 0)
+        elif kind == "head":
+            x, head, dyn, n_cls, o_ch = rec["x"], rec["head"], rec["dyn"], rec["n_cls"], rec["o_ch"]
+            rows = n_cls * o_ch
+            g = ops.nchw_to_nhwc(grad_out.view(x.B, rows, x.H, x.W), pad_to=4)       # (B*HW, rows padded)
+            w_eff = rec["w_eff"][:rows * x.C].view(rows, x.C, 1, 1)
+            dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, mode=1), x.C, 1)
+            _accumulate(grads, x, dx)
+            dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1)
+            d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach())
+            pgrads[id(head.weight)] = d_head
+            grad_dyn = d_dyn
+            if head.bias is not None:
+                pgrads[id(head.bias)] = ops.colsum(g, rows).view(n_cls, o_ch).sum(0)
+        elif kind == "globalmax":
+            x = rec["x"]
+            _accumulate(grads, x, ops.global_maxpool_bwd(grad_out.reshape(x.B, x.C), rec["arg"], x))
+        elif kind == "route":
+            if len(rec["src"]) == 2:
+                g = grads.pop(id(rec["z"]), None)
+                if g is not None:
+                    off = 0
+                    for pv in rec["src_views"]:
+                        _accumulate(grads, pv, View(g.t, g.B, g.H, g.W, pv.C, g.c0 + off))
+                        off += pv.C
+        elif kind == "reorg":
+            g = grads.pop(id(rec["z"]), None)
+            if g is not None:
+                _accumulate(grads, rec["x"], ops.reorg_bwd(g, rec["x"], rec["stride"]))
+        elif kind == "pool":
+            g = grads.pop(id(rec["z"]), None)
+            if g is not None:
+                dt, _ = ops.bn_act_pool_bwd(g, None, rec["x"], None, None, None, None, 1.0, rec["pool"])
+                _accumulate(grads, rec["x"], dt)
+        elif kind == "conv":
+            _conv_backward(net, rec, grads, pgrads, first_input)
+        elif kind == "input":
+            pass
+        else:
+            raise NotImplementedError("backward of tape record %r" % kind)
+    return {"params": [pgrads.get(id(p)) for p in params], "dyn": grad_dyn}

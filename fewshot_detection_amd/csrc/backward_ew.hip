@@ -1,0 +1,359 @@
+// HBM-bound backward companions: gradient through maxpool + leaky + BatchNorm (two passes with
+// per-channel reductions in between), reorg / global-max scatter, the un-folding of the fused
+// reweighting (x) head gradient, and small utilities.  NHWC, float4 along channels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsdet.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPixPerBlock = 256;     // pixels reduced by one block of the first pass
+constexpr int kSlots = 64;
+
+inline unsigned blocks_for(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+struct ActBwdArgs {
+  const float* dz;        // grad of the (pooled) block output, NHWC (B,OH,OW,C), stride dz_ld
+  const float* dz_full;   // optional grad of the un-pooled activation (a [route] tapped it)
+  const float* y;         // raw conv output (B,H,W,C), stride y_ld
+  const float* scale;     // BN affine (nullable = identity)
+  const float* shift;
+  const float* mean;      // BN batch statistics (nullable when no BN)
+  const float* invstd;
+  float* dt;              // out: grad wrt the BN output / pre-activation, dense (pixels, C)
+  float* partial;         // out: [blocks_x][C][2]  (sum dt, sum dt*xhat)
+  long long dz_ld, dzf_ld, y_ld;
+  int H, W, OH, OW, C, pool;
+  long long pixels;
+  float slope;
+};
+
+// One block: 64 channel groups (256 channels) x 4 pixel lanes, looping over kPixPerBlock pixels.
+__global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
+  __shared__ float s_red[4][64][8];
+  const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int g = blockIdx.y * 64 + gl;
+  const int cg = p.C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc = (g_ok && p.scale) ? ld4(p.scale + g * 4) : one;
+  const f32x4 sh = (g_ok && p.shift) ? ld4(p.shift + g * 4) : zero;
+  const f32x4 mu = (g_ok && p.mean) ? ld4(p.mean + g * 4) : zero;
+  const f32x4 is = (g_ok && p.invstd) ? ld4(p.invstd + g * 4) : one;
+  f32x4 s1 = zero, s2 = zero;
+  const long long p0 = (long long)blockIdx.x * kPixPerBlock;
+  if (g_ok) {
+    for (int it = pl; it < kPixPerBlock; it += 4) {
+      const long long pix = p0 + it;
+      if (pix >= p.pixels) break;
+      const int ix = (int)(pix % p.W);
+      const long long t = pix / p.W;
+      const int iy = (int)(t % p.H);
+      const long long b = t / p.H;
+      const f32x4 yv = ld4(p.y + pix * p.y_ld + g * 4);
+      f32x4 tv, gin = zero;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tv[k] = yv[k] * sc[k] + sh[k];
+      if (p.pool == 0) {
+        gin = ld4(p.dz + pix * p.dz_ld + g * 4);
+      } else {
+        // windows that contain this pixel: stride 2 -> one, stride 1 -> up to four
+        const int oy_lo = p.pool == 1 ? iy >> 1 : (iy > 0 ? iy - 1 : 0), oy_hi = p.pool == 1 ? iy >> 1 : iy;
+        const int ox_lo = p.pool == 1 ? ix >> 1 : (ix > 0 ? ix - 1 : 0), ox_hi = p.pool == 1 ? ix >> 1 : ix;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+          for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            if (oy >= p.OH || ox >= p.OW) continue;
+            const int y0 = p.pool == 1 ? 2 * oy : oy, x0 = p.pool == 1 ? 2 * ox : ox;
+            // first maximum in scan order wins (like torch's max_pool2d backward)
+            f32x4 best;
+            int by[4], bx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int wy = min(y0 + (q >> 1), p.H - 1), wx = min(x0 + (q & 1), p.W - 1);
+              const f32x4 v = ld4(p.y + ((b * p.H + wy) * (long long)p.W + wx) * p.y_ld + g * 4);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                float a = v[k] * sc[k] + sh[k];
+                a = a > 0.f ? a : a * p.slope;
+                if (q == 0 || a > best[k]) { best[k] = a; by[k] = wy; bx[k] = wx; }
+              }
+            }
+            const f32x4 gz = ld4(p.dz + ((b * p.OH + oy) * (long long)p.OW + ox) * p.dz_ld + g * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (by[k] == iy && bx[k] == ix) gin[k] += gz[k];
+          }
+      }
+      if (p.dz_full) {
+        const f32x4 gf = ld4(p.dz_full + pix * p.dzf_ld + g * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gin[k] += gf[k];
+      }
+      f32x4 d;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d[k] = tv[k] > 0.f ? gin[k] : gin[k] * p.slope;
+        s1[k] += d[k];
+        s2[k] += d[k] * ((yv[k] - mu[k]) * is[k]);
+      }
+      *reinterpret_cast<f32x4*>(p.dt + pix * p.C + g * 4) = d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_red[pl][gl][k] = s1[k];
+    s_red[pl][gl][4 + k] = s2[k];
+  }
+  __syncthreads();
+  if (pl == 0 && g_ok) {
+    float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dst[2 * k] = s_red[0][gl][k] + s_red[1][gl][k] + s_red[2][gl][k] + s_red[3][gl][k];
+      dst[2 * k + 1] = s_red[0][gl][4 + k] + s_red[1][gl][4 + k] + s_red[2][gl][4 + k] + s_red[3][gl][4 + k];
+    }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ slots, int rows, int two_c) {
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  const int s = blockIdx.x;
+  if (e >= two_c) return;
+  double acc = 0.0;
+  for (int t = s; t < rows; t += kSlots) acc += (double)partial[(long long)t * two_c + e];
+  slots[(long long)s * two_c + e] = acc;
+}
+
+// dgamma/dbeta (or dbias) and the per-channel coefficients of  dy = c1 * (dt - c2 - xhat * c3)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+                                       const float* __restrict__ scale, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= channels) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < n_slots; ++k) {
+    s1 += slots[((long long)k * channels + c) * 2 + 0];
+    s2 += slots[((long long)k * channels + c) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  if (coef) {
+    coef[c] = scale ? scale[c] : 1.f;
+    coef[channels + c] = (float)(s1 / count);
+    coef[2 * channels + c] = (float)(s2 / count);
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(float* __restrict__ dt, const float* __restrict__ y, long long y_ld,
+                                    const float* __restrict__ coef, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, int C, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C >> 2;
+  const int g = (int)(idx % cg);
+  const long long pix = idx / cg;
+  const f32x4 c1 = ld4(coef + g * 4), c2 = ld4(coef + C + g * 4), c3 = ld4(coef + 2 * C + g * 4);
+  const f32x4 mu = ld4(mean + g * 4), is = ld4(invstd + g * 4);
+  const f32x4 yv = ld4(y + pix * y_ld + g * 4);
+  f32x4 d = ld4(dt + pix * C + g * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] = c1[k] * (d[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
+  *reinterpret_cast<f32x4*>(dt + pix * C + g * 4) = d;
+}
+
+// column sums of a (rows, ld) matrix, any C: partial[blocks][C][2] with the second slot zero
+__global__ void colsum_kernel(const float* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)blockIdx.x * kPixPerBlock;
+  float s = 0.f;
+  for (int i = 0; i < kPixPerBlock && r0 + i < rows; ++i) s += m[(r0 + i) * ld + c];
+  partial[((long long)blockIdx.x * C + c) * 2] = s;
+  partial[((long long)blockIdx.x * C + c) * 2 + 1] = 0.f;
+}
+
+__global__ void reorg_bwd_kernel(const float* __restrict__ dout, long long dout_ld, float* __restrict__ dx, long long dx_ld,
+                                 int H, int W, int C, int s, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C / 4;
+  const int g = (int)(idx % cg);
+  long long t = idx / cg;
+  const int ix = (int)(t % W); t /= W;
+  const int iy = (int)(t % H);
+  const long long b = t / H;
+  const int OH = H / s, OW = W / s;
+  const int oi = iy / s, di = iy - oi * s, oj = ix / s, dj = ix - oj * s;
+  const f32x4 v = ld4(dout + ((b * OH + oi) * (long long)OW + oj) * dout_ld + (di * s + dj) * C + g * 4);
+  *reinterpret_cast<f32x4*>(dx + ((b * H + iy) * (long long)W + ix) * dx_ld + g * 4) = v;
+}
+
+__global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ argmax, float* __restrict__ dx,
+                                      long long dx_ld, int HW, int C, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, pixel, c)
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long t = idx / C;
+  const int pix = (int)(t % HW);
+  const long long b = t / HW;
+  dx[(b * HW + pix) * dx_ld + c] = argmax[b * C + c] == pix ? dout[b * C + c] : 0.f;
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, long long dst_ld, const float* __restrict__ src, long long src_ld,
+                                   int C, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long r = idx / C;
+  dst[r * dst_ld + c] += src[r * src_ld + c];
+}
+
+// d head_w[o,c] = sum_n dWeff[n*O+o, c] * dyn[n,c];  d dyn[n,c] = sum_o dWeff[n*O+o, c] * head_w[o,c]
+__global__ void head_unfold_kernel(const float* __restrict__ dweff, const float* __restrict__ head_w,
+                                   const float* __restrict__ dyn, float* __restrict__ d_head_w, float* __restrict__ d_dyn,
+                                   int n_cls, int O, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int which = blockIdx.y;           // [0, O): one head row;  [O, O + n_cls): one class vector
+  if (which < O) {
+    float s = 0.f;
+    for (int n = 0; n < n_cls; ++n) s += dweff[((long long)n * O + which) * C + c] * dyn[(long long)n * C + c];
+    d_head_w[(long long)which * C + c] = s;
+  } else {
+    const int n = which - O;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s += dweff[((long long)n * O + o) * C + c] * head_w[(long long)o * C + c];
+    d_dyn[(long long)n * C + c] = s;
+  }
+}
+
+// SGD with momentum + L2 weight decay over one flat fp32 buffer (torch.optim.SGD semantics)
+__global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ mom, float lr,
+                           float momentum, float weight_decay, int first_step, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float wi = w[i];
+    const float d = g[i] + weight_decay * wi;
+    const float b = first_step ? d : momentum * mom[i] + d;
+    mom[i] = b;
+    w[i] = wi - lr * b;
+  }
+}
+
+}  // namespace
+
+extern "C" int fsd_act_bwd_rows(long long pixels) { return (int)((pixels + kPixPerBlock - 1) / kPixPerBlock); }
+
+extern "C" size_t fsd_reduce_workspace_bytes(int channels) { return (size_t)kSlots * channels * 2 * sizeof(double); }
+
+extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
+                                   const float* y, long long y_ld, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, float slope, int pool, float* dt,
+                                   float* partial, int batch, int height, int width, int channels,
+                                   hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dz || !y || !dt || !partial || batch < 1 || channels < 4 || (channels & 3) || (dz_ld & 3) || (y_ld & 3))
+    return FSD_ERR_ARG;
+  if (dz_full && (dz_full_ld & 3)) return FSD_ERR_ARG;
+  if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
+  ActBwdArgs a;
+  a.dz = dz; a.dz_full = dz_full; a.y = y; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.dt = dt; a.partial = partial; a.dz_ld = dz_ld; a.dzf_ld = dz_full_ld; a.y_ld = y_ld;
+  a.H = height; a.W = width; a.OH = pool == 1 ? height / 2 : height; a.OW = pool == 1 ? width / 2 : width;
+  a.C = channels; a.pool = pool; a.pixels = (long long)batch * height * width; a.slope = slope;
+  const dim3 grid(blocks_for(a.pixels, kPixPerBlock), (channels / 4 + 63) / 64);
+  hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long count, int channels, const float* scale,
+                                   float* dgamma, float* dbeta, float* coef, void* workspace, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!partial || !workspace || rows < 1 || channels < 1 || count < 1) return FSD_ERR_ARG;
+  const int n_slots = rows < kSlots ? rows : kSlots;
+  const int two_c = 2 * channels;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial,
+                     reinterpret_cast<double*>(workspace), rows, two_c);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
+                     reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, scale, dgamma, dbeta,
+                     coef);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const float* coef, const float* mean,
+                                const float* invstd, long long pixels, int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dt || !y || !coef || !mean || !invstd || (channels & 3) || (y_ld & 3)) return FSD_ERR_ARG;
+  const long long total = pixels * (channels / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
+                     invstd, channels, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
+                                   hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!m || !partial || rows < 1 || channels < 1) return FSD_ERR_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(rows, kPixPerBlock), (channels + 255) / 256), dim3(256), 0, stream, m,
+                     ld, partial, channels, rows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_reorg_bwd(const float* dout, long long dout_ld, float* dx, long long dx_ld, int batch, int height,
+                             int width, int channels, int stride, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !dx || stride < 1 || height % stride || width % stride || (channels & 3) || (dout_ld & 3) || (dx_ld & 3))
+    return FSD_ERR_ARG;
+  const long long total = (long long)batch * height * width * (channels / 4);
+  hipLaunchKernelGGL(reorg_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, dout_ld, dx, dx_ld,
+                     height, width, channels, stride, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_global_maxpool_bwd(const float* dout, const int* argmax, float* dx, long long dx_ld, int batch,
+                                      int height, int width, int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !argmax || !dx) return FSD_ERR_ARG;
+  const long long total = (long long)batch * height * width * channels;
+  hipLaunchKernelGGL(global_max_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, argmax, dx, dx_ld,
+                     height * width, channels, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_add_inplace(float* dst, long long dst_ld, const float* src, long long src_ld, long long rows,
+                               int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dst || !src || rows < 1 || channels < 1) return FSD_ERR_ARG;
+  const long long total = rows * channels;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dst, dst_ld, src, src_ld,
+                     channels, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dyn, float* d_head_w,
+                                   float* d_dyn, int n_cls, int out_ch, int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dweff || !head_w || !dyn || !d_head_w || !d_dyn) return FSD_ERR_ARG;
+  hipLaunchKernelGGL(head_unfold_kernel, dim3((channels + 255) / 256, out_ch + n_cls), dim3(256), 0, stream, dweff,
+                     head_w, dyn, d_head_w, d_dyn, n_cls, out_ch, channels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
+                            float weight_decay, int first_step, long long count, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w || !grad || !momentum_buf || count < 0) return FSD_ERR_ARG;
+  if (count == 0) return FSD_OK;
+  long long blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, grad, momentum_buf, lr, momentum,
+                     weight_decay, first_step, count);
+  return (int)hipGetLastError();
+}

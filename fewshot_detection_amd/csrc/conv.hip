@@ -15,6 +15,7 @@
 // accumulator comes out transposed and the store stays coalesced).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fsdet.h"
 
 namespace {
@@ -38,6 +39,8 @@ struct ConvArgs {
   int cpg;       // 16-byte channel groups per tap  (Cin/4)
   int kgroups;   // taps * cpg
   int nk;        // k-chunks
+  int cpt;       // FASTK: chunks per tap (Cin/32)
+  int prio_shift; // tuning: wave priority = (blockIdx >> prio_shift) & 3, <0 = leave at 0
   int Kpad;      // packed weight row length (floats)
   int m_tiles, n_tiles;
 };
@@ -48,7 +51,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK>
 __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves");
   constexpr int TM = BM / WAVES_M / 32;
@@ -58,6 +61,18 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   constexpr int STAGE = (BM + BN) * kLd;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
+  // Co-resident waves on a SIMD (from different workgroups) otherwise alternate MFMAs fairly, run
+  // in lock-step and reach their staging (non-MFMA) phases together, leaving the matrix pipe idle.
+  // Distinct static priorities, keyed on the hardware wave slot (unique per SIMD), de-phase them.
+  if (p.prio_shift >= 0) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> p.prio_shift;   // HW_REG_HW_ID.WAVE_ID
+    switch (slot & 3) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+  }
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -65,8 +80,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int kq = tid & 7, r0 = tid >> 3;
 
+  // Per-thread im2col bookkeeping.  NHWC input and output share the pixel grid (stride 1, "same"
+  // padding), so the input pixel of output pixel `pix` under tap (dy, dx) is pix + dy*W + dx.
   int a_y[A_PER_T], a_x[A_PER_T];
-  long long a_base[A_PER_T];
+  unsigned a_pix[A_PER_T];
 #pragma unroll
   for (int j = 0; j < A_PER_T; ++j) {
     const int pix = m0 + r0 + 32 * j;
@@ -75,34 +92,69 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
     const int yy = rem / p.W;
     a_y[j] = pix < p.M ? yy : -(1 << 20);       // out-of-range rows fail the bounds test below
     a_x[j] = rem - yy * p.W;
-    a_base[j] = (long long)b * p.HW;
+    a_pix[j] = (unsigned)pix;
   }
   const float* wrow = p.w + (long long)(n0 + r0) * p.Kpad + kq * 4;
+  const unsigned x_ld = (unsigned)p.x_ld;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
   unsigned a_mask = 0;     // bit j: ra[j] holds real data (else the tile row is zero padding)
-  auto gload = [&](int kc) {
-    const int kg = kc * 8 + kq;
-    const int tap = kg / p.cpg;
-    const int c4 = kg - tap * p.cpg;
-    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+
+  // FASTK (Cin % 32 == 0): a k-chunk is 32 channels of ONE filter tap, so the bounds tests and
+  // row offsets are recomputed only when the tap changes (every Cin/32 chunks); per chunk the
+  // address work is one add per load.  Offsets are 32-bit element indices (launcher checks range).
+  unsigned a_off[A_PER_T];
+  unsigned tap_mask = 0;
+  int f_tap = 0, f_cc = 0;
+  auto retap = [&]() {
+    const int ky = f_tap / p.ks, kx = f_tap - ky * p.ks;
     const int dy = ky - p.pad, dx = kx - p.pad;
-    const bool kvalid = kg < p.kgroups;
-    a_mask = 0;
+    const int shift = dy * p.W + dx;
+    tap_mask = 0;
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
-      const int iy = a_y[j] + dy, ix = a_x[j] + dx;
-      const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      // Always load (from a clamped, valid address); the zero-select happens in sstore(), i.e.
-      // AFTER the MFMA block, so the loads stay in flight behind the matrix work instead of being
-      // waited for right here.
-      const long long off = ok ? (a_base[j] + (long long)iy * p.W + ix) * p.x_ld + c4 * 4 : 0;
-      ra[j] = *reinterpret_cast<const f32x4*>(p.x + off);
-      a_mask |= ok ? (1u << j) : 0u;
+      const bool ok = (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
+      a_off[j] = ok ? (a_pix[j] + (unsigned)shift) * x_ld + (unsigned)(kq * 4) : (unsigned)(kq * 4);
+      tap_mask |= ok ? (1u << j) : 0u;
     }
+  };
+  if constexpr (FASTK) retap();
+
+  auto gload = [&](int kc) {
+    if constexpr (FASTK) {
+      const unsigned coff = (unsigned)f_cc * kBK;
 #pragma unroll
-    for (int j = 0; j < B_PER_T; ++j)
-      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+      for (int j = 0; j < A_PER_T; ++j) ra[j] = *reinterpret_cast<const f32x4*>(p.x + (a_off[j] + coff));
+      a_mask = tap_mask;
+#pragma unroll
+      for (int j = 0; j < B_PER_T; ++j)
+        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+      if (++f_cc == p.cpt) {      // uniform branch: next chunk starts a new tap
+        f_cc = 0;
+        ++f_tap;
+        retap();
+      }
+    } else {
+      const int kg = kc * 8 + kq;
+      const int tap = kg / p.cpg;
+      const int c4 = kg - tap * p.cpg;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const int dy = ky - p.pad, dx = kx - p.pad;
+      const bool kvalid = kg < p.kgroups;
+      a_mask = 0;
+#pragma unroll
+      for (int j = 0; j < A_PER_T; ++j) {
+        const bool ok = kvalid && (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
+        // Always load (from a clamped, valid address); the zero-select happens in sstore(), i.e.
+        // AFTER the MFMA block, so the loads stay in flight behind the matrix work.
+        const unsigned off = ok ? (a_pix[j] + (unsigned)(dy * p.W + dx)) * x_ld + (unsigned)(c4 * 4) : 0u;
+        ra[j] = *reinterpret_cast<const f32x4*>(p.x + off);
+        a_mask |= ok ? (1u << j) : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < B_PER_T; ++j)
+        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+    }
   };
   auto sstore = [&](float* st) {
 #pragma unroll
@@ -146,7 +198,8 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
     }
   };
 
-  // ---- main loop: register-staged double buffer, one barrier per k-chunk
+  // ---- main loop: global -> registers (prefetch) -> LDS.  STAGES = 2: two LDS buffers, one
+  // barrier per k-chunk.  STAGES = 1: one buffer, two barriers, half the LDS (more blocks per CU).
   gload(0);
   sstore(smem);
   __syncthreads();
@@ -157,9 +210,15 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);     // keep every use of the prefetched registers below the MFMAs
     compute(smem + cur * STAGE);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) sstore(smem + (cur ^ 1) * STAGE);
-    __syncthreads();
-    cur ^= 1;
+    if constexpr (STAGES == 2) {
+      if (more) sstore(smem + (cur ^ 1) * STAGE);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();
+      if (more) sstore(smem);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -261,27 +320,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// tile shape by output width: narrow layers get tall tiles so the MFMA work per staged byte stays high
-inline int tile_cfg(int cout) { return cout <= 32 ? 2 : (cout <= 64 ? 1 : 0); }
-inline int tile_bm(int cfg) { return cfg == 0 ? 128 : 256; }
-inline int tile_bn(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
+// Tile configurations {BM, BN, waves_m, waves_n, stages}.
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kCfgs[] = {{128, 128}, {256, 64}, {256, 32}, {128, 64}, {128, 32}, {256, 128}, {128, 128}, {128, 64}, {128, 32}};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-template <int BM, int BN, int WM, int WN>
-int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(BM + BN) * kLd * sizeof(float);
-  const int grid = a.m_tiles * a.n_tiles;
-  if (nchw) {
-    auto k = conv_gemm_kernel<BM, BN, WM, WN, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, stream, a);
-  } else {
-    auto k = conv_gemm_kernel<BM, BN, WM, WN, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, stream, a);
-  }
+// tile shape by output width: narrow layers get narrower tiles so no MFMA columns are wasted
+inline int tile_cfg(int cout) {
+  static const char* env = getenv("FSD_CONV_TILE");      // tuning aid: force a configuration
+  if (env && env[0] >= '0' && env[0] < '0' + kNumCfgs) return env[0] - '0';
+  return cout <= 32 ? 2 : (cout <= 64 ? 1 : 0);
+}
+
+template <typename K>
+int launch_kernel(K k, const ConvArgs& a, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles), dim3(kThreads), lds, stream, a);
   return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
+  const size_t lds = STAGES * (size_t)(BM + BN) * kLd * sizeof(float);
+  const bool fast = a.cpt > 0;
+  if (nchw)
+    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true>, a, lds, stream)
+                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, false>, a, lds, stream);
+  return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true>, a, lds, stream)
+              : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, false>, a, lds, stream);
 }
 
 }  // namespace
@@ -306,7 +373,7 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
 
 extern "C" int fsd_conv_row_tiles(long long pixels, int cout) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
-  const int bm = tile_bm(tile_cfg(cout));
+  const int bm = kCfgs[tile_cfg(cout)].bm;
   return (int)((pixels + bm - 1) / bm);
 }
 
@@ -331,13 +398,27 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   a.kgroups = ksize * ksize * a.cpg;
   a.Kpad = round_up(ksize * ksize * cin, kBK);
   a.nk = a.Kpad / kBK;
+  a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
+  {
+    static const char* env = getenv("FSD_CONV_PRIO");
+    a.prio_shift = env ? atoi(env) : -1;
+  }
+  // 32-bit element offsets inside the kernel
+  if ((pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
   const int cfg = tile_cfg(cout);
-  const int bm = tile_bm(cfg), bn = tile_bn(cfg);
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   a.m_tiles = (int)((pixels + bm - 1) / bm);
   a.n_tiles = (cout + bn - 1) / bn;
+  const bool nchw = out_nchw != 0;
   switch (cfg) {
-    case 0: return launch<128, 128, 2, 2>(a, out_nchw != 0, stream);
-    case 1: return launch<256, 64, 4, 1>(a, out_nchw != 0, stream);
-    default: return launch<256, 32, 4, 1>(a, out_nchw != 0, stream);
+    case 0: return launch<128, 128, 2, 2, 2>(a, nchw, stream);
+    case 1: return launch<256, 64, 4, 1, 2>(a, nchw, stream);
+    case 2: return launch<256, 32, 4, 1, 2>(a, nchw, stream);
+    case 3: return launch<128, 64, 2, 2, 2>(a, nchw, stream);
+    case 4: return launch<128, 32, 4, 1, 2>(a, nchw, stream);
+    case 5: return launch<256, 128, 2, 2, 2>(a, nchw, stream);
+    case 6: return launch<128, 128, 2, 2, 1>(a, nchw, stream);
+    case 7: return launch<128, 64, 2, 2, 1>(a, nchw, stream);
+    default: return launch<128, 32, 4, 1, 1>(a, nchw, stream);
   }
 }

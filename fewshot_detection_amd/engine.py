@@ -33,6 +33,15 @@ def _slope(activation):
     raise NotImplementedError("activation %r" % activation)
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Call after updating parameters through raw pointers (fused SGD kernel): torch's version
+    counter does not see such writes, so packed weight copies must be invalidated explicitly."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 class _WeightCache(object):
     """Packed (K-major) copies of conv weights, refreshed when the parameter changes."""
 
@@ -41,7 +50,7 @@ class _WeightCache(object):
 
     def get(self, w, mode=0):
         key = (id(w), mode)
-        tag = (w.data_ptr(), w._version)
+        tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
             hit = (tag, ops.pack_weight(w.detach(), mode))
@@ -231,7 +240,7 @@ class Network(object):
                 else:
                     big = bufs[ind]
                     x = View(big.t, big.B, big.H, big.W, self.widths[ind], 0)
-                tape.append(dict(kind="route", src=src, z=x))
+                tape.append(dict(kind="route", src=src, z=x, src_views=[outs[s_] for s_ in src]))
                 outs[ind] = x
             elif kind == "globalmax":
                 vals, arg = ops.global_maxpool(x, want_argmax=True)
@@ -246,4 +255,5 @@ class Network(object):
             if x is None:
                 raise RuntimeError("network produced no output")
             result = ops.nhwc_to_nchw(x)
+            tape.append(dict(kind="output", x=x))
         return result, tape

@@ -185,3 +185,91 @@ def fold_reweight_head(head_w, head_b, dyn):
                                        w_eff.data_ptr(), b_eff.data_ptr(), N, O, Cc, _stream()),
           "fsd_fold_reweight_head")
     return w_eff, b_eff
+
+
+# ---- backward ------------------------------------------------------------------------------
+
+def conv2d_wgrad(dyv, cout, xv, cin, ksize):
+    """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv."""
+    L = lib()
+    dev = xv.t.device
+    ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
+    check(L.fsd_conv2d_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
+                             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
+    return dw
+
+
+def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
+    """-> (dt View dense (pixels, C), partial [rows][C][2])."""
+    L = lib()
+    dev = yv.t.device
+    dt = new_view(yv.B, yv.H, yv.W, yv.C, dev)
+    partial = torch.empty((L.fsd_act_bwd_rows(yv.pixels), yv.C, 2), dtype=torch.float32, device=dev)
+    check(L.fsd_bn_act_pool_bwd(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
+                                0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift),
+                                _ptr(mean), _ptr(invstd), slope, pool, dt.ptr, partial.data_ptr(), yv.B, yv.H, yv.W,
+                                yv.C, _stream()), "fsd_bn_act_pool_bwd")
+    return dt, partial
+
+
+def reduce_partials(partial, count, channels, scale=None, want_coef=False):
+    """-> (sum_col0 [C], sum_col1 [C], coef [3,C] or None)."""
+    L = lib()
+    dev = partial.device
+    out = torch.empty((2, channels), dtype=torch.float32, device=dev)
+    coef = torch.empty((3, channels), dtype=torch.float32, device=dev) if want_coef else None
+    ws = torch.empty(L.fsd_reduce_workspace_bytes(channels) // 8, dtype=torch.float64, device=dev)
+    check(L.fsd_bn_bwd_finalize(partial.data_ptr(), partial.shape[0], count, channels, _ptr(scale), out[1].data_ptr(),
+                                out[0].data_ptr(), _ptr(coef), ws.data_ptr(), _stream()), "fsd_bn_bwd_finalize")
+    return out[0], out[1], coef
+
+
+def bn_bwd_apply(dt, yv, coef, mean, invstd):
+    check(lib().fsd_bn_bwd_apply(dt.ptr, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                 yv.pixels, yv.C, _stream()), "fsd_bn_bwd_apply")
+    return dt
+
+
+def colsum(v, channels):
+    L = lib()
+    partial = torch.empty((L.fsd_act_bwd_rows(v.pixels), channels, 2), dtype=torch.float32, device=v.t.device)
+    check(L.fsd_colsum_partials(v.ptr, v.ld, partial.data_ptr(), v.pixels, channels, _stream()),
+          "fsd_colsum_partials")
+    s, _, _ = reduce_partials(partial, v.pixels, channels)
+    return s
+
+
+def reorg_bwd(dout, xv, stride):
+    dx = new_view(xv.B, xv.H, xv.W, xv.C, xv.t.device)
+    check(lib().fsd_reorg_bwd(dout.ptr, dout.ld, dx.ptr, dx.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()),
+          "fsd_reorg_bwd")
+    return dx
+
+
+def global_maxpool_bwd(dout, arg, xv):
+    dx = new_view(xv.B, xv.H, xv.W, xv.C, xv.t.device)
+    check(lib().fsd_global_maxpool_bwd(dout.contiguous().data_ptr(), arg.data_ptr(), dx.ptr, dx.ld, xv.B, xv.H, xv.W,
+                                       xv.C, _stream()), "fsd_global_maxpool_bwd")
+    return dx
+
+
+def add_inplace(dst, src):
+    check(lib().fsd_add_inplace(dst.ptr, dst.ld, src.ptr, src.ld, dst.pixels, dst.C, _stream()), "fsd_add_inplace")
+    return dst
+
+
+def head_unfold_bwd(dweff, head_w, dyn):
+    O, Cc = head_w.shape[0], head_w.shape[1]
+    N = dyn.shape[0]
+    d_head = torch.empty((O, Cc, 1, 1), dtype=torch.float32, device=dyn.device)
+    d_dyn = torch.empty((N, Cc, 1, 1), dtype=torch.float32, device=dyn.device)
+    check(lib().fsd_head_unfold_bwd(dweff.data_ptr(), head_w.contiguous().data_ptr(), dyn.contiguous().data_ptr(),
+                                    d_head.data_ptr(), d_dyn.data_ptr(), N, O, Cc, _stream()), "fsd_head_unfold_bwd")
+    return d_head, d_dyn
+
+
+def sgd_step(w, g, buf, lr, momentum, weight_decay, first):
+    check(lib().fsd_sgd_step(w.data_ptr(), g.data_ptr(), buf.data_ptr(), lr, momentum, weight_decay,
+                             1 if first else 0, w.numel(), _stream()), "fsd_sgd_step")

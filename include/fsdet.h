@@ -139,6 +139,51 @@ int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, 
 int fsd_fold_reweight_head(const float* head_w, const float* head_b, const float* dyn, float* w_eff_packed,
                            float* bias_eff, int n_cls, int out_ch, int channels, hipStream_t stream);
 
+/* ---- backward pass ------------------------------------------------------------------------- */
+/* Weight gradient dW[co][ci][ky][kx] = sum_p dy[p][co] * x[p+tap][ci] (replaces autograd through
+ * nn.Conv2d, darknet_meta.py:236-250).  dy: (pixels, dy_ld) NHWC gradient of the raw conv output
+ * (dy_ld % 4 == 0, >= round_up(cout,4)); x: the NHWC input the convolution read.  Split-K over
+ * pixels with a deterministic second-stage reduction; dw_oihw is fully overwritten. */
+size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize);
+int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                     void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                     int cout, int ksize, hipStream_t stream);
+/* (The data gradient is fsd_conv2d_fwd on dy with weights packed in mode 1.) */
+
+/* Gradient through pool(act(y*scale+shift)): dt = d loss / d (y*scale+shift), dense (pixels, C),
+ * plus per-block partial sums [fsd_act_bwd_rows(pixels)][C][2] of (dt, dt*xhat) for the BatchNorm
+ * backward.  dz: grad of the block output (pooled grid if pool != 0); dz_full: optional grad of the
+ * un-pooled activation.  The max-pool argmax is recomputed from y (first maximum in scan order). */
+int fsd_act_bwd_rows(long long pixels);
+size_t fsd_reduce_workspace_bytes(int channels);
+int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
+                        const float* y, long long y_ld, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, float slope, int pool, float* dt,
+                        float* partial, int batch, int height, int width, int channels, hipStream_t stream);
+/* Reduce partials -> dgamma (= sum dt*xhat), dbeta (= sum dt; also the bias gradient of a conv
+ * without BN) and coef[3][C] = (scale, dbeta/count, dgamma/count) for fsd_bn_bwd_apply. */
+int fsd_bn_bwd_finalize(const float* partial, int rows, long long count, int channels, const float* scale,
+                        float* dgamma, float* dbeta, float* coef, void* workspace, hipStream_t stream);
+/* In place: dt <- dy = scale * (dt - mean(dt) - xhat * mean(dt*xhat))  (training-mode BatchNorm). */
+int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const float* coef, const float* mean,
+                     const float* invstd, long long pixels, int channels, hipStream_t stream);
+/* Column sums of a (rows, ld) matrix as partials [fsd_act_bwd_rows(rows)][C][2] (any C). */
+int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
+                        hipStream_t stream);
+int fsd_reorg_bwd(const float* dout, long long dout_ld, float* dx, long long dx_ld, int batch, int height,
+                  int width, int channels, int stride, hipStream_t stream);
+int fsd_global_maxpool_bwd(const float* dout, const int* argmax, float* dx, long long dx_ld, int batch,
+                           int height, int width, int channels, hipStream_t stream);
+int fsd_add_inplace(float* dst, long long dst_ld, const float* src, long long src_ld, long long rows,
+                    int channels, hipStream_t stream);
+/* Un-fold the gradient of the fused head weights w_eff[(n*O+o), c] = head_w[o,c] * dyn[n,c]. */
+int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dyn, float* d_head_w,
+                        float* d_dyn, int n_cls, int out_ch, int channels, hipStream_t stream);
+/* SGD with momentum and L2 weight decay on one flat fp32 buffer (train_meta.py:143-147 uses
+ * torch.optim.SGD): d = g + wd*w; buf = first ? d : momentum*buf + d; w -= lr*buf. */
+int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
+                 float weight_decay, int first_step, long long count, hipStream_t stream);
+
 const char* fsd_version(void);
 
 #ifdef __cplusplus

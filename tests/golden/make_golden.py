@@ -106,7 +106,7 @@ def gold_mini_forward(dm):
     sd = net.state_dict()
     grads = {k: p.grad.numpy() for k, p in net.named_parameters()
              if k in ("models.0.conv1.weight", "models.0.bn1.weight", "models.0.bn1.bias",
-                      "models.21.conv17.weight", "models.23.conv19.weight", "models.23.conv19.bias",
+                      "models.21.conv14.weight", "models.23.conv16.weight", "models.23.conv16.bias",
                       "learnet_models.0.conv1.weight", "learnet_models.10.conv6.weight",
                       "learnet_models.10.bn6.weight")}
     np.savez_compressed(os.path.join(HERE, "mini_forward.npz"), x=x.numpy(), metax=metax.numpy(), mask=mask.numpy(),

@@ -1,0 +1,209 @@
+"""Backward-pass parity on the MI355X: kernel level (wgrad, BN/leaky/pool backward) against fp64
+autograd, model level against gradients minted from the reference and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [
+    (2, 13, 13, 64, 128, 3), (3, 9, 7, 3, 32, 3), (2, 13, 13, 256, 30, 1), (1, 6, 6, 1280, 64, 3), (4, 26, 26, 32, 64, 3)])
+def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, 1, (k - 1) // 2).backward(gy)
+    xv = ops.nchw_to_nhwc(x.float().to(dev))
+    gv = ops.nchw_to_nhwc(gy.float().to(dev))
+    dw = ops.conv2d_wgrad(gv, cout, xv, cin, k).cpu()
+    ref = w.grad.float()
+    assert torch.allclose(dw, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max())), float((dw - ref).abs().max())
+
+
+@pytest.mark.parametrize("pool", [0, 1, 2])
+def test_conv_bn_leaky_pool_block_backward(dev, pool):
+    """Whole fused block: dgamma, dbeta, dW and dx against torch autograd (fp64)."""
+    from fewshot_detection_amd import ops
+    torch.manual_seed(10 + pool)
+    B, H, W, cin, cout = 2, 13, 13, 8, 16
+    x = torch.randn(B, cin, H, W, dtype=torch.float64, requires_grad=True)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).double()
+    bn = torch.nn.BatchNorm2d(cout).double()
+    bn.weight.data.uniform_(-1, 1)
+    bn.bias.data.uniform_(-0.5, 0.5)
+    z = F.leaky_relu(bn(conv(x)), 0.1)
+    if pool == 1:
+        z = F.max_pool2d(z, 2, 2)
+    elif pool == 2:
+        z = F.max_pool2d(F.pad(z, (0, 1, 0, 1), mode="replicate"), 2, stride=1)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+
+    bn32 = torch.nn.BatchNorm2d(cout).to(dev)
+    bn32.weight.data.copy_(bn.weight.data.float())
+    bn32.bias.data.copy_(bn.bias.data.float())
+    w32 = conv.weight.data.float().to(dev)
+    xv = ops.nchw_to_nhwc(x.detach().float().to(dev))
+    yv, part = ops.conv2d(xv, ops.pack_weight(w32), cout, 3, bn_partial=True)
+    scale, shift, mean, invstd = ops.bn_finalize(part, xv.pixels, bn32, True)
+    gzv = ops.nchw_to_nhwc(gz.float().to(dev))
+    dt, partial = ops.bn_act_pool_bwd(gzv, None, yv, scale, shift, mean, invstd, 0.1, pool)
+    dbeta, dgamma, coef = ops.reduce_partials(partial, yv.pixels, cout, scale=scale, want_coef=True)
+    ops.bn_bwd_apply(dt, yv, coef, mean, invstd)
+    dw = ops.conv2d_wgrad(dt, cout, xv, cin, 3)
+    dx, _ = ops.conv2d(dt, ops.pack_weight(w32, mode=1), cin, 3)
+    tol = dict(rtol=1e-3, atol=1e-4)
+    assert torch.allclose(dbeta.cpu(), bn.bias.grad.float(), **tol)
+    assert torch.allclose(dgamma.cpu(), bn.weight.grad.float(), **tol)
+    assert torch.allclose(dw.cpu(), conv.weight.grad.float(), **tol)
+    assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), x.grad.float(), **tol)
+
+
+def _load_pair(dev, seed=0, randomize_bn=True):
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from oracle.net import OracleDarknet
+    cfgs = (os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+    torch.manual_seed(seed)
+    ora = OracleDarknet(*cfgs)
+    if randomize_bn:
+        for m in ora.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.uniform_(-0.2, 0.2)
+    net = Darknet(*cfgs)
+    net.load_state_dict(ora.state_dict())
+    return ora.train(), net.to(dev).train()
+
+
+def _rel_err(a, b):
+    return float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+
+
+def test_model_gradients_vs_reference_golden(dev):
+    """Gradients of the reference's own autograd (tests/golden/mini_forward.npz) for the same upstream grad."""
+    from fewshot_detection_amd.darknet_meta import Darknet
+    d = np.load(os.path.join(GOLD, "mini_forward.npz"))
+    net = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+    net.load_weights(os.path.join(GOLD, "mini.weights"))
+    net = net.to(dev).train()
+    x, metax, mask = (torch.from_numpy(d[k]).to(dev) for k in ("x", "metax", "mask"))
+    out = net(x, metax, mask)
+    out.backward(torch.from_numpy(d["grad_out"]).to(dev))
+    named = dict(net.named_parameters())
+    checked = 0
+    for k in d.files:
+        if k.startswith("grad:"):
+            g = named[k[5:]].grad
+            assert g is not None, k
+            assert _rel_err(g.cpu(), torch.from_numpy(d[k])) < 2e-3, (k, _rel_err(g.cpu(), torch.from_numpy(d[k])))
+            checked += 1
+    assert checked == 9
+
+
+def test_full_episode_gradients_vs_oracle(dev):
+    """forward + RegionLossV2 + backward: every parameter gradient against the CPU oracle (autograd)."""
+    from fewshot_detection_amd.cfg import cfg
+    from oracle.region import region_loss_v2
+    ora, net = _load_pair(dev, seed=5)
+    B, N, S = 3, 4, 128
+    x, metax = torch.rand(B, 3, S, S), torch.rand(N, 3, S, S)
+    mask = (torch.rand(N, 1, S, S) > 0.6).float()
+    tgt = torch.zeros(B, N, 250, dtype=torch.float64)
+    tgt[0, 1, :5] = torch.tensor([1, 0.52, 0.43, 0.4, 0.3])
+    tgt[1, 2, :10] = torch.tensor([2, 0.3, 0.6, 0.2, 0.5, 2, 0.7, 0.2, 0.25, 0.2])
+    tgt[2, 0, :5] = torch.tensor([0, 0.8, 0.8, 0.3, 0.3])
+    cfg.neg_ratio = "full"
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    region.seen = 20000
+    out = net(x.to(dev), metax.to(dev), mask.to(dev))
+    loss = region(out, tgt)
+    loss.backward()
+    ref_out = ora(x, metax, mask)
+    r = region_loss_v2(ref_out, tgt, ora.region.anchors, seen=20000)
+    r["loss"].backward()
+    assert abs(float(loss) - float(r["loss"])) < 1e-3 * max(1.0, abs(float(r["loss"])))
+    ref = dict(ora.named_parameters())
+    worst = 0.0
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        e = _rel_err(p.grad.cpu(), ref[name].grad)
+        worst = max(worst, e)
+        assert e < 5e-3, (name, e)
+    print("worst relative gradient error", worst)
+
+
+def test_sgd_step_matches_torch_optim(dev):
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    from oracle.region import region_loss_v2
+    ora, net = _load_pair(dev, seed=7)
+    B, N, S = 2, 3, 64
+    x, metax = torch.rand(B, 3, S, S), torch.rand(N, 3, S, S)
+    mask = (torch.rand(N, 1, S, S) > 0.5).float()
+    tgt = torch.zeros(B, N, 250, dtype=torch.float64)
+    tgt[0, 1, :5] = torch.tensor([1, 0.5, 0.5, 0.4, 0.3])
+    tgt[1, 0, :5] = torch.tensor([0, 0.3, 0.6, 0.2, 0.5])
+    cfg.neg_ratio = "full"
+    lr, mom, wd = 1e-4, 0.9, 5e-3
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    trainer = EpisodeTrainer(net, lr=lr, momentum=mom, weight_decay=wd)
+    opt = torch.optim.SGD(ora.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+    for step in range(2):
+        loss = region(net(x.to(dev), metax.to(dev), mask.to(dev)), tgt)
+        trainer.backward_and_step(loss)
+        opt.zero_grad()
+        r = region_loss_v2(ora(x, metax, mask), tgt, ora.region.anchors, seen=0)
+        r["loss"].backward()
+        opt.step()
+        assert abs(float(loss) - float(r["loss"])) < 2e-3 * max(1.0, abs(float(r["loss"]))), step
+    ref = dict(ora.named_parameters())
+    for name, p in net.named_parameters():
+        assert _rel_err(p.detach().cpu(), ref[name].detach()) < 1e-3, name
+
+
+def test_plain_yolo_backward_vs_oracle(dev):
+    """tiny-yolo style net (MaxPoolStride1, RegionLoss v1, 40-channel biased head) end to end."""
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet import Darknet
+    from oracle.net import OracleYolo
+    from oracle.region import region_loss_v1
+    torch.manual_seed(11)
+    c = os.path.join(GOLD, "mini_tiny_yolo.cfg")
+    ora = OracleYolo(c).train()
+    net = Darknet(c)
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train()
+    x = torch.rand(2, 3, 64, 64)
+    tgt = torch.zeros(2, 250, dtype=torch.float64)
+    tgt[0, :5] = torch.tensor([2, 0.5, 0.5, 0.4, 0.3])
+    tgt[1, :10] = torch.tensor([0, 0.3, 0.6, 0.2, 0.5, 1, 0.7, 0.2, 0.25, 0.2])
+    cfg.neg_ratio, cfg.metayolo = "full", False
+    try:
+        region = net.models[len(net.models) - 1]
+        region.verbose = False
+        loss = region(net(x.to(dev)), tgt)
+        loss.backward()
+        r = region_loss_v1(ora(x), tgt, ora.region.anchors, 5, 3)
+        r["loss"].backward()
+        assert abs(float(loss) - float(r["loss"])) < 1e-3 * max(1.0, abs(float(r["loss"])))
+        ref = dict(ora.named_parameters())
+        for name, p in net.named_parameters():
+            assert p.grad is not None, name
+            assert _rel_err(p.grad.cpu(), ref[name].grad) < 5e-3, name
+    finally:
+        cfg.metayolo = True
