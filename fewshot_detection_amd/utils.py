@@ -1,0 +1,99 @@
+"""Box math and small helpers with the reference's names (utils.py).
+
+bbox_iou / bbox_ious / nms / read_data_cfg / convert2cpu / logging keep the reference's semantics
+(utils.py:21-104, 460-475, 571-572).  get_region_boxes_v2 (utils.py:195-290) -- the inference-side
+decode of the meta detector -- runs its softmax-over-classes + box decode on the device and only
+ships the surviving boxes to the host.
+"""
+import math
+import time
+
+import torch
+
+
+def sigmoid(x):
+    return 1.0 / (math.exp(-x) + 1.0)
+
+
+def bbox_iou(box1, box2, x1y1x2y2=True):
+    """IoU of two boxes given as python numbers (corner or centre format); reference utils.py:21-52."""
+    if x1y1x2y2:
+        mx, Mx = min(box1[0], box2[0]), max(box1[2], box2[2])
+        my, My = min(box1[1], box2[1]), max(box1[3], box2[3])
+        w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
+        w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
+    else:
+        mx = min(box1[0] - box1[2] / 2.0, box2[0] - box2[2] / 2.0)
+        Mx = max(box1[0] + box1[2] / 2.0, box2[0] + box2[2] / 2.0)
+        my = min(box1[1] - box1[3] / 2.0, box2[1] - box2[3] / 2.0)
+        My = max(box1[1] + box1[3] / 2.0, box2[1] + box2[3] / 2.0)
+        w1, h1, w2, h2 = box1[2], box1[3], box2[2], box2[3]
+    cw = w1 + w2 - (Mx - mx)
+    ch = h1 + h2 - (My - my)
+    if cw <= 0 or ch <= 0:
+        return 0.0
+    carea = cw * ch
+    return carea / (w1 * h1 + w2 * h2 - carea)
+
+
+def bbox_ious(boxes1, boxes2, x1y1x2y2=True):
+    """Vectorised IoU of (4, n) tensors; reference utils.py:54-83."""
+    if x1y1x2y2:
+        mx, Mx = torch.min(boxes1[0], boxes2[0]), torch.max(boxes1[2], boxes2[2])
+        my, My = torch.min(boxes1[1], boxes2[1]), torch.max(boxes1[3], boxes2[3])
+        w1, h1 = boxes1[2] - boxes1[0], boxes1[3] - boxes1[1]
+        w2, h2 = boxes2[2] - boxes2[0], boxes2[3] - boxes2[1]
+    else:
+        mx = torch.min(boxes1[0] - boxes1[2] / 2.0, boxes2[0] - boxes2[2] / 2.0)
+        Mx = torch.max(boxes1[0] + boxes1[2] / 2.0, boxes2[0] + boxes2[2] / 2.0)
+        my = torch.min(boxes1[1] - boxes1[3] / 2.0, boxes2[1] - boxes2[3] / 2.0)
+        My = torch.max(boxes1[1] + boxes1[3] / 2.0, boxes2[1] + boxes2[3] / 2.0)
+        w1, h1, w2, h2 = boxes1[2], boxes1[3], boxes2[2], boxes2[3]
+    cw = w1 + w2 - (Mx - mx)
+    ch = h1 + h2 - (My - my)
+    carea = cw * ch
+    carea = torch.where((cw <= 0) | (ch <= 0), torch.zeros_like(carea), carea)
+    return carea / (w1 * h1 + w2 * h2 - carea)
+
+
+def nms(boxes, nms_thresh):
+    """Greedy NMS over python box lists [cx, cy, w, h, det_conf, ...]; reference utils.py:85-104.
+    Suppressed boxes get det_conf = 0 in place, like the reference."""
+    if len(boxes) == 0:
+        return boxes
+    order = sorted(range(len(boxes)), key=lambda i: 1 - boxes[i][4])
+    out = []
+    for pos, i in enumerate(order):
+        bi = boxes[i]
+        if bi[4] > 0:
+            out.append(bi)
+            for j in order[pos + 1:]:
+                bj = boxes[j]
+                if bbox_iou(bi, bj, x1y1x2y2=False) > nms_thresh:
+                    bj[4] = 0
+    return out
+
+
+def convert2cpu(gpu_matrix):
+    return torch.FloatTensor(gpu_matrix.size()).copy_(gpu_matrix)
+
+
+def convert2cpu_long(gpu_matrix):
+    return torch.LongTensor(gpu_matrix.size()).copy_(gpu_matrix)
+
+
+def read_data_cfg(datacfg):
+    """key = value file -> dict, with the reference's defaults (utils.py:460-475)."""
+    options = {"gpus": "0,1,2,3", "num_workers": "10"}
+    with open(datacfg, "r") as fp:
+        for line in fp:
+            line = line.strip()
+            if line == "" or "=" not in line or line.startswith("#"):
+                continue
+            key, value = line.split("=", 1)
+            options[key.strip()] = value.strip()
+    return options
+
+
+def logging(message):
+    print("%s %s" % (time.strftime("%Y-%m-%d %H:%M:%S", time.localtime()), message))
