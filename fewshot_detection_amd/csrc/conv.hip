@@ -27,6 +27,8 @@ constexpr int kBK = 32;      // k-chunk (floats) staged per LDS buffer
 constexpr int kLd = 36;      // padded LDS row stride (floats)
 constexpr int kThreads = 256;
 
+__device__ float g_zero_page[64];   // zero-initialised, never written: source of padding for the DMA path
+
 struct ConvArgs {
   const float* x;
   const float* w;
@@ -40,9 +42,12 @@ struct ConvArgs {
   int kgroups;   // taps * cpg
   int nk;        // k-chunks
   int cpt;       // FASTK: chunks per tap (Cin/32)
+  int ablate;     // diagnosis only (FSD_CONV_ABLATE): 1 = no staging after the first chunk, 2 = no barriers (wrong results)
   int prio_shift; // tuning: wave priority = (blockIdx >> prio_shift) & 3, <0 = leave at 0
   int Kpad;      // packed weight row length (floats)
   int m_tiles, n_tiles;
+  int m_base;     // first output row handled by this launch (tail launches start past the main rows)
+  int part_base;  // first bn_partial row of this launch
 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -51,14 +56,19 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK>
-__global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
-  static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves");
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, int VAR, bool GLDS = false>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;      // threads per workgroup (4 or 8 waves)
+  constexpr int RPP = NT / 8;                     // tile rows staged per pass (8 threads x 16 B per row)
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
-  constexpr int A_PER_T = BM / 32;   // float4 loads per thread per chunk
-  constexpr int B_PER_T = BN / 32;
-  constexpr int STAGE = (BM + BN) * kLd;
+  constexpr int A_PER_T = BM / RPP;   // float4 loads per thread per chunk
+  constexpr int B_PER_T = BN / RPP;
+  static_assert(!GLDS || (FASTK && STAGES >= 2), "direct-to-LDS staging needs the per-tap fast path and >= 2 LDS stages");
+  constexpr int LD = GLDS ? kBK : kLd;          // GLDS: linear 128-B rows (XOR-swizzled), else padded rows
+  constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   // Co-resident waves on a SIMD (from different workgroups) otherwise alternate MFMAs fairly, run
@@ -75,10 +85,13 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   }
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_base + mt * BM, n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int kq = tid & 7, r0 = tid >> 3;
+  // GLDS: the DMA writes LDS linearly (wave base + lane*16 B); bank conflicts are avoided by
+  // permuting which 16-B k-group each lane FETCHES (same 128-B line) and un-permuting on the read.
+  const int kq_src = GLDS ? (kq ^ (r0 & 7)) : kq;
 
   // Per-thread im2col bookkeeping.  NHWC input and output share the pixel grid (stride 1, "same"
   // padding), so the input pixel of output pixel `pix` under tap (dy, dx) is pix + dy*W + dx.
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
   unsigned a_pix[A_PER_T];
 #pragma unroll
   for (int j = 0; j < A_PER_T; ++j) {
-    const int pix = m0 + r0 + 32 * j;
+    const int pix = m0 + r0 + RPP * j;
     const int b = pix / p.HW;
     const int rem = pix - b * p.HW;
     const int yy = rem / p.W;
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
     a_x[j] = rem - yy * p.W;
     a_pix[j] = (unsigned)pix;
   }
-  const float* wrow = p.w + (long long)(n0 + r0) * p.Kpad + kq * 4;
+  const float* wrow = p.w + (long long)(n0 + r0) * p.Kpad + kq_src * 4;
   const unsigned x_ld = (unsigned)p.x_ld;
 
   f32x4 ra[A_PER_T], rb[B_PER_T];
@@ -114,12 +127,31 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const bool ok = (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
-      a_off[j] = ok ? (a_pix[j] + (unsigned)shift) * x_ld + (unsigned)(kq * 4) : (unsigned)(kq * 4);
+      a_off[j] = ok ? (a_pix[j] + (unsigned)shift) * x_ld + (unsigned)(kq_src * 4) : (unsigned)(kq_src * 4);
       tap_mask |= ok ? (1u << j) : 0u;
     }
   };
   if constexpr (FASTK) retap();
 
+  auto gload_lds = [&](int kc, float* st) {
+    // 16-byte global->LDS DMA per lane: no staging registers, no ds_write, no select.  Padding
+    // (image border taps, rows past M) is fetched from a zero page.
+    const unsigned coff = (unsigned)f_cc * kBK;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const float* src = (tap_mask >> j) & 1u ? p.x + (a_off[j] + coff) : g_zero_page + kq * 4;
+      __builtin_amdgcn_global_load_lds(src, st + (j * RPP + wave * 8) * kBK, 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j)
+      __builtin_amdgcn_global_load_lds(wrow + (long long)j * RPP * p.Kpad + kc * kBK,
+                                       st + (BM + j * RPP + wave * 8) * kBK, 16, 0, 0);
+    if (++f_cc == p.cpt) {
+      f_cc = 0;
+      ++f_tap;
+      retap();
+    }
+  };
   auto gload = [&](int kc) {
     if constexpr (FASTK) {
       const unsigned coff = (unsigned)f_cc * kBK;
@@ -128,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
       a_mask = tap_mask;
 #pragma unroll
       for (int j = 0; j < B_PER_T; ++j)
-        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * RPP * p.Kpad + kc * kBK);
       if (++f_cc == p.cpt) {      // uniform branch: next chunk starts a new tap
         f_cc = 0;
         ++f_tap;
@@ -153,18 +185,18 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < B_PER_T; ++j)
-        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * 32 * p.Kpad + kc * kBK);
+        rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * RPP * p.Kpad + kc * kBK);
     }
   };
   auto sstore = [&](float* st) {
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const f32x4 v = (a_mask >> j) & 1u ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(st + (r0 + 32 * j) * kLd + kq * 4) = v;
+      *reinterpret_cast<f32x4*>(st + (r0 + RPP * j) * kLd + kq * 4) = v;
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j)
-      *reinterpret_cast<f32x4*>(st + (BM + r0 + 32 * j) * kLd + kq * 4) = rb[j];
+      *reinterpret_cast<f32x4*>(st + (BM + r0 + RPP * j) * kLd + kq * 4) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -175,50 +207,131 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag_off = (lane & 31) * kLd + (lane >> 5) * 4;
+  const int frag_off = GLDS ? (lane & 31) * LD : (lane & 31) * LD + (lane >> 5) * 4;
+  // GLDS read-side un-swizzle: logical k-group g of row r sits at physical group g ^ (r & 7)
+  auto kofs = [&](int k8) { return GLDS ? (((k8 * 2 + (lane >> 5)) ^ (lane & 7)) * 4) : k8 * 8; };
   auto compute = [&](const float* st) {
-    const float* sa = st + (wm * TM * 32) * kLd + frag_off;
-    const float* sb = st + (BM + wn * TN * 32) * kLd + frag_off;
+    const float* sa = st + (wm * TM * 32) * LD + frag_off;
+    const float* sb = st + (BM + wn * TN * 32) * LD + frag_off;
+    if constexpr (VAR >= 3) {
+      // software-pipelined fragments: the reads of k-step k8+1 are in flight under the MFMAs of k8
+      f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int k8 = 0; k8 < kBK / 8; ++k8) {
-      f32x4 af[TM], bf[TN];
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * LD + kofs(0));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * kLd + k8 * 8);
+      for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * LD + kofs(0));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * kLd + k8 * 8);
+      for (int k8 = 0; k8 < kBK / 8; ++k8) {
+        if (k8 + 1 < kBK / 8) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+          for (int i = 0; i < TM; ++i) af[(k8 + 1) & 1][i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * LD + kofs(k8 + 1));
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j) bf[(k8 + 1) & 1][j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * LD + kofs(k8 + 1));
+        }
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = NCHW_OUT
-                            ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = NCHW_OUT
+                              ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[k8 & 1][j][kk], af[k8 & 1][i][kk], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x2f32(af[k8 & 1][i][kk], bf[k8 & 1][j][kk], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int k8 = 0; k8 < kBK / 8; ++k8) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * LD + kofs(k8));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * LD + kofs(k8));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = NCHW_OUT
+                              ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
   // ---- main loop: global -> registers (prefetch) -> LDS.  STAGES = 2: two LDS buffers, one
   // barrier per k-chunk.  STAGES = 1: one buffer, two barriers, half the LDS (more blocks per CU).
+  if constexpr (GLDS && STAGES == 2) {
+    gload_lds(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kc = 0; kc < p.nk; ++kc) {
+      if (kc + 1 < p.nk) gload_lds(kc + 1, smem + (cur ^ 1) * STAGE);   // buffer last read before the previous barrier
+      compute(smem + cur * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // DMA of the next tile has landed
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else if constexpr (GLDS) {
+    // Ring of STAGES LDS buffers, DMA running STAGES-1 chunks ahead of the MFMAs: an L2 miss
+    // (MALL/HBM, ~2 us under load) in chunk k+2 no longer stalls chunk k+1.  Each wave waits, with
+    // a COUNTED vmcnt, only for its own DMA of the NEXT chunk; the raw barrier then publishes
+    // every wave's part.  (A plain __syncthreads() would drain the whole queue, vmcnt(0).)
+    constexpr int PER = A_PER_T + B_PER_T;          // DMA instructions per wave per chunk
+    static_assert(PER == 4 || PER == 6 || PER == 8 || PER == 12, "counted waits below are literal");
+    gload_lds(0, smem);
+    if (p.nk > 1) gload_lds(1, smem + STAGE);
+    if (p.nk > 1) {
+      if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt2 = 2;                          // buffer of chunk kc, buffer for chunk kc+2
+    for (int kc = 0; kc < p.nk; ++kc) {
+      const bool ahead = kc + 2 < p.nk;
+      if (ahead) gload_lds(kc + 2, smem + nxt2 * STAGE);   // last read in iteration kc-1, before its barrier
+      compute(smem + cur * STAGE);
+      if (ahead) {
+        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == STAGES ? 0 : cur + 1;
+      nxt2 = nxt2 + 1 == STAGES ? 0 : nxt2 + 1;
+    }
+    __syncthreads();
+  } else {
   gload(0);
   sstore(smem);
   __syncthreads();
   int cur = 0;
   for (int kc = 0; kc < p.nk; ++kc) {
-    const bool more = kc + 1 < p.nk;
-    if (more) gload(kc + 1);
-    __builtin_amdgcn_sched_barrier(0);     // keep every use of the prefetched registers below the MFMAs
+    const bool more = (kc + 1 < p.nk) && !(p.ablate & 1);
+    if (more && !(p.ablate & 8)) gload(kc + 1);
+    if constexpr (VAR != 2) __builtin_amdgcn_sched_barrier(0);   // keep uses of the prefetched registers below the MFMAs
     compute(smem + cur * STAGE);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (VAR == 0 || VAR == 4) __builtin_amdgcn_sched_barrier(0);
     if constexpr (STAGES == 2) {
-      if (more) sstore(smem + (cur ^ 1) * STAGE);
-      __syncthreads();
+      if (more && !(p.ablate & 4)) sstore(smem + (cur ^ 1) * STAGE);
+      if (p.ablate & 4) asm volatile("" :: "v"(ra[0][0]), "v"(rb[0][0]), "v"(ra[A_PER_T - 1][3]), "v"(rb[B_PER_T - 1][3]));
+      if (!(p.ablate & 2)) __syncthreads();
       cur ^= 1;
     } else {
-      __syncthreads();
+      if (!(p.ablate & 2)) __syncthreads();
       if (more) sstore(smem);
-      __syncthreads();
+      if (!(p.ablate & 2)) __syncthreads();
     }
+  }
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -270,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_kernel(ConvArgs p) {
         }
         const int n = n0 + tid;
         if (n < p.Cout) {
-          float* dst = p.bn_partial + ((long long)mt * p.Cout + n) * 2;
+          float* dst = p.bn_partial + ((long long)(p.part_base + mt) * p.Cout + n) * 2;
           dst[0] = s;
           dst[1] = q;
         }
@@ -322,33 +435,48 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Tile configurations {BM, BN, waves_m, waves_n, stages}.
 struct TileCfg { int bm, bn; };
-constexpr TileCfg kCfgs[] = {{128, 128}, {256, 64}, {256, 32}, {128, 64}, {128, 32}, {256, 128}, {128, 128}, {128, 64}, {128, 32}};
+constexpr TileCfg kCfgs[] = {{128, 128}, {256, 64}, {256, 32}, {128, 64}, {128, 32}, {256, 128}, {128, 128}, {128, 64}, {128, 32}, {64, 64}, {64, 64}, {128, 128}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128}, {64, 64}, {256, 128}, {128, 128}, {128, 128}, {64, 64}};
+constexpr int kSlots = 512;   // co-resident 128x128 workgroups on the chip (256 CUs x 2)
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // tile shape by output width: narrow layers get narrower tiles so no MFMA columns are wasted
-inline int tile_cfg(int cout) {
+// Measured on MI355X (profiles/r01_summary.txt, section D): 64x64 tiles with a single LDS stage
+// (18 KB -> 8 workgroups = 32 waves per CU) run every layer of the path at 104-116 TFLOP/s and are
+// insensitive to code placement; the 128x128 two-stage kernel peaks a little higher on the
+// 13x13 layers but swings between 87 and 120 TFLOP/s with unrelated code changes.  Short-K layers
+// (first convs, K <= 320) are store/latency-bound and prefer 128x32.
+inline int tile_cfg(int cout, int cin, int ksize) {
   static const char* env = getenv("FSD_CONV_TILE");      // tuning aid: force a configuration
-  if (env && env[0] >= '0' && env[0] < '0' + kNumCfgs) return env[0] - '0';
-  return cout <= 32 ? 2 : (cout <= 64 ? 1 : 0);
+  if (env && env[0] >= 'a' && env[0] < 'a' + kNumCfgs) return env[0] - 'a';
+  (void)cout;
+  return ksize * ksize * cin <= 320 ? 8 : 10;
 }
 
 template <typename K>
-int launch_kernel(K k, const ConvArgs& a, size_t lds, hipStream_t stream) {
+int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles), dim3(threads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int VAR = 0, bool GLDS = false>
 int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
-  const size_t lds = STAGES * (size_t)(BM + BN) * kLd * sizeof(float);
   const bool fast = a.cpt > 0;
+  constexpr int NT = WM * WN * 64;
+  if constexpr (GLDS) {
+    if (fast) {
+      const size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
+      return nchw ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, VAR, true>, a, lds_g, NT, stream)
+                  : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, VAR, true>, a, lds_g, NT, stream);
+    }
+  }
+  const size_t lds = STAGES * (size_t)(BM + BN) * kLd * sizeof(float);
   if (nchw)
-    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true>, a, lds, stream)
-                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, false>, a, lds, stream);
-  return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true>, a, lds, stream)
-              : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, false>, a, lds, stream);
+    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, VAR>, a, lds, NT, stream)
+                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, false, VAR>, a, lds, NT, stream);
+  return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, VAR>, a, lds, NT, stream)
+              : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, false, VAR>, a, lds, NT, stream);
 }
 
 }  // namespace
@@ -371,10 +499,33 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_conv_row_tiles(long long pixels, int cout) {
-  (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
-  const int bm = kCfgs[tile_cfg(cout)].bm;
-  return (int)((pixels + bm - 1) / bm);
+namespace {
+// Tail splitting for the 128x128 configuration: rows covered by WHOLE rounds of co-resident
+// workgroups use 128x128 tiles; the remaining rows (a partial round that would leave CUs idle for
+// up to a full tile time) are cut into 64x64 tiles, which balance ~4x finer.
+struct RowPlan { int main_m_tiles; int tail_m_tiles; };
+inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  const int m_tiles = (int)((pixels + bm - 1) / bm);
+  RowPlan r{m_tiles, 0};
+  static const char* env = getenv("FSD_CONV_TAIL");
+  const bool enabled = !(env && env[0] == '0');
+  if (cfg != 0 || !enabled) return r;
+  const int n_tiles = (cout + bn - 1) / bn;
+  const long long total = (long long)m_tiles * n_tiles;
+  if (total <= kSlots || total % kSlots == 0) return r;
+  const int main_m = (int)((total / kSlots) * kSlots / n_tiles);
+  if (main_m <= 0 || main_m >= m_tiles) return r;
+  const long long tail_rows = pixels - (long long)main_m * bm;
+  r.main_m_tiles = main_m;
+  r.tail_m_tiles = (int)((tail_rows + 63) / 64);
+  return r;
+}
+}  // namespace
+
+extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize) {
+  const RowPlan r = plan_rows(pixels, cout, tile_cfg(cout, cin, ksize));
+  return r.main_m_tiles + r.tail_m_tiles;
 }
 
 extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const float* bias,
@@ -402,23 +553,61 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   {
     static const char* env = getenv("FSD_CONV_PRIO");
     a.prio_shift = env ? atoi(env) : -1;
+    static const char* abl = getenv("FSD_CONV_ABLATE");
+    a.ablate = abl ? atoi(abl) : 0;
   }
   // 32-bit element offsets inside the kernel
   if ((pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
-  const int cfg = tile_cfg(cout);
+  const int cfg = tile_cfg(cout, cin, ksize);
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
-  a.m_tiles = (int)((pixels + bm - 1) / bm);
+  const RowPlan plan = out_nchw ? RowPlan{(int)((pixels + bm - 1) / bm), 0} : plan_rows(pixels, cout, cfg);
+  a.m_tiles = plan.main_m_tiles;
   a.n_tiles = (cout + bn - 1) / bn;
+  a.m_base = 0;
+  a.part_base = 0;
   const bool nchw = out_nchw != 0;
+  if (plan.tail_m_tiles > 0) {
+    ConvArgs t = a;
+    t.m_base = plan.main_m_tiles * bm;
+    t.part_base = plan.main_m_tiles;
+    t.m_tiles = plan.tail_m_tiles;
+    t.n_tiles = (cout + 63) / 64;
+    const int rc = launch<64, 64, 2, 2, 2, 3>(t, nchw, stream);
+    if (rc != 0) return rc;
+  }
   switch (cfg) {
-    case 0: return launch<128, 128, 2, 2, 2>(a, nchw, stream);
+    case 0: {
+      static const char* venv = getenv("FSD_CONV_VAR");
+      const int var = venv ? atoi(venv) : 0;
+      if (var == 1) return launch<128, 128, 2, 2, 2, 1>(a, nchw, stream);
+      if (var == 2) return launch<128, 128, 2, 2, 2, 2>(a, nchw, stream);
+      if (var == 3) return launch<128, 128, 2, 2, 2, 3>(a, nchw, stream);
+      if (var == 4) return launch<128, 128, 2, 2, 1, 4>(a, nchw, stream);
+      if (var == 5) return launch<128, 128, 2, 2, 1, 3>(a, nchw, stream);
+      if (var == 6) return launch<128, 128, 2, 2, 2, 0>(a, nchw, stream);
+      return launch<128, 128, 2, 2, 2, 3>(a, nchw, stream);
+    }
     case 1: return launch<256, 64, 4, 1, 2>(a, nchw, stream);
     case 2: return launch<256, 32, 4, 1, 2>(a, nchw, stream);
     case 3: return launch<128, 64, 2, 2, 2>(a, nchw, stream);
     case 4: return launch<128, 32, 4, 1, 2>(a, nchw, stream);
     case 5: return launch<256, 128, 2, 2, 2>(a, nchw, stream);
     case 6: return launch<128, 128, 2, 2, 1>(a, nchw, stream);
-    case 7: return launch<128, 64, 2, 2, 1>(a, nchw, stream);
-    default: return launch<128, 32, 4, 1, 1>(a, nchw, stream);
+    case 7: return launch<128, 64, 2, 2, 1, 3>(a, nchw, stream);
+    case 8: return launch<128, 32, 4, 1, 1, 3>(a, nchw, stream);
+    case 9: return launch<64, 64, 2, 2, 2, 3>(a, nchw, stream);
+    case 10: return launch<64, 64, 2, 2, 1, 3>(a, nchw, stream);
+    case 11: return launch<128, 128, 2, 4, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 64x32, single LDS stage
+    case 12: return launch<128, 128, 2, 4, 2, 3>(a, nchw, stream);    // ... double stage
+    case 13: return launch<128, 128, 4, 2, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 32x64
+    case 14: return launch<128, 128, 4, 2, 2, 3>(a, nchw, stream);
+    case 15: return launch<256, 128, 4, 2, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 64x64, 55 KB
+    case 16: return launch<128, 128, 2, 2, 2, 3, true>(a, nchw, stream);   // q: DMA staging, 4 waves
+    case 17: return launch<128, 128, 2, 4, 2, 3, true>(a, nchw, stream);   // r: DMA staging, 8 waves
+    case 18: return launch<64, 64, 2, 2, 2, 3, true>(a, nchw, stream);     // s: DMA staging, 64x64
+    case 19: return launch<256, 128, 4, 2, 2, 3, true>(a, nchw, stream);   // t: DMA staging, 256x128, 8 waves
+    case 20: return launch<128, 128, 2, 2, 3, 3, true>(a, nchw, stream);   // u: DMA, 3-stage ring, 4 waves (96 KB)
+    case 21: return launch<128, 128, 2, 4, 3, 3, true>(a, nchw, stream);   // v: DMA, 3-stage ring, 8 waves
+    default: return launch<64, 64, 2, 2, 3, 3, true>(a, nchw, stream);     // w: DMA, 3-stage ring, 64x64 (48 KB)
   }
 }

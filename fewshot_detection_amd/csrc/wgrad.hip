@@ -20,8 +20,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
-constexpr int kBM = 128, kBN = 128;
+// 64x64 tiles, one LDS stage (17 KB -> 8 workgroups per CU): same occupancy-first choice as the
+// forward kernel (conv.hip), which measured best and most stable on MI355X.
+constexpr int kBM = 64, kBN = 64;
+constexpr int kStages = 1;
 constexpr int kLdT = kBM + 4;        // LDS row stride (floats), keeps 16-byte alignment
+constexpr int kCQ = kBM / 4;         // float4 column groups per tile row
+constexpr int kRPP = kThreads / kCQ; // k rows staged per pass
+constexpr int kPasses = kBK / kRPP;
+constexpr int kT = kBM / 64;         // 32x32 MFMA tiles per wave along each dimension (2x2 waves)
 
 struct WgradArgs {
   const float* dy;     // (pixels, dy_ld), columns [0, Cout) (zero padded to a multiple of 4)
@@ -45,7 +52,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   const int nk = (p_end - p_begin + kBK - 1) / kBK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int cq = tid & 31, kr = tid >> 5;        // this thread's 4-channel column group / first k row
+  const int cq = tid % kCQ, kr = tid / kCQ;      // this thread's 4-channel column group / first k row
 
   // A: dy columns are fixed per thread
   const int a_col = m0 + cq * 4;
@@ -59,13 +66,13 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   const int dyy = ky - p.pad, dxx = kx - p.pad;
   const int shift = dyy * p.W + dxx;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[kPasses], rb[kPasses];
   unsigned okmask = 0;
   auto gload = [&](int kc) {
     okmask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pix = p_begin + kc * kBK + kr + 8 * j;
+    for (int j = 0; j < kPasses; ++j) {
+      const int pix = p_begin + kc * kBK + kr + kRPP * j;
       const bool pv = pix < p_end;
       const bool aok = pv && a_ok;
       ra[j] = *reinterpret_cast<const f32x4*>(p.dy + (aok ? (long long)pix * p.dy_ld + a_col : 0));
@@ -75,45 +82,57 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       const bool bok = pv && b_colok && (unsigned)(yy + dyy) < (unsigned)p.H && (unsigned)(xx + dxx) < (unsigned)p.W;
       rb[j] = *reinterpret_cast<const f32x4*>(p.x + (bok ? (long long)(pix + shift) * p.x_ld + ci : 0));
       okmask |= (aok ? 1u : 0u) << j;
-      okmask |= (bok ? 16u : 0u) << j;
+      okmask |= (bok ? 256u : 0u) << j;
     }
   };
   auto sstore = [&](float* st) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kPasses; ++j) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(st + (kr + 8 * j) * kLdT + cq * 4) = (okmask >> j) & 1u ? ra[j] : z;
-      *reinterpret_cast<f32x4*>(st + (kBK + kr + 8 * j) * kLdT + cq * 4) = (okmask >> (4 + j)) & 1u ? rb[j] : z;
+      *reinterpret_cast<f32x4*>(st + (kr + kRPP * j) * kLdT + cq * 4) = (okmask >> j) & 1u ? ra[j] : z;
+      *reinterpret_cast<f32x4*>(st + (kBK + kr + kRPP * j) * kLdT + cq * 4) = (okmask >> (8 + j)) & 1u ? rb[j] : z;
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[kT][kT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < kT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frag = (lane >> 5) * 4 * kLdT + (lane & 31);
   auto compute = [&](const float* st) {
-    const float* sa = st + wm * 64 + frag;
-    const float* sb = st + kBK * kLdT + wn * 64 + frag;
+    const float* sa = st + wm * (kT * 32) + frag;
+    const float* sb = st + kBK * kLdT + wn * (kT * 32) + frag;
+    // fragments one k8-step ahead of the MFMAs (statically indexed double buffer)
+    float af[2][4][kT], bf[2][4][kT];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < kT; ++i) af[0][kk][i] = sa[kk * kLdT + i * 32];
+#pragma unroll
+      for (int j = 0; j < kT; ++j) bf[0][kk][j] = sb[kk * kLdT + j * 32];
+    }
 #pragma unroll
     for (int k8 = 0; k8 < kBK / 8; ++k8) {
+      if (k8 + 1 < kBK / 8) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float af[2], bf[2];
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = sa[(k8 * 8 + kk) * kLdT + i * 32];
+          for (int i = 0; i < kT; ++i) af[(k8 + 1) & 1][kk][i] = sa[((k8 + 1) * 8 + kk) * kLdT + i * 32];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = sb[(k8 * 8 + kk) * kLdT + j * 32];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < kT; ++j) bf[(k8 + 1) & 1][kk][j] = sb[((k8 + 1) * 8 + kk) * kLdT + j * 32];
+        }
       }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < kT; ++i)
+#pragma unroll
+          for (int j = 0; j < kT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k8 & 1][kk][i], bf[k8 & 1][kk][j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -128,22 +147,28 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       compute(smem + cur * STAGE);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) sstore(smem + (cur ^ 1) * STAGE);
-      __syncthreads();
-      cur ^= 1;
+      if constexpr (kStages == 2) {
+        if (more) sstore(smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+        cur ^= 1;
+      } else {
+        __syncthreads();
+        if (more) sstore(smem);
+        __syncthreads();
+      }
     }
   }
 
   float* out = p.ws + (long long)split * p.Cout * p.ncols;
   const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + c_lane;
+    for (int j = 0; j < kT; ++j) {
+      const int n = n0 + wn * (kT * 32) + j * 32 + c_lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        const int m = m0 + wm * (kT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
         if (m < p.Cout && n < p.ncols) out[(long long)m * p.ncols + n] = acc[i][j][r];
       }
     }
@@ -169,7 +194,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 inline int pick_splits(long long pixels, int tiles) {
-  int s = (1024 + tiles - 1) / tiles;
+  int s = (4096 + tiles - 1) / tiles;
   const long long max_s = (pixels + 255) / 256;      // at least 8 k-chunks per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
@@ -207,7 +232,7 @@ extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x
   a.n_tiles = (a.ncols + kBN - 1) / kBN;
   const int splits = pick_splits(pixels, a.m_tiles * a.n_tiles);
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
-  const size_t lds = 2 * (size_t)(2 * kBK * kLdT) * sizeof(float);
+  const size_t lds = kStages * (size_t)(2 * kBK * kLdT) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(wgrad_kernel, dim3(a.m_tiles * a.n_tiles, splits), dim3(kThreads), lds, stream, a);

@@ -108,7 +108,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
         y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
         y_ptr, y_ld = y.ptr, y.ld
     if bn_partial:
-        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout)
+        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize)
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -80,9 +80,9 @@ size_t fsd_packed_weight_elems(int rows, int red, int ksize);
 int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ksize, int mode,
                          hipStream_t stream);
 
-/* Number of row tiles the conv kernel will use for `pixels` outputs and `cout` channels
- * (= first dimension of the BN partial-sum buffer). */
-int fsd_conv_row_tiles(long long pixels, int cout);
+/* Number of row tiles the conv kernel will use for this problem (= first dimension of the BN
+ * partial-sum buffer). */
+int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize);
 
 /* y[p, co] = sum_{tap, ci} x[p + tap, ci] * w[co, tap, ci] (+ bias[co]);  stride 1,
  * pad = (ksize-1)/2, ksize in {1, 3}.  x: NHWC, cin % 4 == 0, pixel stride x_ld (floats).
