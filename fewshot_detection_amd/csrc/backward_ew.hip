@@ -121,6 +121,85 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
   }
 }
 
+// pool == 1 (2x2 stride 2) specialisation: one thread per 2x2 CELL and 4 channels, so every y is
+// read once, the argmax is decided once and the (up to) four dt values are written together.
+// Cells on the odd border (no pooling window) only carry the dz_full / zero gradient.
+__global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
+  __shared__ float s_red[4][64][8];
+  const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int g = blockIdx.y * 64 + gl;
+  const int cg = p.C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc = (g_ok && p.scale) ? ld4(p.scale + g * 4) : one;
+  const f32x4 sh = (g_ok && p.shift) ? ld4(p.shift + g * 4) : zero;
+  const f32x4 mu = (g_ok && p.mean) ? ld4(p.mean + g * 4) : zero;
+  const f32x4 is = (g_ok && p.invstd) ? ld4(p.invstd + g * 4) : one;
+  const int CH = (p.H + 1) >> 1, CW = (p.W + 1) >> 1;
+  const long long cells = (long long)(p.pixels / ((long long)p.H * p.W)) * CH * CW;
+  f32x4 s1 = zero, s2 = zero;
+  const long long c0 = (long long)blockIdx.x * (kPixPerBlock / 4);
+  if (g_ok) {
+    for (int it = pl; it < kPixPerBlock / 4; it += 4) {
+      const long long cell = c0 + it;
+      if (cell >= cells) break;
+      const int cx = (int)(cell % CW);
+      const long long t = cell / CW;
+      const int cy = (int)(t % CH);
+      const long long b = t / CH;
+      const bool win = cy < p.OH && cx < p.OW;
+      f32x4 yv[4], tv[4];
+      bool in[4];
+      int best[4] = {0, 0, 0, 0};
+      f32x4 bv = zero;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+        in[q] = yy < p.H && xx < p.W;
+        yv[q] = in[q] ? ld4(p.y + ((b * p.H + yy) * (long long)p.W + xx) * p.y_ld + g * 4) : zero;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          tv[q][k] = yv[q][k] * sc[k] + sh[k];
+          const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * p.slope;
+          if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
+        }
+      }
+      const f32x4 gz = win ? ld4(p.dz + ((b * p.OH + cy) * (long long)p.OW + cx) * p.dz_ld + g * 4) : zero;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!in[q]) continue;
+        const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+        const long long pix = (b * p.H + yy) * (long long)p.W + xx;
+        f32x4 gin = zero;
+        if (p.dz_full) gin = ld4(p.dz_full + pix * p.dzf_ld + g * 4);
+        f32x4 d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (win && best[k] == q) gin[k] += gz[k];
+          d[k] = tv[q][k] > 0.f ? gin[k] : gin[k] * p.slope;
+          s1[k] += d[k];
+          s2[k] += d[k] * ((yv[q][k] - mu[k]) * is[k]);
+        }
+        *reinterpret_cast<f32x4*>(p.dt + pix * p.C + g * 4) = d;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_red[pl][gl][k] = s1[k];
+    s_red[pl][gl][4 + k] = s2[k];
+  }
+  __syncthreads();
+  if (pl == 0 && g_ok) {
+    float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dst[2 * k] = s_red[0][gl][k] + s_red[1][gl][k] + s_red[2][gl][k] + s_red[3][gl][k];
+      dst[2 * k + 1] = s_red[0][gl][4 + k] + s_red[1][gl][4 + k] + s_red[2][gl][4 + k] + s_red[3][gl][4 + k];
+    }
+  }
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ slots, int rows, int two_c) {
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   const int s = blockIdx.x;
@@ -251,6 +330,14 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
 
 extern "C" int fsd_act_bwd_rows(long long pixels) { return (int)((pixels + kPixPerBlock - 1) / kPixPerBlock); }
 
+extern "C" int fsd_bn_act_pool_bwd_rows(int batch, int height, int width, int pool) {
+  if (pool == 1) {
+    const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
+    return (int)((cells + kPixPerBlock / 4 - 1) / (kPixPerBlock / 4));
+  }
+  return fsd_act_bwd_rows((long long)batch * height * width);
+}
+
 extern "C" size_t fsd_reduce_workspace_bytes(int channels) { return (size_t)kSlots * channels * 2 * sizeof(double); }
 
 extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
@@ -268,6 +355,13 @@ extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float
   a.dt = dt; a.partial = partial; a.dz_ld = dz_ld; a.dzf_ld = dz_full_ld; a.y_ld = y_ld;
   a.H = height; a.W = width; a.OH = pool == 1 ? height / 2 : height; a.OW = pool == 1 ? width / 2 : width;
   a.C = channels; a.pool = pool; a.pixels = (long long)batch * height * width; a.slope = slope;
+  if (pool == 1) {
+    // window-major: a block covers kPixPerBlock/4 cells; partial rows = cells / (kPixPerBlock/4) <= fsd_act_bwd_rows(pixels)
+    const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
+    const dim3 grid(blocks_for(cells, kPixPerBlock / 4), (channels / 4 + 63) / 64);
+    hipLaunchKernelGGL(act_bwd_pool2_kernel, grid, dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   const dim3 grid(blocks_for(a.pixels, kPixPerBlock), (channels / 4 + 63) / 64);
   hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();

@@ -174,21 +174,34 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-// dw[co][ci][ky][kx] = sum_s ws[s][co][tap*cin4 + ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int cout, int cin,
-                                    int cin4, int taps, int ncols) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)cout * cin * taps;
-  if (idx >= total) return;
-  const int tap = (int)(idx % taps);
-  const long long t = idx / taps;
-  const int ci = (int)(t % cin);
-  const int co = (int)(t / cin);
-  const long long src = (long long)co * ncols + tap * cin4 + ci;
+// dw[co][ci][ky][kx] = sum_s ws[s][co][tap*cin4 + ci].  Threads run along the workspace's fastest
+// dimension (coalesced reads); SY lanes share the split loop when there are many splits (small
+// layers) and are folded through LDS.  Fixed summation order -> deterministic.
+template <int SY>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                          int cout, int cin, int cin4, int taps, int ncols) {
+  constexpr int NX = 256 / SY;
+  __shared__ float s_part[SY][NX];
+  const int tx = threadIdx.x % NX, ty = threadIdx.x / NX;
+  const int col = blockIdx.x * NX + tx;
+  const int co = blockIdx.y;
   const long long slice = (long long)cout * ncols;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[k * slice + src];
-  dw[idx] = s;
+  float v = 0.f;
+  if (col < ncols) {
+    const float* src = ws + (long long)co * ncols + col;
+    for (int k = ty; k < splits; k += SY) v += src[k * slice];
+  }
+  if constexpr (SY > 1) {
+    s_part[ty][tx] = v;
+    __syncthreads();
+    if (ty != 0) return;
+#pragma unroll
+    for (int y = 1; y < SY; ++y) v += s_part[y][tx];
+  }
+  if (col < ncols) {
+    const int tap = col / cin4, ci = col - tap * cin4;
+    if (ci < cin) dw[((long long)co * cin + ci) * taps + tap] = v;
+  }
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -236,8 +249,11 @@ extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(wgrad_kernel, dim3(a.m_tiles * a.n_tiles, splits), dim3(kThreads), lds, stream, a);
-  const long long total = (long long)cout * cin * ksize * ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.ws, dw_oihw,
-                     splits, cout, cin, cin4, ksize * ksize, a.ncols);
+  if (splits <= 8)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
+                       splits, cout, cin, cin4, ksize * ksize, a.ncols);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((a.ncols + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw,
+                       splits, cout, cin, cin4, ksize * ksize, a.ncols);
   return (int)hipGetLastError();
 }

@@ -206,7 +206,8 @@ def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     L = lib()
     dev = yv.t.device
     dt = new_view(yv.B, yv.H, yv.W, yv.C, dev)
-    partial = torch.empty((L.fsd_act_bwd_rows(yv.pixels), yv.C, 2), dtype=torch.float32, device=dev)
+    partial = torch.empty((L.fsd_bn_act_pool_bwd_rows(yv.B, yv.H, yv.W, pool), yv.C, 2), dtype=torch.float32,
+                          device=dev)
     check(L.fsd_bn_act_pool_bwd(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
                                 0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift),
                                 _ptr(mean), _ptr(invstd), slope, pool, dt.ptr, partial.data_ptr(), yv.B, yv.H, yv.W,

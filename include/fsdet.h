@@ -151,10 +151,11 @@ int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long
 /* (The data gradient is fsd_conv2d_fwd on dy with weights packed in mode 1.) */
 
 /* Gradient through pool(act(y*scale+shift)): dt = d loss / d (y*scale+shift), dense (pixels, C),
- * plus per-block partial sums [fsd_act_bwd_rows(pixels)][C][2] of (dt, dt*xhat) for the BatchNorm
+ * plus per-block partial sums [fsd_bn_act_pool_bwd_rows(...)][C][2] of (dt, dt*xhat) for the BatchNorm
  * backward.  dz: grad of the block output (pooled grid if pool != 0); dz_full: optional grad of the
  * un-pooled activation.  The max-pool argmax is recomputed from y (first maximum in scan order). */
 int fsd_act_bwd_rows(long long pixels);
+int fsd_bn_act_pool_bwd_rows(int batch, int height, int width, int pool);   /* rows of `partial` below */
 size_t fsd_reduce_workspace_bytes(int channels);
 int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
                         const float* y, long long y_ld, const float* scale, const float* shift,
