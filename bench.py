@@ -90,7 +90,7 @@ def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
     from fewshot_detection_amd.cfg import parse_cfg
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    Bs, Ns = 1, min(args.classes, 2)
+    Bs, Ns = min(args.batch, 32), args.classes          # about 10-20 s of CPU work on a 64-core host
     ora = OracleDarknet(dyn_cfg, rw_cfg).train()
     x, metax, mask, tgt = synth_episode(123, Bs, Ns, args.size, args.support)
     blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
@@ -113,6 +113,17 @@ def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
                       "scaled by conv FLOPs (%.1f -> %.1f GFLOP) to the full episode"
                       % (args.mode, Bs, args.size, args.size, Ns, args.support, args.support, t,
                          sample_flops / 1e9, full_flops / 1e9)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_conv_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE
+    passes of this very command).  Counters cannot be read live; None if the summary is absent."""
+    p = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+    try:
+        return json.load(open(p))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -237,7 +248,10 @@ def main():
                        "episode_forward_gflop": full_flops / 1e9},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, all launches)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 else None,
+                         "flop_per_launch": conv_flops / max(1, len(prof)),
+                         "avg_launch_ms": conv_ms / max(1, len(prof)),
                          "launches_per_step": len(prof) // max(1, args.steps),
                          "conv_ms_per_step": conv_ms / max(1, args.steps)},
         }
