@@ -354,3 +354,87 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
   hipLaunchKernelGGL(region_finalize_kernel, dim3(1), dim3(1), 0, stream, p.stats, loss_out);
   return (int)hipGetLastError();
 }
+
+// ---- inference-side decode (utils.get_region_boxes_v2, utils.py:195-290) ------------------------
+namespace {
+
+struct DecodeArgs {
+  const float* out;     // (rows, A*(5+C), H, W)
+  float* boxes;         // [rows][cap][8]: key, cx/W, cy/H, w/W, h/H, det_conf, cls_conf, cls_id
+  int* counts;          // [rows]
+  int rows, rows_per_image, A, C, H, W, cap, only_objectness, softmax_over_rows;
+  float thresh;
+  float aw[kMaxAnchors], ah[kMaxAnchors];
+};
+
+// One thread per (row, anchor, cell).  Survivors are appended with an atomic per-row cursor; `key`
+// = (cy*W + cx)*A + a is the reference's visiting order so the host can restore it with one sort.
+__global__ __launch_bounds__(kThreads) void region_decode_kernel(DecodeArgs p) {
+  const int HW = p.H * p.W;
+  const int cells = p.A * HW;
+  const int chans = 5 + p.C;
+  const long long gid = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long long)p.rows * cells) return;
+  const int row = (int)(gid / cells);
+  const int c = (int)(gid - (long long)row * cells);
+  const int a = c / HW, hw = c - a * HW;
+  const int j = hw / p.W, i = hw - j * p.W;
+  const long long row_stride = (long long)p.A * chans * HW;
+  const float* oc = p.out + row * row_stride + (long long)a * chans * HW + hw;
+  const float det = sigmoidf_(oc[4 * HW]);
+  float cls_conf, cls_id = 0.f;
+  if (p.softmax_over_rows) {         // class confidence = softmax across the N rows of this image
+    const int img = row / p.rows_per_image;
+    const float* base = p.out + (long long)img * p.rows_per_image * row_stride + ((long long)a * chans + 5) * HW + hw;
+    float m = -INFINITY;
+    for (int n = 0; n < p.rows_per_image; ++n) m = fmaxf(m, base[n * row_stride]);
+    float s = 0.f;
+    for (int n = 0; n < p.rows_per_image; ++n) s += expf(base[n * row_stride] - m);
+    cls_conf = expf(oc[5 * HW] - m) / s;
+  } else {                           // classic per-cell softmax over the C class channels
+    float m = -INFINITY;
+    for (int k = 0; k < p.C; ++k) m = fmaxf(m, oc[(5 + k) * HW]);
+    float s = 0.f, best = -1.f;
+    for (int k = 0; k < p.C; ++k) s += expf(oc[(5 + k) * HW] - m);
+    for (int k = 0; k < p.C; ++k) {
+      const float v = expf(oc[(5 + k) * HW] - m) / s;
+      if (v > best) { best = v; cls_id = (float)k; }
+    }
+    cls_conf = best;
+  }
+  const float conf = p.only_objectness ? det : det * cls_conf;
+  if (!(conf > p.thresh)) return;
+  const int slot = atomicAdd(&p.counts[row], 1);
+  if (slot >= p.cap) return;
+  float* b = p.boxes + ((long long)row * p.cap + slot) * 8;
+  b[0] = (float)((j * p.W + i) * p.A + a);
+  b[1] = (sigmoidf_(oc[0]) + (float)i) / (float)p.W;
+  b[2] = (sigmoidf_(oc[HW]) + (float)j) / (float)p.H;
+  b[3] = expf(oc[2 * HW]) * p.aw[a] / (float)p.W;
+  b[4] = expf(oc[3 * HW]) * p.ah[a] / (float)p.H;
+  b[5] = det;
+  b[6] = cls_conf;
+  b[7] = cls_id;
+}
+
+}  // namespace
+
+extern "C" int fsd_region_decode(const float* output, float* boxes, int* counts, int rows, int rows_per_image,
+                                 int num_anchors, int num_classes, int height, int width, const double* anchors_host,
+                                 float conf_thresh, int only_objectness, int softmax_over_rows, int cap,
+                                 hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!output || !boxes || !counts || !anchors_host || rows < 1 || cap < 1) return FSD_ERR_ARG;
+  if (num_anchors < 1 || num_anchors > kMaxAnchors || rows_per_image < 1 || rows % rows_per_image) return FSD_ERR_ARG;
+  if (softmax_over_rows && num_classes != 1) return FSD_ERR_UNSUPPORTED;
+  DecodeArgs p;
+  p.out = output; p.boxes = boxes; p.counts = counts; p.rows = rows; p.rows_per_image = rows_per_image;
+  p.A = num_anchors; p.C = num_classes; p.H = height; p.W = width; p.cap = cap;
+  p.only_objectness = only_objectness; p.softmax_over_rows = softmax_over_rows; p.thresh = conf_thresh;
+  for (int a = 0; a < num_anchors; ++a) { p.aw[a] = (float)anchors_host[2 * a]; p.ah[a] = (float)anchors_host[2 * a + 1]; }
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * rows, stream);
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)rows * num_anchors * height * width;
+  hipLaunchKernelGGL(region_decode_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, p);
+  return (int)hipGetLastError();
+}

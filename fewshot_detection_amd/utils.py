@@ -97,3 +97,50 @@ def read_data_cfg(datacfg):
 
 def logging(message):
     print("%s %s" % (time.strftime("%Y-%m-%d %H:%M:%S", time.localtime()), message))
+
+
+def _decode(output, rows_per_image, conf_thresh, num_classes, anchors, num_anchors, only_objectness, over_rows):
+    import numpy as np
+
+    from ._lib import check, lib
+    from .ops import require_device
+    if output.dim() == 3:
+        output = output.unsqueeze(0)
+    require_device(output)
+    out = output.detach().contiguous().float()
+    rows, chans, h, w = out.shape
+    assert chans == (5 + num_classes) * num_anchors
+    cap = num_anchors * h * w
+    boxes = torch.empty((rows, cap, 8), dtype=torch.float32, device=out.device)
+    counts = torch.empty(rows, dtype=torch.int32, device=out.device)
+    anc = np.ctypeslib.as_ctypes(np.asarray(anchors, dtype=np.float64)[:2 * num_anchors].copy())
+    check(lib().fsd_region_decode(out.data_ptr(), boxes.data_ptr(), counts.data_ptr(), rows, rows_per_image,
+                                  num_anchors, num_classes, h, w, anc, float(conf_thresh), int(bool(only_objectness)),
+                                  int(over_rows), cap, torch.cuda.current_stream().cuda_stream), "fsd_region_decode")
+    n = counts.cpu().numpy()                              # tiny; the survivors follow in one more copy
+    top = int(n.max()) if rows else 0
+    host = boxes[:, :max(top, 1)].cpu().numpy()
+    all_boxes = []
+    for r in range(rows):
+        b = host[r, :n[r]]
+        b = b[np.argsort(b[:, 0], kind="stable")]         # restore the reference's (cy, cx, anchor) order
+        all_boxes.append([[float(v[1]), float(v[2]), float(v[3]), float(v[4]), float(v[5]), float(v[6]), int(v[7])]
+                          for v in b])
+    return all_boxes
+
+
+def get_region_boxes_v2(output, n_models, conf_thresh, num_classes, anchors, num_anchors, only_objectness=1,
+                        validation=False):
+    """Meta-detector decode (reference utils.py:195-290): output (bs*n_models, A*(5+C), H, W) -> per-row lists of
+    [cx, cy, w, h, det_conf, cls_conf, cls_id]; class confidence = softmax across the n_models rows of an image."""
+    if num_classes != 1:
+        raise NotImplementedError("the meta detector uses classes=1")
+    assert output.size(0) % n_models == 0
+    return _decode(output, n_models, conf_thresh, num_classes, anchors, num_anchors, only_objectness, True)
+
+
+def get_region_boxes(output, conf_thresh, num_classes, anchors, num_anchors, only_objectness=1, validation=False):
+    """Plain YOLOv2 decode (reference utils.py:112-193), per-cell softmax over the class channels."""
+    if validation and not only_objectness:
+        raise NotImplementedError("validation-mode extra class scores are not on the MI355X path")
+    return _decode(output, 1, conf_thresh, num_classes, anchors, num_anchors, only_objectness, False)

@@ -71,6 +71,17 @@ int fsd_region_loss_fwd_bwd(const float* output, const double* target, const int
                             float class_scale, float thresh, long long seen, int max_boxes,
                             int softmax_over_rows, int zero_tcls, float* dbg_targets, hipStream_t stream);
 
+/* Inference-side decode = utils.get_region_boxes_v2 (utils.py:195-290; softmax_over_rows = 1) or
+ * utils.get_region_boxes (softmax_over_rows = 0): per (row, anchor, cell) sigmoid/exp decode, class
+ * confidence, threshold, and compaction of the survivors on the device.
+ *   boxes  [rows][cap][8] floats: key, cx, cy, w, h (normalised), det_conf, cls_conf, cls_id, where
+ *          key = (cy*W + cx)*A + a is the reference's visiting order (sort by it on the host)
+ *   counts [rows] int32: survivors per row (may exceed cap: the excess was dropped) */
+int fsd_region_decode(const float* output, float* boxes, int* counts, int rows, int rows_per_image,
+                      int num_anchors, int num_classes, int height, int width, const double* anchors_host,
+                      float conf_thresh, int only_objectness, int softmax_over_rows, int cap,
+                      hipStream_t stream);
+
 /* ---- convolution as implicit GEMM on the fp32 matrix cores -------------------------------- */
 /* Packed weight: [round_up(rows,128)][round_up(taps*round_up(red,4), 32)] floats, K-major,
  * k = tap*red4 + r.  mode 0 (forward, replaces nn.Conv2d weight use, darknet_meta.py:236-250):

@@ -190,3 +190,30 @@ def test_region_loss_v1_vs_reference_golden(dev, case):
         _check_loss(mod, d, dev)
     finally:
         cfg.metayolo = True
+
+
+@pytest.mark.parametrize("only_obj", [1, 0])
+def test_region_decode_vs_reference_golden(dev, only_obj):
+    """utils.get_region_boxes_v2 on the device == the reference's python triple loop (tests/golden/decode_v2.npz)."""
+    from fewshot_detection_amd import utils
+    d = np.load(os.path.join(GOLD, "decode_v2.npz"))
+    out = torch.from_numpy(d["output"]).to(dev)
+    cs = int(d["n_models"])
+    got = utils.get_region_boxes_v2(out, cs, float(d["conf_thresh"]), 1, ANCH, 5, only_objectness=only_obj)
+    if only_obj:
+        flat = np.array([[r] + b for r, bl in enumerate(got) for b in bl])
+        ref = d["boxes"]
+        assert flat.shape == ref.shape
+        assert np.array_equal(flat[:, 0], ref[:, 0]) and np.array_equal(flat[:, 7], ref[:, 7])
+        assert np.allclose(flat[:, 1:7], ref[:, 1:7], rtol=1e-5, atol=1e-6)
+        kept = [[r] + b for r, bl in enumerate(got) for b in utils.nms(bl, float(d["nms_thresh"]))]
+        assert np.allclose(np.array(kept), d["kept"], rtol=1e-5, atol=1e-6)
+    else:
+        # det_conf * softmax-over-classes confidence: compare against the oracle formula
+        o = torch.from_numpy(d["output"])
+        rows, _, H, W = o.shape
+        o5 = o.view(rows // cs, cs, 5, 6, H, W)
+        prob = torch.softmax(o5[:, :, :, 5], dim=1)
+        det = torch.sigmoid(o5[:, :, :, 4])
+        n_ref = int(((det * prob) > float(d["conf_thresh"])).sum())
+        assert sum(len(bl) for bl in got) == n_ref
