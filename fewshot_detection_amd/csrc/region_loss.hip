@@ -74,9 +74,9 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
   const int cells = p.A * HW;
   const int chans = 5 + p.C;
   double* s_gt = reinterpret_cast<double*>(smem);                  // kMaxGT * 5
-  int* s_owner = reinterpret_cast<int*>(s_gt + kMaxGT * 5);        // cells
-  int* s_cnt = s_owner + cells;                                    // [0]=#gt for assignment, [1]=#gt for silence
-  double* s_red = reinterpret_cast<double*>(s_cnt + 4);            // 9 * (kThreads/64)
+  double* s_red = s_gt + kMaxGT * 5;                               // 9 * (kThreads/64)  (doubles first: 8-byte aligned)
+  int* s_cnt = reinterpret_cast<int*>(s_red + 9 * (kThreads / 64)); // [0]=#gt for assignment, [1]=#gt for silence
+  int* s_owner = s_cnt + 4;                                        // cells
 
   const int row = blockIdx.x;
   const int tid = threadIdx.x;

@@ -18,7 +18,8 @@ def dev():
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [
-    (2, 13, 13, 64, 128, 3), (3, 9, 7, 3, 32, 3), (2, 13, 13, 256, 30, 1), (1, 6, 6, 1280, 64, 3), (4, 26, 26, 32, 64, 3)])
+    (2, 13, 13, 64, 128, 3), (3, 9, 7, 3, 32, 3), (2, 13, 13, 256, 30, 1), (1, 6, 6, 1280, 64, 3), (4, 26, 26, 32, 64, 3),
+    (2, 13, 13, 1280, 1024, 3), (3, 104, 104, 64, 128, 3), (2, 26, 26, 512, 64, 1)])
 def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(cin + cout)
@@ -33,12 +34,13 @@ def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
     assert torch.allclose(dw, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max())), float((dw - ref).abs().max())
 
 
-@pytest.mark.parametrize("pool", [0, 1, 2])
-def test_conv_bn_leaky_pool_block_backward(dev, pool):
-    """Whole fused block: dgamma, dbeta, dW and dx against torch autograd (fp64)."""
+@pytest.mark.parametrize("pool,B,H,W,cin,cout", [(0, 2, 13, 13, 8, 16), (1, 2, 13, 13, 8, 16), (2, 2, 13, 13, 8, 16),
+                                                  (0, 2, 13, 13, 1280, 1024), (1, 3, 104, 104, 64, 128),
+                                                  (1, 2, 26, 26, 256, 512)])
+def test_conv_bn_leaky_pool_block_backward(dev, pool, B, H, W, cin, cout):
+    """Whole fused block: dgamma, dbeta, dW and dx against torch autograd (fp64), incl. full-size layer shapes."""
     from fewshot_detection_amd import ops
     torch.manual_seed(10 + pool)
-    B, H, W, cin, cout = 2, 13, 13, 8, 16
     x = torch.randn(B, cin, H, W, dtype=torch.float64, requires_grad=True)
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).double()
     bn = torch.nn.BatchNorm2d(cout).double()
