@@ -25,7 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32;      // k-chunk (floats) staged per LDS buffer
 constexpr int kLd = 36;      // padded LDS row stride (floats)
-constexpr int kThreads = 256;
 
 __device__ float g_zero_page[64];   // zero-initialised, never written: source of padding for the DMA path
 
@@ -42,8 +41,6 @@ struct ConvArgs {
   int kgroups;   // taps * cpg
   int nk;        // k-chunks
   int cpt;       // FASTK: chunks per tap (Cin/32)
-  int ablate;     // diagnosis only (FSD_CONV_ABLATE): 1 = no staging after the first chunk, 2 = no barriers (wrong results)
-  int prio_shift; // tuning: wave priority = (blockIdx >> prio_shift) & 3, <0 = leave at 0
   int Kpad;      // packed weight row length (floats)
   int m_tiles, n_tiles;
   int m_base;     // first output row handled by this launch (tail launches start past the main rows)
@@ -56,8 +53,8 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, int VAR, bool GLDS = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void conv_gemm_kernel(ConvArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, bool GLDS>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;      // threads per workgroup (4 or 8 waves)
   constexpr int RPP = NT / 8;                     // tile rows staged per pass (8 threads x 16 B per row)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves");
@@ -71,18 +68,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void co
   constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  // Co-resident waves on a SIMD (from different workgroups) otherwise alternate MFMAs fairly, run
-  // in lock-step and reach their staging (non-MFMA) phases together, leaving the matrix pipe idle.
-  // Distinct static priorities, keyed on the hardware wave slot (unique per SIMD), de-phase them.
-  if (p.prio_shift >= 0) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> p.prio_shift;   // HW_REG_HW_ID.WAVE_ID
-    switch (slot & 3) {
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      default: break;
-    }
-  }
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
   const int m0 = p.m_base + mt * BM, n0 = nt * BN;
@@ -213,7 +198,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void co
   auto compute = [&](const float* st) {
     const float* sa = st + (wm * TM * 32) * LD + frag_off;
     const float* sb = st + (BM + wn * TN * 32) * LD + frag_off;
-    if constexpr (VAR >= 3) {
+    {
       // software-pipelined fragments: the reads of k-step k8+1 are in flight under the MFMAs of k8
       f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -237,24 +222,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void co
               acc[i][j] = NCHW_OUT
                               ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[k8 & 1][j][kk], af[k8 & 1][i][kk], acc[i][j], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x2f32(af[k8 & 1][i][kk], bf[k8 & 1][j][kk], acc[i][j], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int k8 = 0; k8 < kBK / 8; ++k8) {
-        f32x4 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * LD + kofs(k8));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * LD + kofs(k8));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = NCHW_OUT
-                              ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -316,20 +283,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (VAR == 4 ? 3 : 1)) void co
   __syncthreads();
   int cur = 0;
   for (int kc = 0; kc < p.nk; ++kc) {
-    const bool more = (kc + 1 < p.nk) && !(p.ablate & 1);
-    if (more && !(p.ablate & 8)) gload(kc + 1);
-    if constexpr (VAR != 2) __builtin_amdgcn_sched_barrier(0);   // keep uses of the prefetched registers below the MFMAs
+    const bool more = kc + 1 < p.nk;
+    if (more) gload(kc + 1);
+    __builtin_amdgcn_sched_barrier(0);   // the zero-select/LDS store of the prefetched registers stays below the MFMAs
     compute(smem + cur * STAGE);
-    if constexpr (VAR == 0 || VAR == 4) __builtin_amdgcn_sched_barrier(0);
     if constexpr (STAGES == 2) {
-      if (more && !(p.ablate & 4)) sstore(smem + (cur ^ 1) * STAGE);
-      if (p.ablate & 4) asm volatile("" :: "v"(ra[0][0]), "v"(rb[0][0]), "v"(ra[A_PER_T - 1][3]), "v"(rb[B_PER_T - 1][3]));
-      if (!(p.ablate & 2)) __syncthreads();
+      if (more) sstore(smem + (cur ^ 1) * STAGE);
+      __syncthreads();
       cur ^= 1;
     } else {
-      if (!(p.ablate & 2)) __syncthreads();
+      __syncthreads();
       if (more) sstore(smem);
-      if (!(p.ablate & 2)) __syncthreads();
+      __syncthreads();
     }
   }
   }
@@ -433,23 +398,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// Tile configurations {BM, BN, waves_m, waves_n, stages}.
+// ---- tile configurations -----------------------------------------------------------------------
+// Measured on MI355X (profiles/r01_summary.txt, section D):
+//  * kTile64     64x64, one LDS stage (18 KB -> 8 workgroups = 32 waves per CU): 104-116 TFLOP/s on every
+//                layer of the path and insensitive to code placement.                      [DEFAULT]
+//  * kTile128x32 128x32, one stage: the short-K layers (first convs, K <= 320) are store/latency bound.
+//  * kTile128    128x128, two stages, + 64x64 tiles for the rows of the last partial round of
+//                co-resident workgroups ("tail split"): up to 120 TFLOP/s on the 13x13 layers but swings
+//                between 87 and 120 with unrelated code changes.
+//  * kDma*       direct global->LDS DMA staging (XOR-swizzled linear LDS image; 2 stages or a 3-deep
+//                ring with counted vmcnt): same throughput as register staging today; kept because it
+//                frees 32 VGPRs per lane for the planned bf16 path.
+// FSD_CONV_TILE=<letter> forces one configuration (tuning aid, read once per process).
+enum TileId { kTile64 = 0, kTile128x32, kTile128, kDma128, kDma128Ring, kDma64, kNumTiles };
 struct TileCfg { int bm, bn; };
-constexpr TileCfg kCfgs[] = {{128, 128}, {256, 64}, {256, 32}, {128, 64}, {128, 32}, {256, 128}, {128, 128}, {128, 64}, {128, 32}, {64, 64}, {64, 64}, {128, 128}, {128, 128}, {128, 128}, {128, 128}, {256, 128}, {128, 128}, {128, 128}, {64, 64}, {256, 128}, {128, 128}, {128, 128}, {64, 64}};
+constexpr TileCfg kCfgs[kNumTiles] = {{64, 64}, {128, 32}, {128, 128}, {128, 128}, {128, 128}, {64, 64}};
 constexpr int kSlots = 512;   // co-resident 128x128 workgroups on the chip (256 CUs x 2)
-constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// tile shape by output width: narrow layers get narrower tiles so no MFMA columns are wasted
-// Measured on MI355X (profiles/r01_summary.txt, section D): 64x64 tiles with a single LDS stage
-// (18 KB -> 8 workgroups = 32 waves per CU) run every layer of the path at 104-116 TFLOP/s and are
-// insensitive to code placement; the 128x128 two-stage kernel peaks a little higher on the
-// 13x13 layers but swings between 87 and 120 TFLOP/s with unrelated code changes.  Short-K layers
-// (first convs, K <= 320) are store/latency-bound and prefer 128x32.
-inline int tile_cfg(int cout, int cin, int ksize) {
-  static const char* env = getenv("FSD_CONV_TILE");      // tuning aid: force a configuration
-  if (env && env[0] >= 'a' && env[0] < 'a' + kNumCfgs) return env[0] - 'a';
-  (void)cout;
-  return ksize * ksize * cin <= 320 ? 8 : 10;
+inline int tile_cfg(int cin, int ksize) {
+  static const char* env = getenv("FSD_CONV_TILE");
+  if (env && env[0] >= 'a' && env[0] < 'a' + kNumTiles) return env[0] - 'a';
+  return ksize * ksize * cin <= 320 ? kTile128x32 : kTile64;
 }
 
 template <typename K>
@@ -460,23 +429,43 @@ int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t s
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int VAR = 0, bool GLDS = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool GLDS = false>
 int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
   const bool fast = a.cpt > 0;
   constexpr int NT = WM * WN * 64;
   if constexpr (GLDS) {
-    if (fast) {
+    if (fast) {      // the DMA path needs the per-tap fast path; other layers fall through to register staging
       const size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
-      return nchw ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, VAR, true>, a, lds_g, NT, stream)
-                  : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, VAR, true>, a, lds_g, NT, stream);
+      return nchw ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, true>, a, lds_g, NT, stream)
+                  : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, true>, a, lds_g, NT, stream);
     }
   }
-  const size_t lds = STAGES * (size_t)(BM + BN) * kLd * sizeof(float);
+  constexpr int RS = STAGES > 2 ? 2 : STAGES;
+  const size_t lds = RS * (size_t)(BM + BN) * kLd * sizeof(float);
   if (nchw)
-    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, VAR>, a, lds, NT, stream)
-                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, false, VAR>, a, lds, NT, stream);
-  return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, VAR>, a, lds, NT, stream)
-              : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, false, VAR>, a, lds, NT, stream);
+    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, RS, true, false>, a, lds, NT, stream)
+                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, RS, false, false>, a, lds, NT, stream);
+  return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, RS, true, false>, a, lds, NT, stream)
+              : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, RS, false, false>, a, lds, NT, stream);
+}
+
+// Tail splitting for kTile128: rows covered by WHOLE rounds of co-resident workgroups use 128x128 tiles; the
+// remaining rows (a partial round that would leave CUs idle for up to a full tile time) are cut into 64x64
+// tiles, which balance ~4x finer.
+struct RowPlan { int main_m_tiles; int tail_m_tiles; };
+inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  const int m_tiles = (int)((pixels + bm - 1) / bm);
+  RowPlan r{m_tiles, 0};
+  if (cfg != kTile128) return r;
+  const int n_tiles = (cout + bn - 1) / bn;
+  const long long total = (long long)m_tiles * n_tiles;
+  if (total <= kSlots || total % kSlots == 0) return r;
+  const int main_m = (int)((total / kSlots) * kSlots / n_tiles);
+  if (main_m <= 0 || main_m >= m_tiles) return r;
+  r.main_m_tiles = main_m;
+  r.tail_m_tiles = (int)((pixels - (long long)main_m * bm + 63) / 64);
+  return r;
 }
 
 }  // namespace
@@ -499,32 +488,8 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   return (int)hipGetLastError();
 }
 
-namespace {
-// Tail splitting for the 128x128 configuration: rows covered by WHOLE rounds of co-resident
-// workgroups use 128x128 tiles; the remaining rows (a partial round that would leave CUs idle for
-// up to a full tile time) are cut into 64x64 tiles, which balance ~4x finer.
-struct RowPlan { int main_m_tiles; int tail_m_tiles; };
-inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
-  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
-  const int m_tiles = (int)((pixels + bm - 1) / bm);
-  RowPlan r{m_tiles, 0};
-  static const char* env = getenv("FSD_CONV_TAIL");
-  const bool enabled = !(env && env[0] == '0');
-  if (cfg != 0 || !enabled) return r;
-  const int n_tiles = (cout + bn - 1) / bn;
-  const long long total = (long long)m_tiles * n_tiles;
-  if (total <= kSlots || total % kSlots == 0) return r;
-  const int main_m = (int)((total / kSlots) * kSlots / n_tiles);
-  if (main_m <= 0 || main_m >= m_tiles) return r;
-  const long long tail_rows = pixels - (long long)main_m * bm;
-  r.main_m_tiles = main_m;
-  r.tail_m_tiles = (int)((tail_rows + 63) / 64);
-  return r;
-}
-}  // namespace
-
 extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize) {
-  const RowPlan r = plan_rows(pixels, cout, tile_cfg(cout, cin, ksize));
+  const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize));
   return r.main_m_tiles + r.tail_m_tiles;
 }
 
@@ -540,6 +505,7 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15)) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
   if (pixels > 0x7fffffffLL - 512) return FSD_ERR_UNSUPPORTED;
+  if ((pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit element offsets in the kernel
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.bn_partial = bn_partial;
   a.x_ld = x_ld; a.y_ld = y_ld;
@@ -550,64 +516,29 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   a.Kpad = round_up(ksize * ksize * cin, kBK);
   a.nk = a.Kpad / kBK;
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
-  {
-    static const char* env = getenv("FSD_CONV_PRIO");
-    a.prio_shift = env ? atoi(env) : -1;
-    static const char* abl = getenv("FSD_CONV_ABLATE");
-    a.ablate = abl ? atoi(abl) : 0;
-  }
-  // 32-bit element offsets inside the kernel
-  if ((pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
-  const int cfg = tile_cfg(cout, cin, ksize);
+  const int cfg = tile_cfg(cin, ksize);
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
-  const RowPlan plan = out_nchw ? RowPlan{(int)((pixels + bm - 1) / bm), 0} : plan_rows(pixels, cout, cfg);
+  const bool nchw = out_nchw != 0;
+  const RowPlan plan = nchw ? RowPlan{(int)((pixels + bm - 1) / bm), 0} : plan_rows(pixels, cout, cfg);
   a.m_tiles = plan.main_m_tiles;
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
   a.part_base = 0;
-  const bool nchw = out_nchw != 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;
     t.m_base = plan.main_m_tiles * bm;
     t.part_base = plan.main_m_tiles;
     t.m_tiles = plan.tail_m_tiles;
     t.n_tiles = (cout + 63) / 64;
-    const int rc = launch<64, 64, 2, 2, 2, 3>(t, nchw, stream);
+    const int rc = launch<64, 64, 2, 2, 2>(t, nchw, stream);
     if (rc != 0) return rc;
   }
   switch (cfg) {
-    case 0: {
-      static const char* venv = getenv("FSD_CONV_VAR");
-      const int var = venv ? atoi(venv) : 0;
-      if (var == 1) return launch<128, 128, 2, 2, 2, 1>(a, nchw, stream);
-      if (var == 2) return launch<128, 128, 2, 2, 2, 2>(a, nchw, stream);
-      if (var == 3) return launch<128, 128, 2, 2, 2, 3>(a, nchw, stream);
-      if (var == 4) return launch<128, 128, 2, 2, 1, 4>(a, nchw, stream);
-      if (var == 5) return launch<128, 128, 2, 2, 1, 3>(a, nchw, stream);
-      if (var == 6) return launch<128, 128, 2, 2, 2, 0>(a, nchw, stream);
-      return launch<128, 128, 2, 2, 2, 3>(a, nchw, stream);
-    }
-    case 1: return launch<256, 64, 4, 1, 2>(a, nchw, stream);
-    case 2: return launch<256, 32, 4, 1, 2>(a, nchw, stream);
-    case 3: return launch<128, 64, 2, 2, 2>(a, nchw, stream);
-    case 4: return launch<128, 32, 4, 1, 2>(a, nchw, stream);
-    case 5: return launch<256, 128, 2, 2, 2>(a, nchw, stream);
-    case 6: return launch<128, 128, 2, 2, 1>(a, nchw, stream);
-    case 7: return launch<128, 64, 2, 2, 1, 3>(a, nchw, stream);
-    case 8: return launch<128, 32, 4, 1, 1, 3>(a, nchw, stream);
-    case 9: return launch<64, 64, 2, 2, 2, 3>(a, nchw, stream);
-    case 10: return launch<64, 64, 2, 2, 1, 3>(a, nchw, stream);
-    case 11: return launch<128, 128, 2, 4, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 64x32, single LDS stage
-    case 12: return launch<128, 128, 2, 4, 2, 3>(a, nchw, stream);    // ... double stage
-    case 13: return launch<128, 128, 4, 2, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 32x64
-    case 14: return launch<128, 128, 4, 2, 2, 3>(a, nchw, stream);
-    case 15: return launch<256, 128, 4, 2, 1, 3>(a, nchw, stream);    // 8 waves, wave tile 64x64, 55 KB
-    case 16: return launch<128, 128, 2, 2, 2, 3, true>(a, nchw, stream);   // q: DMA staging, 4 waves
-    case 17: return launch<128, 128, 2, 4, 2, 3, true>(a, nchw, stream);   // r: DMA staging, 8 waves
-    case 18: return launch<64, 64, 2, 2, 2, 3, true>(a, nchw, stream);     // s: DMA staging, 64x64
-    case 19: return launch<256, 128, 4, 2, 2, 3, true>(a, nchw, stream);   // t: DMA staging, 256x128, 8 waves
-    case 20: return launch<128, 128, 2, 2, 3, 3, true>(a, nchw, stream);   // u: DMA, 3-stage ring, 4 waves (96 KB)
-    case 21: return launch<128, 128, 2, 4, 3, 3, true>(a, nchw, stream);   // v: DMA, 3-stage ring, 8 waves
-    default: return launch<64, 64, 2, 2, 3, 3, true>(a, nchw, stream);     // w: DMA, 3-stage ring, 64x64 (48 KB)
+    case kTile64: return launch<64, 64, 2, 2, 1>(a, nchw, stream);
+    case kTile128x32: return launch<128, 32, 4, 1, 1>(a, nchw, stream);
+    case kTile128: return launch<128, 128, 2, 2, 2>(a, nchw, stream);
+    case kDma128: return launch<128, 128, 2, 2, 2, true>(a, nchw, stream);
+    case kDma128Ring: return launch<128, 128, 2, 4, 3, true>(a, nchw, stream);
+    default: return launch<64, 64, 2, 2, 2, true>(a, nchw, stream);
   }
 }
