@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
 
 
 def synth_targets(rng, bs, cs):
@@ -137,6 +138,9 @@ def main():
     ap.add_argument("--support", type=int, default=416, help="support image side (cfg/reweighting_net.cfg: 416)")
     ap.add_argument("--mode", choices=["train", "forward"], default=None)
     ap.add_argument("--neg", default="1", help="cfg.neg_ratio ('full' or a number; metayolo.data uses 1)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="conv compute mode: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, fp32 "
+                         "accumulate, fp32 BN/loss/master weights and fp32 weight gradients (BASELINE C3/C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
     args = ap.parse_args()
@@ -171,7 +175,7 @@ def main():
     dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(tmp)
     torch.manual_seed(0)
     random.seed(0)
-    net = Darknet(dyn_cfg, rw_cfg).to(dev).train()
+    net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(args.dtype)
     region = net.models[len(net.models) - 1]
     region.verbose = False
     x, metax, mask, target = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
@@ -238,18 +242,21 @@ def main():
                 "train step (fwd + RegionLoss + bwd + SGD)" if args.mode == "train" else "forward + RegionLoss fwd/grad"),
             "value": world * args.steps / elapsed, "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "img_per_s": world * args.batch * args.steps / elapsed,
             "loss": loss_val,
             "config": {"workload": "BASELINE configs[1]: darknet_dynamic.cfg + reweighting_net.cfg base-training "
-                                   "episode, B=%d queries %dx%d + N=%d supports %dx%d per GPU, fp32, neg_ratio=%s"
-                                   % (args.batch, args.size, args.size, args.classes, args.support, args.support, args.neg),
+                                   "episode, B=%d queries %dx%d + N=%d supports %dx%d per GPU, %s, neg_ratio=%s"
+                                   % (args.batch, args.size, args.size, args.classes, args.support, args.support,
+                                      "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
                        "mode": args.mode, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "episode_forward_gflop": full_flops / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, all launches)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 else None,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, all launches)"
+                         if args.dtype == "f32" else "conv_gemm_bf16_kernel (bf16 implicit-GEMM conv, all launches)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s",
+                         "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
+                         "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 and args.dtype == "f32" else None,
                          "flop_per_launch": conv_flops / max(1, len(prof)),
                          "avg_launch_ms": conv_ms / max(1, len(prof)),
                          "launches_per_step": len(prof) // max(1, args.steps),

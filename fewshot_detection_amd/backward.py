@@ -56,7 +56,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
     pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
-        wp = net.cache.get(conv.weight, mode=1)
+        wp = net.cache.get(conv.weight, 1, net.compute_dtype)
         dx, _ = ops.conv2d(dyv, wp, xv.C, k)
         _accumulate(grads, xv, dx)
 
@@ -79,7 +79,7 @@ def run(net, tape, grad_out, params):
             rows = n_cls * o_ch
             g = ops.nchw_to_nhwc(grad_out.view(x.B, rows, x.H, x.W), pad_to=4)       # (B*HW, rows padded)
             w_eff = rec["w_eff"][:rows * x.C].view(rows, x.C, 1, 1)
-            dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, mode=1), x.C, 1)
+            dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, net.compute_dtype), x.C, 1)
             _accumulate(grads, x, dx)
             dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1)
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach())

@@ -1,0 +1,123 @@
+// Shared by the fp32 (conv.hip) and bf16 (conv_bf16.hip) implicit-GEMM kernels: launch arguments, the
+// XCD-aware tile mapping and the accumulator epilogue (the C/D layout of the 32x32 MFMAs is dtype-independent).
+#ifndef FSD_CONV_COMMON_HPP_
+#define FSD_CONV_COMMON_HPP_
+#include <hip/hip_runtime.h>
+
+namespace fsd_conv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* x;
+  const void* w;        // packed weights: float (fp32 path) or bf16 (bf16 path)
+  const float* bias;
+  float* y;
+  float* bn_partial;
+  long long x_ld, y_ld;
+  int H, W, HW, M;
+  int Cout, ks, pad;
+  int cpg;       // 16-byte channel groups per tap  (Cin/4)
+  int kgroups;   // taps * cpg
+  int nk;        // k-chunks
+  int cpt;       // FASTK: chunks per tap (Cin/32)
+  int Kpad;      // packed weight row length (floats)
+  int m_tiles, n_tiles;
+  int m_base;     // first output row handled by this launch (tail launches start past the main rows)
+  int part_base;  // first bn_partial row of this launch
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  // consecutive logical tiles on one XCD (own L2): dispatch places block b on XCD b % 8
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+
+// Epilogue of one workgroup tile.  acc[i][j] are the TM x TN 32x32 accumulators of this wave
+// (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)); for NCHW_OUT the MFMA operands were swapped,
+// so rows are output channels and columns are pixels.  `smem` is free to reuse (callers end their main
+// loop with a barrier).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool NCHW_OUT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int mt, int tid, int lane, int wm, int wn) {
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+  if constexpr (!NCHW_OUT) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + c_lane;
+      const bool n_ok = n < p.Cout;
+      const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          if (n_ok && m < p.M) p.y[(long long)m * p.y_ld + n] = acc[i][j][r] + bv;
+        }
+      }
+    }
+    if (p.bn_partial != nullptr) {
+      // per-tile column sums of the raw outputs (rows past M hold exact zeros)
+      float* s_stat = smem;    // [WAVES_M][BN][2]; the main loop's last barrier freed the staging LDS
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32) {
+          const int col = (wn * TN + j) * 32 + c_lane;
+          s_stat[(wm * BN + col) * 2 + 0] = s;
+          s_stat[(wm * BN + col) * 2 + 1] = q;
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s += s_stat[(w * BN + tid) * 2 + 0];
+          q += s_stat[(w * BN + tid) * 2 + 1];
+        }
+        const int n = n0 + tid;
+        if (n < p.Cout) {
+          float* dst = p.bn_partial + ((long long)(p.part_base + mt) * p.Cout + n) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
+      }
+    }
+  } else {
+    // transposed accumulator: rows = output channels, cols = pixels -> NCHW store, pixel-contiguous
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + c_lane;
+      const int b = m / p.HW;
+      const int hw = m - b * p.HW;
+      const bool m_ok = m < p.M;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wn * TN + j) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          if (m_ok && n < p.Cout) {
+            const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+            p.y[((long long)b * p.Cout + n) * p.HW + hw] = acc[i][j][r] + bv;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fsd_conv
+#endif  // FSD_CONV_COMMON_HPP_

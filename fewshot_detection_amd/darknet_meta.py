@@ -226,6 +226,13 @@ class Darknet(nn.Module):
         self._det = Network(self.blocks, self.models)
         self._meta = Network(self.learnet_blocks, self.learnet_models)
 
+    def set_compute_dtype(self, dtype):
+        """"f32" (default, exact fp32 MFMA) or "bf16" (conv operands in bf16, fp32 accumulate: BASELINE C3/C5)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        self._det.compute_dtype = self._meta.compute_dtype = dtype
+        return self
+
     # ---- forward ---------------------------------------------------------------------------
     def meta_forward(self, metax, mask):
         """Support images (+ masks) -> list of reweighting vectors [(N, C, 1, 1)]."""

@@ -48,12 +48,12 @@ class _WeightCache(object):
     def __init__(self):
         self._store = {}
 
-    def get(self, w, mode=0):
-        key = (id(w), mode)
+    def get(self, w, mode=0, dtype="f32"):
+        key = (id(w), mode, dtype)
         tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
-            hit = (tag, ops.pack_weight(w.detach(), mode))
+            hit = (tag, ops.pack_weight(w.detach(), mode, dtype))
             self._store[key] = hit
         return hit[1]
 
@@ -66,6 +66,9 @@ class Network(object):
         self.models = models
         self.layers = blocks[1:]
         self.cache = _WeightCache()
+        # "f32": exact fp32 MFMA.  "bf16": conv operands rounded to bf16, fp32 accumulate (BASELINE C3/C5);
+        # BatchNorm statistics, activations, loss, weight gradients and master weights stay fp32.
+        self.compute_dtype = "f32"
         # static analysis: who is read by a [route], and which producers write into a concat buffer
         self.route_src = {}
         self.concat_of = {}
@@ -118,7 +121,7 @@ class Network(object):
             raise NotImplementedError("conv size=%d pad=%s" % (k, blk["pad"]))
         cout = int(blk["filters"])
         slope = _slope(blk["activation"])
-        wp = self.cache.get(conv.weight)
+        wp = self.cache.get(conv.weight, 0, self.compute_dtype)
         dev = xv.t.device
         cin_true = conv.weight.shape[1]
         rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool)
@@ -195,9 +198,9 @@ class Network(object):
                     raise ValueError("reweighting vectors %s do not match %d feature channels"
                                      % (tuple(vec.shape), x.C))
                 n_cls, o_ch = vec.shape[0], head.weight.shape[0]
-                w_eff, b_eff = ops.fold_reweight_head(head.weight.detach(), None if head.bias is None
-                                                      else head.bias.detach(), vec.detach())
-                y, _ = ops.conv2d(x, w_eff, n_cls * o_ch, 1, bias=b_eff, nchw_out=True)
+                w_op, b_eff, w_eff = ops.fold_reweight_head(head.weight.detach(), None if head.bias is None
+                                                            else head.bias.detach(), vec.detach(), self.compute_dtype)
+                y, _ = ops.conv2d(x, w_op, n_cls * o_ch, 1, bias=b_eff, nchw_out=True)
                 result = y.view(x.B * n_cls, o_ch, x.H, x.W)
                 tape.append(dict(kind="head", x=x, head=head, dyn=vec, w_eff=w_eff, n_cls=n_cls, o_ch=o_ch))
                 skip = ind + 1

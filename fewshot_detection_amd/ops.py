@@ -83,11 +83,16 @@ def nhwc_to_nchw(v):
     return out
 
 
-def pack_weight(w, mode=0):
-    """(Cout,Cin,k,k) -> packed K-major operand of fsd_conv2d_fwd (mode 0) / its data gradient (mode 1)."""
+def pack_weight(w, mode=0, dtype="f32"):
+    """(Cout,Cin,k,k) -> packed K-major operand of fsd_conv2d_fwd[_bf16] (mode 0) / its data gradient (mode 1)."""
     require_device(w)
     cout, cin, k, _ = w.shape
     rows, red = (cout, cin) if mode == 0 else (cin, cout)
+    if dtype == "bf16":
+        out = torch.empty(lib().fsd_packed_weight_elems_bf16(rows, red, k), dtype=torch.bfloat16, device=w.device)
+        check(lib().fsd_pack_conv_weight_bf16(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()),
+              "fsd_pack_conv_weight_bf16")
+        return out
     out = torch.empty(lib().fsd_packed_weight_elems(rows, red, k), dtype=torch.float32, device=w.device)
     check(lib().fsd_pack_conv_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()),
           "fsd_pack_conv_weight")
@@ -107,15 +112,18 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     else:
         y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
         y_ptr, y_ld = y.ptr, y.ld
+    bf16 = w_packed.dtype == torch.bfloat16          # the packed operand carries the compute mode
     if bn_partial:
-        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize)
+        tiles = (lib().fsd_conv_row_tiles_bf16(xv.pixels) if bf16
+                 else lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize))
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().fsd_conv2d_fwd(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
-                               xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()),
-          "fsd_conv2d_fwd")
+    fn = lib().fsd_conv2d_fwd_bf16 if bf16 else lib().fsd_conv2d_fwd
+    check(fn(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+             xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()),
+          "fsd_conv2d_fwd_bf16" if bf16 else "fsd_conv2d_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels))
@@ -175,8 +183,17 @@ def dynamic_conv(x, w):
     return out
 
 
-def fold_reweight_head(head_w, head_b, dyn):
-    """-> (w_eff_packed, bias_eff) for the fused reweighting (x) 1x1 head GEMM."""
+def fold_reweight_head(head_w, head_b, dyn, dtype="f32"):
+    """-> (w_eff_packed, bias_eff, w_eff_f32) for the fused reweighting (x) 1x1 head GEMM.  The fp32 fold is
+    always built (the backward un-folds it); in bf16 mode it is re-packed as the bf16 operand."""
+    w_eff, b_eff = _fold_reweight_head_f32(head_w, head_b, dyn)
+    if dtype == "bf16":
+        rows, Cc = dyn.shape[0] * head_w.shape[0], head_w.shape[1]
+        return pack_weight(w_eff[:rows * Cc].view(rows, Cc, 1, 1), 0, "bf16"), b_eff, w_eff
+    return w_eff, b_eff, w_eff
+
+
+def _fold_reweight_head_f32(head_w, head_b, dyn):
     O, Cc = head_w.shape[0], head_w.shape[1]
     N = dyn.shape[0]
     w_eff = torch.empty(lib().fsd_packed_weight_elems(N * O, Cc, 1), dtype=torch.float32, device=dyn.device)

@@ -105,6 +105,18 @@ int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const 
                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
                    int cout, int ksize, int out_nchw, hipStream_t stream);
 
+/* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
+ * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;
+ * weights are packed once as bf16 ([round_up(rows,128)][round_up(taps*round_up(red,4), 64)] bf16);
+ * outputs, bias and the BatchNorm partial sums are fp32.  bn_partial has fsd_conv_row_tiles_bf16 rows. */
+size_t fsd_packed_weight_elems_bf16(int rows, int red, int ksize);
+int fsd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed_bf16, int cout, int cin, int ksize, int mode,
+                              hipStream_t stream);
+int fsd_conv_row_tiles_bf16(long long pixels);
+int fsd_conv2d_fwd_bf16(const float* x, long long x_ld, const void* w_packed_bf16, const float* bias, float* y,
+                        long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
+                        int cout, int ksize, int out_nchw, hipStream_t stream);
+
 /* ---- batch norm (training statistics) + activation + pooling ------------------------------ */
 /* Reduce the per-tile partials, produce the per-channel affine (scale = gamma*invstd,
  * shift = beta - mean*scale), save mean / invstd for the backward pass and update the running
