@@ -42,6 +42,7 @@ PROTOTYPES = {
     "fsd_fold_reweight_head": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "fsd_conv2d_wgrad": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_conv2d_wgrad_bf16": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_act_bwd_rows": (_i, [_ll]),
     "fsd_bn_act_pool_bwd_rows": (_i, [_i, _i, _i, _i]),
     "fsd_reduce_workspace_bytes": (_sz, [_i]),

@@ -53,7 +53,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         elif conv.bias is not None:
             pgrads[id(conv.bias)] = s1
         dy = dt
-    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k)
+    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         wp = net.cache.get(conv.weight, 1, net.compute_dtype)
@@ -81,7 +81,7 @@ def run(net, tape, grad_out, params):
             w_eff = rec["w_eff"][:rows * x.C].view(rows, x.C, 1, 1)
             dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, net.compute_dtype), x.C, 1)
             _accumulate(grads, x, dx)
-            dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1)
+            dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1, net.compute_dtype)
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach())
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn

@@ -11,6 +11,7 @@
 // slices in a fixed order (deterministic) while scattering into the OIHW layout of the parameter.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "fsdet.h"
 
 namespace {
@@ -18,17 +19,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBK = 32;
+constexpr int kBK = 32;       // pixels per k-chunk
 constexpr int kThreads = 256;
-// 64x64 tiles, one LDS stage (17 KB -> 8 workgroups per CU): same occupancy-first choice as the
-// forward kernel (conv.hip), which measured best and most stable on MI355X.
-constexpr int kBM = 64, kBN = 64;
-constexpr int kStages = 1;
-constexpr int kLdT = kBM + 4;        // LDS row stride (floats), keeps 16-byte alignment
-constexpr int kCQ = kBM / 4;         // float4 column groups per tile row
-constexpr int kRPP = kThreads / kCQ; // k rows staged per pass
-constexpr int kPasses = kBK / kRPP;
-constexpr int kT = kBM / 64;         // 32x32 MFMA tiles per wave along each dimension (2x2 waves)
 
 struct WgradArgs {
   const float* dy;     // (pixels, dy_ld), columns [0, Cout) (zero padded to a multiple of 4)
@@ -40,25 +32,39 @@ struct WgradArgs {
   int m_tiles, n_tiles, pix_per_split;
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// TILE x TILE outputs per workgroup (2x2 waves), STAGES LDS buffers.
+//   BF16 = false: exact fp32 MFMA (32x32x2), LDS tiles hold floats.            TILE 64, 1 stage (17 KB, 8 WGs/CU)
+//   BF16 = true : operands rounded to bf16 (RNE) on the LDS store, 32x32x16 MFMA with fp32 accumulation
+//                 (BASELINE C3/C5); fragments need 8 consecutive PIXELS per lane, which are LDS rows here, so
+//                 they are gathered with 16-bit LDS reads (pairs land in the two halves of one VGPR).
+template <int TILE, int STAGES, bool BF16>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int STAGE = 2 * kBK * kLdT;          // A tile + B tile
+  typedef typename std::conditional<BF16, unsigned short, float>::type lds_t;
+  constexpr int LDT = TILE + (BF16 ? 8 : 4);       // LDS row stride in elements (keeps 16-byte alignment)
+  constexpr int CQ = TILE / 4;                     // float4 column groups per tile row
+  constexpr int RPP = kThreads / CQ;               // pixel rows staged per pass
+  constexpr int PASSES = kBK / RPP;
+  constexpr int T = TILE / 64;                     // 32x32 MFMA tiles per wave along each dimension
+  constexpr int STAGE = 2 * kBK * LDT;             // A tile + B tile, in elements
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  lds_t* smem = reinterpret_cast<lds_t*>(smem_raw);
+
   const int tile = blockIdx.x;
   const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
-  const int m0 = mt * kBM, n0 = nt * kBN;
+  const int m0 = mt * TILE, n0 = nt * TILE;
   const int split = blockIdx.y;
   const int p_begin = split * p.pix_per_split;
   const int p_end = min(p.M, p_begin + p.pix_per_split);
   const int nk = (p_end - p_begin + kBK - 1) / kBK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int cq = tid % kCQ, kr = tid / kCQ;      // this thread's 4-channel column group / first k row
+  const int cq = tid % CQ, kr = tid / CQ;          // this thread's 4-channel column group / first pixel row
 
-  // A: dy columns are fixed per thread
-  const int a_col = m0 + cq * 4;
+  const int a_col = m0 + cq * 4;                   // A: dy columns are fixed per thread
   const bool a_ok = a_col < p.Cout;
-  // B: the im2col column (tap, ci) is fixed per thread
-  const int b_col = n0 + cq * 4;
+  const int b_col = n0 + cq * 4;                   // B: the im2col column (tap, ci) is fixed per thread
   const bool b_colok = b_col < p.ncols;
   const int tap = b_colok ? b_col / p.cin4 : 0;
   const int ci = b_col - tap * p.cin4;
@@ -66,13 +72,13 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   const int dyy = ky - p.pad, dxx = kx - p.pad;
   const int shift = dyy * p.W + dxx;
 
-  f32x4 ra[kPasses], rb[kPasses];
+  f32x4 ra[PASSES], rb[PASSES];
   unsigned okmask = 0;
   auto gload = [&](int kc) {
     okmask = 0;
 #pragma unroll
-    for (int j = 0; j < kPasses; ++j) {
-      const int pix = p_begin + kc * kBK + kr + kRPP * j;
+    for (int j = 0; j < PASSES; ++j) {
+      const int pix = p_begin + kc * kBK + kr + RPP * j;
       const bool pv = pix < p_end;
       const bool aok = pv && a_ok;
       ra[j] = *reinterpret_cast<const f32x4*>(p.dy + (aok ? (long long)pix * p.dy_ld + a_col : 0));
@@ -85,54 +91,96 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       okmask |= (bok ? 256u : 0u) << j;
     }
   };
-  auto sstore = [&](float* st) {
+  auto put = [&](lds_t* dst, f32x4 v, bool ok) {
+    if constexpr (BF16) {
+      uint2 w = make_uint2(0u, 0u);
+      if (ok) {
+        const __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
+        w.x = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+        w.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+      }
+      *reinterpret_cast<uint2*>(dst) = w;
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto sstore = [&](lds_t* st) {
 #pragma unroll
-    for (int j = 0; j < kPasses; ++j) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(st + (kr + kRPP * j) * kLdT + cq * 4) = (okmask >> j) & 1u ? ra[j] : z;
-      *reinterpret_cast<f32x4*>(st + (kBK + kr + kRPP * j) * kLdT + cq * 4) = (okmask >> (8 + j)) & 1u ? rb[j] : z;
+    for (int j = 0; j < PASSES; ++j) {
+      put(st + (kr + RPP * j) * LDT + cq * 4, ra[j], (okmask >> j) & 1u);
+      put(st + (kBK + kr + RPP * j) * LDT + cq * 4, rb[j], (okmask >> (8 + j)) & 1u);
     }
   };
 
-  f32x16 acc[kT][kT];
+  f32x16 acc[T][T];
 #pragma unroll
-  for (int i = 0; i < kT; ++i)
+  for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = 0; j < kT; ++j)
+    for (int j = 0; j < T; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frag = (lane >> 5) * 4 * kLdT + (lane & 31);
-  auto compute = [&](const float* st) {
-    const float* sa = st + wm * (kT * 32) + frag;
-    const float* sb = st + kBK * kLdT + wn * (kT * 32) + frag;
-    // fragments one k8-step ahead of the MFMAs (statically indexed double buffer)
-    float af[2][4][kT], bf[2][4][kT];
+  auto compute = [&](const lds_t* st) {
+    if constexpr (BF16) {
+      // lane (m = lane & 31, h = lane >> 5) supplies pixels s*16 + h*8 .. +7 of column m
+      const unsigned short* sa = st + (lane >> 5) * 8 * LDT + wm * (T * 32) + (lane & 31);
+      const unsigned short* sb = st + kBK * LDT + (lane >> 5) * 8 * LDT + wn * (T * 32) + (lane & 31);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+      for (int s16 = 0; s16 < kBK / 16; ++s16) {
+        bf16x8 af[T], bf[T];
 #pragma unroll
-      for (int i = 0; i < kT; ++i) af[0][kk][i] = sa[kk * kLdT + i * 32];
+        for (int i = 0; i < T; ++i) {
+          unsigned short v[8];
 #pragma unroll
-      for (int j = 0; j < kT; ++j) bf[0][kk][j] = sb[kk * kLdT + j * 32];
-    }
+          for (int e = 0; e < 8; ++e) v[e] = sa[(s16 * 16 + e) * LDT + i * 32];
 #pragma unroll
-    for (int k8 = 0; k8 < kBK / 8; ++k8) {
-      if (k8 + 1 < kBK / 8) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-          for (int i = 0; i < kT; ++i) af[(k8 + 1) & 1][kk][i] = sa[((k8 + 1) * 8 + kk) * kLdT + i * 32];
-#pragma unroll
-          for (int j = 0; j < kT; ++j) bf[(k8 + 1) & 1][kk][j] = sb[((k8 + 1) * 8 + kk) * kLdT + j * 32];
+          for (int e = 0; e < 8; ++e) af[i][e] = __builtin_bit_cast(__bf16, v[e]);
         }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          unsigned short v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = sb[(s16 * 16 + e) * LDT + j * 32];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bf[j][e] = __builtin_bit_cast(__bf16, v[e]);
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+          for (int j = 0; j < T; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const float* sa = st + (lane >> 5) * 4 * LDT + wm * (T * 32) + (lane & 31);
+      const float* sb = st + kBK * LDT + (lane >> 5) * 4 * LDT + wn * (T * 32) + (lane & 31);
+      // fragments one k8-step ahead of the MFMAs (statically indexed double buffer)
+      float af[2][4][T], bf[2][4][T];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) af[0][kk][i] = sa[kk * LDT + i * 32];
+#pragma unroll
+        for (int j = 0; j < T; ++j) bf[0][kk][j] = sb[kk * LDT + j * 32];
       }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int k8 = 0; k8 < kBK / 8; ++k8) {
+        if (k8 + 1 < kBK / 8) {
 #pragma unroll
-        for (int i = 0; i < kT; ++i)
+          for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-          for (int j = 0; j < kT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k8 & 1][kk][i], bf[k8 & 1][kk][j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < T; ++i) af[(k8 + 1) & 1][kk][i] = sa[((k8 + 1) * 8 + kk) * LDT + i * 32];
+#pragma unroll
+            for (int j = 0; j < T; ++j) bf[(k8 + 1) & 1][kk][j] = sb[((k8 + 1) * 8 + kk) * LDT + j * 32];
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k8 & 1][kk][i], bf[k8 & 1][kk][j], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -147,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       compute(smem + cur * STAGE);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kStages == 2) {
+      if constexpr (STAGES == 2) {
         if (more) sstore(smem + (cur ^ 1) * STAGE);
         __syncthreads();
         cur ^= 1;
@@ -162,13 +210,13 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   float* out = p.ws + (long long)split * p.Cout * p.ncols;
   const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
 #pragma unroll
-  for (int i = 0; i < kT; ++i)
+  for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = 0; j < kT; ++j) {
-      const int n = n0 + wn * (kT * 32) + j * 32 + c_lane;
+    for (int j = 0; j < T; ++j) {
+      const int n = n0 + wn * (T * 32) + j * 32 + c_lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (kT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        const int m = m0 + wm * (T * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
         if (m < p.Cout && n < p.ncols) out[(long long)m * p.ncols + n] = acc[i][j][r];
       }
     }
@@ -215,18 +263,11 @@ inline int pick_splits(long long pixels, int tiles) {
   return s;
 }
 
-}  // namespace
+inline int tile_of(int bf16) { return bf16 ? 128 : 64; }
 
-extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
-  const long long pixels = (long long)batch * height * width;
-  const int ncols = ksize * ksize * round_up(cin, 4);
-  const int tiles = ((cout + kBM - 1) / kBM) * ((ncols + kBN - 1) / kBN);
-  return (size_t)pick_splits(pixels, tiles) * cout * ncols * sizeof(float);
-}
-
-extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
-                                void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
-                                int cout, int ksize, hipStream_t stream) {
+int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw, void* workspace,
+               size_t workspace_bytes, int batch, int height, int width, int cin, int cout, int ksize, int bf16,
+               hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!dy || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 || cin < 1 || cout < 1) return FSD_ERR_ARG;
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
@@ -234,21 +275,26 @@ extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x
   if ((dy_ld & 3) || (x_ld & 3) || dy_ld < round_up(cout, 4) || x_ld < cin4) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
   if (pixels > 0x7fffffffLL - 4096) return FSD_ERR_UNSUPPORTED;
-  if (workspace_bytes < fsd_conv2d_wgrad_workspace_bytes(batch, height, width, cin, cout, ksize)) return FSD_ERR_WORKSPACE;
+  const int tile = tile_of(bf16);
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
   a.dy_ld = dy_ld; a.x_ld = x_ld;
   a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
   a.Cout = cout; a.cin4 = cin4; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.ncols = ksize * ksize * cin4;
-  a.m_tiles = (cout + kBM - 1) / kBM;
-  a.n_tiles = (a.ncols + kBN - 1) / kBN;
+  a.m_tiles = (cout + tile - 1) / tile;
+  a.n_tiles = (a.ncols + tile - 1) / tile;
   const int splits = pick_splits(pixels, a.m_tiles * a.n_tiles);
+  if (workspace_bytes < (size_t)splits * cout * a.ncols * sizeof(float)) return FSD_ERR_WORKSPACE;
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
-  const size_t lds = kStages * (size_t)(2 * kBK * kLdT) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(a.m_tiles * a.n_tiles, splits), dim3(kThreads), lds, stream, a);
+  const dim3 grid(a.m_tiles * a.n_tiles, splits);
+  if (bf16) {
+    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
+    hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
+  } else {
+    const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
+  }
   if (splits <= 8)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
@@ -256,4 +302,34 @@ extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((a.ncols + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
+  // sized for the finer (fp32, 64x64) tiling, which needs the larger number of splits; valid for both modes
+  const long long pixels = (long long)batch * height * width;
+  const int ncols = ksize * ksize * round_up(cin, 4);
+  size_t best = 0;
+  for (int bf16 = 0; bf16 < 2; ++bf16) {
+    const int tile = tile_of(bf16);
+    const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
+    const size_t need = (size_t)pick_splits(pixels, tiles) * cout * ncols * sizeof(float);
+    if (need > best) best = need;
+  }
+  return best;
+}
+
+extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                                void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                int cout, int ksize, hipStream_t stream) {
+  return wgrad_impl(dy, dy_ld, x, x_ld, dw_oihw, workspace, workspace_bytes, batch, height, width, cin, cout, ksize, 0,
+                    stream);
+}
+
+extern "C" int fsd_conv2d_wgrad_bf16(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                                     void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                     int cout, int ksize, hipStream_t stream) {
+  return wgrad_impl(dy, dy_ld, x, x_ld, dw_oihw, workspace, workspace_bytes, batch, height, width, cin, cout, ksize, 1,
+                    stream);
 }

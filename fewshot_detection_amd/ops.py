@@ -206,15 +206,16 @@ def _fold_reweight_head_f32(head_w, head_b, dyn):
 
 # ---- backward ------------------------------------------------------------------------------
 
-def conv2d_wgrad(dyv, cout, xv, cin, ksize):
+def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32"):
     """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv."""
     L = lib()
     dev = xv.t.device
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
-    check(L.fsd_conv2d_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
-                             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
+    fn = L.fsd_conv2d_wgrad_bf16 if dtype == "bf16" else L.fsd_conv2d_wgrad
+    check(fn(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
+             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
     return dw
 
 

@@ -171,7 +171,12 @@ size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int ci
 int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
                      void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                      int cout, int ksize, hipStream_t stream);
-/* (The data gradient is fsd_conv2d_fwd on dy with weights packed in mode 1.) */
+/* bf16 compute mode of the same gradient: dy and x are rounded to bf16 (RNE) on their way into LDS,
+ * products accumulate in fp32; same workspace query. */
+int fsd_conv2d_wgrad_bf16(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                          void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                          int cout, int ksize, hipStream_t stream);
+/* (The data gradient is fsd_conv2d_fwd[_bf16] on dy with weights packed in mode 1.) */
 
 /* Gradient through pool(act(y*scale+shift)): dt = d loss / d (y*scale+shift), dense (pixels, C),
  * plus per-block partial sums [fsd_bn_act_pool_bwd_rows(...)][C][2] of (dt, dt*xhat) for the BatchNorm
