@@ -11,6 +11,7 @@
 // slices in a fixed order (deterministic) while scattering into the OIHW layout of the parameter.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "fsdet.h"
 
@@ -263,7 +264,11 @@ inline int pick_splits(long long pixels, int tiles) {
   return s;
 }
 
-inline int tile_of(int bf16) { return bf16 ? 128 : 64; }
+inline int tile_of(int bf16) {
+  static const char* env = getenv("FSD_WGRAD_TILE");     // tuning aid
+  if (env && !bf16) return atoi(env) == 128 ? 128 : 64;
+  return bf16 ? 128 : 64;
+}
 
 int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw, void* workspace,
                size_t workspace_bytes, int batch, int height, int width, int cin, int cout, int ksize, int bf16,
@@ -291,6 +296,11 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   if (bf16) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
     hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
+  } else if (tile == 128) {
+    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((wgrad_kernel<128, 2, false>), grid, dim3(kThreads), lds, stream, a);
   } else {
     const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
     hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
