@@ -222,7 +222,9 @@ int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
 #undef FSD_LAUNCH
 }
 
-constexpr int kBM = 128, kBN = 128;
+constexpr int kBM = 128;
+// narrow layers get narrow tiles so no MFMA columns (and no staged weight rows) are wasted
+inline int tile_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
 }  // namespace
 
@@ -269,9 +271,12 @@ extern "C" int fsd_conv2d_fwd_bf16(const float* x, long long x_ld, const void* w
   a.Kpad = round_up(ksize * ksize * cin, kBKh);
   a.nk = a.Kpad / kBKh;
   a.cpt = (cin % kBKh == 0) ? cin / kBKh : 0;
+  const int bn = tile_bn(cout);
   a.m_tiles = (int)((pixels + kBM - 1) / kBM);
-  a.n_tiles = (cout + kBN - 1) / kBN;
+  a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
   a.part_base = 0;
-  return launch<kBM, kBN, 2, 2>(a, out_nchw != 0, stream);
+  if (bn == 32) return launch<kBM, 32, 4, 1>(a, out_nchw != 0, stream);
+  if (bn == 64) return launch<kBM, 64, 2, 2>(a, out_nchw != 0, stream);
+  return launch<kBM, 128, 2, 2>(a, out_nchw != 0, stream);
 }
