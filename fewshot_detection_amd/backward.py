@@ -56,8 +56,10 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
     pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
-        wp = net.cache.get(conv.weight, 1, net.compute_dtype)
-        dx, _ = ops.conv2d(dyv, wp, xv.C, k)
+        if net.compute_dtype == "f32" and ops.wino_eligible(dyv.C, xv.C, k):
+            dx, _ = ops.conv3x3_wino(dyv, net.cache.get(conv.weight, 1, "wino"), xv.C)
+        else:
+            dx, _ = ops.conv2d(dyv, net.cache.get(conv.weight, 1, net.compute_dtype), xv.C, k)
         _accumulate(grads, xv, dx)
 
 

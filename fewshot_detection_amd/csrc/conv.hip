@@ -43,6 +43,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   constexpr int STAGE = (BM + BN) * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
+  if (gridDim.y > 1) {      // batched GEMMs: every batch has its own operand / result matrices
+    p.x += (long long)blockIdx.y * p.x_bs;
+    p.w = static_cast<const float*>(p.w) + (long long)blockIdx.y * p.w_bs;
+    p.y += (long long)blockIdx.y * p.y_bs;
+  }
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
   const int m0 = p.m_base + mt * BM, n0 = nt * BN;
@@ -325,7 +330,7 @@ template <typename K>
 int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles), dim3(threads), lds, stream, a);
+  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, a.batches), dim3(threads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -369,6 +374,29 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
 }
 
 }  // namespace
+
+int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs,
+                                float* y, long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches,
+                                hipStream_t stream) {
+  if (cin % kBK != 0 || rows < 1 || rows > 0x7fffffffLL - 512 || (rows + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = nullptr; a.y = y; a.bn_partial = nullptr;
+  a.x_ld = x_ld; a.y_ld = y_ld;
+  a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;     // one "image" of `rows` pixels, 1x1 taps
+  a.Cout = cout; a.ks = 1; a.pad = 0;
+  a.cpg = cin / 4;
+  a.kgroups = a.cpg;
+  a.Kpad = cin;
+  a.nk = cin / kBK;
+  a.cpt = cin / kBK;
+  a.m_tiles = (int)((rows + 63) / 64);
+  a.n_tiles = (cout + 63) / 64;
+  a.m_base = 0;
+  a.part_base = 0;
+  a.batches = batches;
+  a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
+  return launch<64, 64, 2, 2, 1>(a, false, stream);
+}
 
 extern "C" size_t fsd_packed_weight_elems(int rows, int red, int ksize) {
   return (size_t)round_up(rows, 128) * (size_t)round_up(ksize * ksize * round_up(red, 4), kBK);
@@ -424,6 +452,8 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
   a.part_base = 0;
+  a.batches = 1;
+  a.x_bs = a.w_bs = a.y_bs = 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;
     t.m_base = plan.main_m_tiles * bm;

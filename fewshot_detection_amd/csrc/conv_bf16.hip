@@ -276,6 +276,8 @@ extern "C" int fsd_conv2d_fwd_bf16(const float* x, long long x_ld, const void* w
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
   a.part_base = 0;
+  a.batches = 1;
+  a.x_bs = a.w_bs = a.y_bs = 0;
   if (bn == 32) return launch<kBM, 32, 4, 1>(a, out_nchw != 0, stream);
   if (bn == 64) return launch<kBM, 64, 2, 2>(a, out_nchw != 0, stream);
   return launch<kBM, 128, 2, 2>(a, out_nchw != 0, stream);

@@ -26,7 +26,14 @@ struct ConvArgs {
   int m_tiles, n_tiles;
   int m_base;     // first output row handled by this launch (tail launches start past the main rows)
   int part_base;  // first bn_partial row of this launch
+  // batched GEMMs (gridDim.y > 1, used by the Winograd path): element strides between the operands of consecutive batches
+  long long x_bs, w_bs, y_bs;
+  int batches;
 };
+
+// fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)
+int conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs, float* y,
+                      long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches, hipStream_t stream);
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   // consecutive logical tiles on one XCD (own L2): dispatch places block b on XCD b % 8

@@ -1,0 +1,229 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride-1 / "same" convolutions of the path (fp32).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiplications per 2x2 outputs instead of 36: 2.25x less matrix work on the layers that hold 93 % of
+// the FLOPs.  Three launches:
+//   1. wino_input_kernel   x (NHWC)  ->  V[16][tiles][Cin]      (B^T d B, zero padding handled here)
+//   2. conv_gemm_batched   M[p] = V[p] * U[p]^T for the 16 positions p  (the fp32 MFMA kernel of conv.hip,
+//                          grid.y = 16; U = G g G^T is packed once per weight update)
+//   3. wino_output_kernel  M -> y (NHWC, + bias) and the per-block BatchNorm partial sums (sum y, sum y^2)
+// The data gradient is the same pipeline with the filter rotated by 180 degrees and channels swapped (mode 1).
+// Transforms are pure adds in fp32; the result differs from the direct convolution by ~1e-6 relative.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsdet.h"
+#include "conv_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTilesPerBlock = 64;     // tiles reduced by one block of the output transform
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// One thread: one tile x 4 channels.
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
+                                                        int H, int W, int TH, int TW, int C, long long T) {
+  const int cg = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * cg) return;
+  const int g = (int)(idx % cg);
+  const long long tile = idx / cg;
+  const int tx = (int)(tile % TW);
+  const long long t2 = tile / TW;
+  const int ty = (int)(t2 % TH);
+  const long long b = t2 / TH;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int iy = 2 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ix = 2 * tx - 1 + j;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      d[i][j] = ok ? ld4(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4) : zero;
+    }
+  }
+  // t = B^T d   (rows), then V = t B (columns);  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  f32x4 t[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = d[0][j] - d[2][j];
+    t[1][j] = d[1][j] + d[2][j];
+    t[2][j] = d[2][j] - d[1][j];
+    t[3][j] = d[1][j] - d[3][j];
+  }
+  float* dst = V + tile * C + g * 4;
+  const long long ps = T * C;                 // stride between the 16 position matrices
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st4(dst + (i * 4 + 0) * ps, t[i][0] - t[i][2]);
+    st4(dst + (i * 4 + 1) * ps, t[i][1] + t[i][2]);
+    st4(dst + (i * 4 + 2) * ps, t[i][2] - t[i][1]);
+    st4(dst + (i * 4 + 3) * ps, t[i][1] - t[i][3]);
+  }
+}
+
+// One block: 64 channel groups x 4 tile lanes over kTilesPerBlock tiles; writes y and the BN partial sums.
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long long y_ld, float* __restrict__ partial,
+                                                         int H, int W, int TH, int TW, int C, long long T) {
+  __shared__ float s_red[4][64][8];
+  const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int g = blockIdx.y * 64 + gl;
+  const int cg = C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
+  f32x4 s1 = zero, s2 = zero;
+  const long long t0 = (long long)blockIdx.x * kTilesPerBlock;
+  const long long ps = T * C;
+  if (g_ok) {
+    for (int it = pl; it < kTilesPerBlock; it += 4) {
+      const long long tile = t0 + it;
+      if (tile >= T) break;
+      const int tx = (int)(tile % TW);
+      const long long t2 = tile / TW;
+      const int ty = (int)(t2 % TH);
+      const long long b = t2 / TH;
+      const float* src = Mb + tile * C + g * 4;
+      f32x4 m[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = ld4(src + (i * 4 + j) * ps);
+      // s = A^T m (rows), Y = s A (columns);  A^T = [1 1 1 0; 0 1 -1 -1]
+      f32x4 s[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[0][j] = m[0][j] + m[1][j] + m[2][j];
+        s[1][j] = m[1][j] - m[2][j] - m[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oy = 2 * ty + i;
+        if (oy >= H) continue;
+        const f32x4 o0 = s[i][0] + s[i][1] + s[i][2];
+        const f32x4 o1 = s[i][1] - s[i][2] - s[i][3];
+        const int ox = 2 * tx;
+        float* dst = y + ((b * H + oy) * (long long)W + ox) * y_ld + g * 4;
+        st4(dst, o0 + bv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += o0[k]; s2[k] += o0[k] * o0[k]; }
+        if (ox + 1 < W) {
+          st4(dst + y_ld, o1 + bv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s1[k] += o1[k]; s2[k] += o1[k] * o1[k]; }
+        }
+      }
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_red[pl][gl][k] = s1[k];
+    s_red[pl][gl][4 + k] = s2[k];
+  }
+  __syncthreads();
+  if (pl == 0 && g_ok) {
+    float* dst = partial + ((long long)blockIdx.x * C + g * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dst[2 * k] = s_red[0][gl][k] + s_red[1][gl][k] + s_red[2][gl][k] + s_red[3][gl][k];
+      dst[2 * k + 1] = s_red[0][gl][4 + k] + s_red[1][gl][4 + k] + s_red[2][gl][4 + k] + s_red[3][gl][4 + k];
+    }
+  }
+}
+
+// U[p][row][k] = (G g G^T)[p],  g = w[row][k] (mode 0) or the rotated / channel-swapped filter (mode 1);
+// written in the packed layout of the GEMM kernel: [16][rows_pad][red] (rows_pad = round_up(rows, 128)).
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int mode,
+                                   int rows, int red, int rows_pad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows_pad * red) return;
+  const int row = (int)(idx / red), k = (int)(idx - (long long)row * red);
+  float gk[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (row < rows) {
+        v = mode == 0 ? w[(((long long)row * cin + k) * 3 + a) * 3 + b]
+                      : w[(((long long)k * cin + row) * 3 + (2 - a)) * 3 + (2 - b)];
+      }
+      gk[a][b] = v;
+    }
+  // t = G g : rows [g0; (g0+g1+g2)/2; (g0-g1+g2)/2; g2]
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = gk[0][b];
+    t[1][b] = 0.5f * (gk[0][b] + gk[1][b] + gk[2][b]);
+    t[2][b] = 0.5f * (gk[0][b] - gk[1][b] + gk[2][b]);
+    t[3][b] = gk[2][b];
+  }
+  const long long ps = (long long)rows_pad * red;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    U[(a * 4 + 0) * ps + idx] = t[a][0];
+    U[(a * 4 + 1) * ps + idx] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    U[(a * 4 + 2) * ps + idx] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+    U[(a * 4 + 3) * ps + idx] = t[a][2];
+  }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline long long tiles_of(int batch, int h, int w) { return (long long)batch * ((h + 1) / 2) * ((w + 1) / 2); }
+
+}  // namespace
+
+extern "C" size_t fsd_wino_packed_weight_elems(int rows, int red) { return (size_t)16 * round_up(rows, 128) * red; }
+
+extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode,
+                                    hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w_oihw || !u_packed || cout < 1 || cin < 1 || (mode != 0 && mode != 1)) return FSD_ERR_ARG;
+  const int rows = mode == 0 ? cout : cin, red = mode == 0 ? cin : cout;
+  if (red % 32) return FSD_ERR_UNSUPPORTED;
+  const int rows_pad = round_up(rows, 128);
+  const long long total = (long long)rows_pad * red;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
+                     cout, cin, mode, rows, red, rows_pad);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout) {
+  return (size_t)16 * tiles_of(batch, height, width) * (size_t)(cin + cout) * sizeof(float);
+}
+
+extern "C" int fsd_wino_partial_rows(int batch, int height, int width) {
+  return (int)((tiles_of(batch, height, width) + kTilesPerBlock - 1) / kTilesPerBlock);
+}
+
+extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                                    long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
+                                    int height, int width, int cin, int cout, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (cin % 32 || (cout & 3) || (x_ld & 3) || (y_ld & 3) || x_ld < cin || y_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
+  const int TH = (height + 1) / 2, TW = (width + 1) / 2;
+  const long long T = tiles_of(batch, height, width);
+  float* V = reinterpret_cast<float*>(workspace);
+  float* Mb = V + (size_t)16 * T * cin;
+  const long long n_in = T * (cin / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
+                     width, TH, TW, cin, T);
+  const int rows_pad = round_up(cout, 128);
+  int rc = fsd_conv::conv_gemm_batched(V, cin, T * cin, u_packed, (long long)rows_pad * cin, Mb, cout, T * cout, T, cin, cout,
+                                       16, stream);
+  if (rc != 0) return rc;
+  const dim3 grid((unsigned)((T + kTilesPerBlock - 1) / kTilesPerBlock), (cout / 4 + 63) / 64);
+  hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial, height, width, TH, TW,
+                     cout, T);
+  return (int)hipGetLastError();
+}

@@ -53,7 +53,8 @@ class _WeightCache(object):
         tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
-            hit = (tag, ops.pack_weight(w.detach(), mode, dtype))
+            packed = ops.pack_weight_wino(w.detach(), mode) if dtype == "wino" else ops.pack_weight(w.detach(), mode, dtype)
+            hit = (tag, packed)
             self._store[key] = hit
         return hit[1]
 
@@ -121,18 +122,26 @@ class Network(object):
             raise NotImplementedError("conv size=%d pad=%s" % (k, blk["pad"]))
         cout = int(blk["filters"])
         slope = _slope(blk["activation"])
-        wp = self.cache.get(conv.weight, 0, self.compute_dtype)
+        wino = self.compute_dtype == "f32" and ops.wino_eligible(xv.C, cout, k)
+        wp = self.cache.get(conv.weight, 0, "wino" if wino else self.compute_dtype)
         dev = xv.t.device
         cin_true = conv.weight.shape[1]
         rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool)
         if bn is None and slope == 1.0 and pool == 0:
             z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
-            ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
+            if wino:
+                ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z)
+            else:
+                ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
             rec.update(y=z, z=z, z_full=None)
             tape.append(rec)
             return z, None
-        y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
-                                bn_partial=bn is not None and training, cin_true=cin_true)
+        if wino:
+            y, partial = ops.conv3x3_wino(xv, wp, cout, bias=None if bn is not None else conv.bias,
+                                          bn_partial=bn is not None and training)
+        else:
+            y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
+                                    bn_partial=bn is not None and training, cin_true=cin_true)
         scale = shift = mean = invstd = None
         if bn is not None:
             scale, shift, mean, invstd = ops.bn_finalize(partial, xv.pixels, bn, training)

@@ -99,6 +99,47 @@ def pack_weight(w, mode=0, dtype="f32"):
     return out
 
 
+def pack_weight_wino(w, mode=0):
+    """(Cout,Cin,3,3) -> 16 transformed (G g G^T) matrices in the GEMM kernel's packed layout."""
+    require_device(w)
+    cout, cin, k, _ = w.shape
+    assert k == 3
+    rows, red = (cout, cin) if mode == 0 else (cin, cout)
+    out = torch.empty(lib().fsd_wino_packed_weight_elems(rows, red), dtype=torch.float32, device=w.device)
+    check(lib().fsd_wino_pack_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, mode, _stream()),
+          "fsd_wino_pack_weight")
+    return out
+
+
+def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False):
+    """Winograd F(2x2,3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3)."""
+    L = lib()
+    dev = xv.t.device
+    y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
+    partial = None
+    if bn_partial:
+        partial = torch.empty((L.fsd_wino_partial_rows(xv.B, xv.H, xv.W), cout, 2), dtype=torch.float32, device=dev)
+    ws_bytes = L.fsd_wino_workspace_bytes(xv.B, xv.H, xv.W, xv.C, cout)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(L.fsd_wino_conv3x3_fwd(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+                                 ws.data_ptr(), ws_bytes, xv.B, xv.H, xv.W, xv.C, cout, _stream()),
+          "fsd_wino_conv3x3_fwd")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels))
+    return y, partial
+
+
+def wino_eligible(cin, cout, ksize):
+    """Measured on MI355X: the transforms cost ~16x(Cin+Cout) floats of HBM traffic per tile, which only pays
+    once both channel counts reach 128 (the 104x104 layers with 64 channels are faster on the direct kernel)."""
+    return WINOGRAD and ksize == 3 and cin % 32 == 0 and cout % 4 == 0 and min(cin, cout) >= 128
+
+
+WINOGRAD = True     # Winograd F(2x2,3x3) for eligible fp32 3x3 layers (forward + data gradient)
 PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per conv launch
 
 

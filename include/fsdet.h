@@ -105,6 +105,18 @@ int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const 
                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
                    int cout, int ksize, int out_nchw, hipStream_t stream);
 
+/* Winograd F(2x2,3x3) form of the fp32 3x3 convolution (2.25x fewer multiplications): input transform ->
+ * 16 batched GEMMs on the fp32 MFMA kernel -> output transform (+bias, + BatchNorm partial sums
+ * [fsd_wino_partial_rows][cout][2]).  u_packed = G g G^T from fsd_wino_pack_weight (mode 0 forward,
+ * mode 1 data gradient), cin % 32 == 0, cout % 4 == 0.  Result equals fsd_conv2d_fwd up to fp32 round-off. */
+size_t fsd_wino_packed_weight_elems(int rows, int red);
+int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode, hipStream_t stream);
+size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout);
+int fsd_wino_partial_rows(int batch, int height, int width);
+int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                         long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
+                         int height, int width, int cin, int cout, hipStream_t stream);
+
 /* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
  * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;
  * weights are packed once as bf16 ([round_up(rows,128)][round_up(taps*round_up(red,4), 64)] bf16);

@@ -254,3 +254,38 @@ def test_conv_bf16_matches_bf16_rounded_reference(dev, B, H, W, cin, cout, k, bi
         flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
         assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-3)
         assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,bias", [
+    (2, 13, 13, 64, 128, False),     # odd size: 7x7 tiles, last row/column half empty
+    (1, 26, 26, 128, 64, True),
+    (2, 6, 6, 1280, 1024, False),    # L29 channel widths
+    (3, 8, 10, 96, 36, False),       # Cout not a multiple of 64
+    (1, 2, 2, 64, 32, True),         # a single tile per image
+])
+def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias):
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 1).float()
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    yv, part = ops.conv3x3_wino(xv, ops.pack_weight_wino(w.to(dev)), cout, bias=None if b is None else b.to(dev),
+                                bn_partial=not bias)
+    y = ops.nhwc_to_nchw(yv).cpu()
+    assert torch.allclose(y, ref, rtol=1e-4, atol=5e-5), float((y - ref).abs().max())
+    if part is not None:
+        p = part.double().sum(0).cpu()
+        flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
+        assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
+    if cout % 32:                                # the data gradient swaps the roles of cin / cout
+        return
+    # data gradient through the same pipeline (mode-1 weights)
+    xg = x.double().requires_grad_(True)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    F.conv2d(xg, w.double(), None, 1, 1).backward(gy.double())
+    dx, _ = ops.conv3x3_wino(ops.nchw_to_nhwc(gy.to(dev)), ops.pack_weight_wino(w.to(dev), mode=1), cin)
+    gref = xg.grad.float()
+    assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), gref, rtol=1e-4, atol=1e-4 * float(gref.abs().max()))
