@@ -251,8 +251,13 @@ def main():
                                       "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
                        "mode": args.mode, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "episode_forward_gflop": full_flops / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv, all launches)"
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv launches: conv_gemm_kernel (fp32 MFMA implicit GEMM); 3x3 layers with >=128 channels "
+                                   "run as wino_input_kernel + conv_gemm_kernel (16 batched GEMMs) + wino_output_kernel"
                          if args.dtype == "f32" else "conv_gemm_bf16_kernel (bf16 implicit-GEMM conv, all launches)",
+                         "note": "achieved = ALGORITHMIC direct-convolution FLOPs (2*k*k*Cin*Cout*pixels) / HIP-event time of "
+                                 "the conv launches; Winograd executes 2.25x fewer MFMA FLOPs than that on its layers. "
+                                 "rocprof check: conv_ms_per_step == per-step sum of the kernels named in `kernel`",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),

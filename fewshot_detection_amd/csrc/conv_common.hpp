@@ -126,5 +126,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   }
 }
 
+// batched reduction GEMMs on the fp32 weight-gradient kernel (defined in wgrad.hip)
+int wgrad_batched_splits(long long rows, int cin, int cout, int batches);
+int wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_bs, const float* x, long long x_ld, long long x_bs,
+                       float* ws, long long rows, int cin, int cout, int batches, int* splits_out, hipStream_t stream);
+
 }  // namespace fsd_conv
 #endif  // FSD_CONV_COMMON_HPP_

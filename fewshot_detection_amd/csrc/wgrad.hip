@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "fsdet.h"
+#include "conv_common.hpp"
 
 namespace {
 
@@ -31,6 +32,7 @@ struct WgradArgs {
   int H, W, HW, M;     // M = pixels
   int Cout, cin4, ks, pad, ncols;
   int m_tiles, n_tiles, pix_per_split;
+  long long dy_bs, x_bs, ws_bs;   // batched (gridDim.z > 1, Winograd weight gradient): strides between batches
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -51,6 +53,11 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   constexpr int STAGE = 2 * kBK * LDT;             // A tile + B tile, in elements
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   lds_t* smem = reinterpret_cast<lds_t*>(smem_raw);
+  if (gridDim.z > 1) {
+    p.dy += (long long)blockIdx.z * p.dy_bs;
+    p.x += (long long)blockIdx.z * p.x_bs;
+    p.ws += (long long)blockIdx.z * p.ws_bs;
+  }
 
   const int tile = blockIdx.x;
   const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
@@ -292,6 +299,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   const int splits = pick_splits(pixels, a.m_tiles * a.n_tiles);
   if (workspace_bytes < (size_t)splits * cout * a.ncols * sizeof(float)) return FSD_ERR_WORKSPACE;
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
+  a.dy_bs = a.x_bs = a.ws_bs = 0;
   const dim3 grid(a.m_tiles * a.n_tiles, splits);
   if (bf16) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
@@ -315,6 +323,34 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
 }
 
 }  // namespace
+
+// 16 (or any number of) independent reduction GEMMs  ws[b][split][m][n] = sum_rows dy[b][row][m] * x[b][row][n]
+// on the fp32 weight-gradient kernel (ks = 1).  Returns the number of splits through *splits_out.
+int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_bs, const float* x, long long x_ld,
+                                 long long x_bs, float* ws, long long rows, int cin, int cout, int batches,
+                                 int* splits_out, hipStream_t stream) {
+  if (rows < 1 || rows > 0x7fffffffLL - 4096 || (cin & 3) || (dy_ld & 3) || (x_ld & 3)) return FSD_ERR_UNSUPPORTED;
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.ws = ws;
+  a.dy_ld = dy_ld; a.x_ld = x_ld;
+  a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;
+  a.Cout = cout; a.cin4 = cin; a.ks = 1; a.pad = 0;
+  a.ncols = cin;
+  a.m_tiles = (cout + 63) / 64;
+  a.n_tiles = (cin + 63) / 64;
+  const int splits = wgrad_batched_splits(rows, cin, cout, batches);
+  a.pix_per_split = round_up((int)((rows + splits - 1) / splits), kBK);
+  a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)splits * cout * cin;
+  const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+  hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), dim3(a.m_tiles * a.n_tiles, splits, batches), dim3(kThreads), lds, stream, a);
+  *splits_out = splits;
+  return (int)hipGetLastError();
+}
+
+int fsd_conv::wgrad_batched_splits(long long rows, int cin, int cout, int batches) {
+  const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64) * batches;
+  return pick_splits(rows, tiles);
+}
 
 extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
   // sized for the finer (fp32, 64x64) tiling, which needs the larger number of splits; valid for both modes

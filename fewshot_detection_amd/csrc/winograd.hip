@@ -176,6 +176,76 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// Weight gradient, F(3x3, 2x2):  dW = A3^T [ (G2 dy G2^T) (.) (B^T d B) ] A3  summed over tiles.
+// The input transform B^T d B is the forward one; the sign difference between the F(2,3) and F(3,2)
+// B matrices is folded into G2 = [1 0; .5 .5; .5 -.5; 0 -1].
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
+                                                     int H, int W, int TH, int TW, int C, long long T) {
+  const int cg = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * cg) return;
+  const int g = (int)(idx % cg);
+  const long long tile = idx / cg;
+  const int tx = (int)(tile % TW);
+  const long long t2 = tile / TW;
+  const int ty = (int)(t2 % TH);
+  const long long b = t2 / TH;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 q[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oy = 2 * ty + i, ox = 2 * tx + j;
+      q[i][j] = (oy < H && ox < W) ? ld4(dy + ((b * H + oy) * (long long)W + ox) * dy_ld + g * 4) : zero;
+    }
+  f32x4 t[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    t[0][j] = q[0][j];
+    t[1][j] = 0.5f * (q[0][j] + q[1][j]);
+    t[2][j] = 0.5f * (q[0][j] - q[1][j]);
+    t[3][j] = -q[1][j];
+  }
+  float* dst = Wt + tile * C + g * 4;
+  const long long ps = T * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st4(dst + (i * 4 + 0) * ps, t[i][0]);
+    st4(dst + (i * 4 + 1) * ps, 0.5f * (t[i][0] + t[i][1]));
+    st4(dst + (i * 4 + 2) * ps, 0.5f * (t[i][0] - t[i][1]));
+    st4(dst + (i * 4 + 3) * ps, -t[i][1]);
+  }
+}
+
+// ws[p][split][co][ci] -> dw[co][ci][3][3] = A3^T m A3,  A3^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
+__global__ void wino_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int cout, int cin) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (co, ci), ci fastest
+  const long long n = (long long)cout * cin;
+  if (idx >= n) return;
+  float m[4][4];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    float v = 0.f;
+    for (int k = 0; k < splits; ++k) v += ws[((long long)p * splits + k) * n + idx];
+    m[p >> 2][p & 3] = v;
+  }
+  float s[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = m[0][j] + m[1][j] + m[2][j];
+    s[1][j] = m[1][j] - m[2][j];
+    s[2][j] = m[1][j] + m[2][j] + m[3][j];
+  }
+  float* dst = dw + idx * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dst[i * 3 + 0] = s[i][0] + s[i][1] + s[i][2];
+    dst[i * 3 + 1] = s[i][1] - s[i][2];
+    dst[i * 3 + 2] = s[i][1] + s[i][2] + s[i][3];
+  }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline long long tiles_of(int batch, int h, int w) { return (long long)batch * ((h + 1) / 2) * ((w + 1) / 2); }
 
@@ -225,5 +295,36 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   const dim3 grid((unsigned)((T + kTilesPerBlock - 1) / kTilesPerBlock), (cout / 4 + 63) / 64);
   hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial, height, width, TH, TW,
                      cout, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout) {
+  const long long T = tiles_of(batch, height, width);
+  const int splits = fsd_conv::wgrad_batched_splits(T, cin, cout, 16);
+  return ((size_t)16 * T * (size_t)(cin + cout) + (size_t)16 * splits * cout * cin) * sizeof(float);
+}
+
+extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                                      void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                      int cout, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if ((cin & 3) || (cout & 3) || (x_ld & 3) || (dy_ld & 3) || x_ld < cin || dy_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
+  const int TH = (height + 1) / 2, TW = (width + 1) / 2;
+  const long long T = tiles_of(batch, height, width);
+  float* V = reinterpret_cast<float*>(workspace);
+  float* Wt = V + (size_t)16 * T * cin;
+  float* ws = Wt + (size_t)16 * T * cout;
+  const long long n_in = T * (cin / 4), n_dy = T * (cout / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
+                     width, TH, TW, cin, T);
+  hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
+                     width, TH, TW, cout, T);
+  int splits = 0;
+  int rc = fsd_conv::wgrad_gemm_batched(Wt, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, 16, &splits, stream);
+  if (rc != 0) return rc;
+  const long long n = (long long)cout * cin;
+  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }

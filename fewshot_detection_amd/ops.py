@@ -251,6 +251,13 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32"):
     """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv."""
     L = lib()
     dev = xv.t.device
+    if dtype == "f32" and wino_eligible(cin, cout, ksize) and cin == xv.C:
+        ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout)
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+        check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B,
+                                       xv.H, xv.W, cin, cout, _stream()), "fsd_wino_conv3x3_wgrad")
+        return dw
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)

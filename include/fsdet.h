@@ -117,6 +117,13 @@ int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, 
                          long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
                          int height, int width, int cin, int cout, hipStream_t stream);
 
+/* Winograd F(3x3,2x2) form of the fp32 weight gradient of a 3x3 convolution: dW = sum over 2x2 tiles,
+ * 16 batched reduction GEMMs over tiles instead of 9 taps x pixels (2.25x fewer multiplications). */
+size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout);
+int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                           void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                           int cout, hipStream_t stream);
+
 /* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
  * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;
  * weights are packed once as bf16 ([round_up(rows,128)][round_up(taps*round_up(red,4), 64)] bf16);

@@ -19,7 +19,9 @@ def dev():
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [
     (2, 13, 13, 64, 128, 3), (3, 9, 7, 3, 32, 3), (2, 13, 13, 256, 30, 1), (1, 6, 6, 1280, 64, 3), (4, 26, 26, 32, 64, 3),
-    (2, 13, 13, 1280, 1024, 3), (3, 104, 104, 64, 128, 3), (2, 26, 26, 512, 64, 1)])
+    (2, 13, 13, 1280, 1024, 3), (3, 104, 104, 64, 128, 3), (2, 26, 26, 512, 64, 1),
+    # Winograd F(3x3,2x2) weight-gradient shapes (>=128 channels both sides), incl. odd extents
+    (3, 13, 11, 128, 256, 3), (2, 52, 52, 128, 256, 3), (1, 7, 9, 256, 128, 3), (5, 1, 1, 128, 128, 3)])
 def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(cin + cout)
@@ -32,6 +34,19 @@ def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
     dw = ops.conv2d_wgrad(gv, cout, xv, cin, k).cpu()
     ref = w.grad.float()
     assert torch.allclose(dw, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max())), float((dw - ref).abs().max())
+
+
+def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(5)
+    xv = ops.nchw_to_nhwc(torch.randn(4, 256, 26, 26, generator=g).to(dev))
+    gv = ops.nchw_to_nhwc(torch.randn(4, 512, 26, 26, generator=g).to(dev))
+    assert ops.wino_eligible(256, 512, 3)
+    a = ops.conv2d_wgrad(gv, 512, xv, 256, 3)
+    monkeypatch.setattr(ops, "WINOGRAD", False)
+    b = ops.conv2d_wgrad(gv, 512, xv, 256, 3)
+    assert not torch.equal(a, b)                      # really two different code paths
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize("pool,B,H,W,cin,cout", [(0, 2, 13, 13, 8, 16), (1, 2, 13, 13, 8, 16), (2, 2, 13, 13, 8, 16),
