@@ -9,7 +9,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPixPerBlock = 256;     // pixels reduced by one block of the first pass
-constexpr int kSlots = 64;
+constexpr int kSlots = 256;
 
 inline unsigned blocks_for(long long n, int per) {
   long long b = (n + per - 1) / per;
@@ -32,13 +32,17 @@ struct ActBwdArgs {
   int H, W, OH, OW, C, pool;
   long long pixels;
   float slope;
+  int ppb;                // pixels (cells x 4 for the pool2 kernel) covered by one block = one partial row
 };
 
-// One block: 64 channel groups (256 channels) x 4 pixel lanes, looping over kPixPerBlock pixels.
+// One block: GL channel groups (4 channels each) x 256/GL pixel lanes, looping over kPixPerBlock pixels.
+// GL follows the layer (8 for 32 channels ... 64 for >= 256) so that narrow layers keep every lane busy.
+template <int GL>
 __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
-  __shared__ float s_red[4][64][8];
-  const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int g = blockIdx.y * 64 + gl;
+  constexpr int NPL = 256 / GL;
+  __shared__ float s_red[NPL][GL][8];
+  const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
+  const int g = blockIdx.y * GL + gl;
   const int cg = p.C >> 2;
   const bool g_ok = g < cg;
   const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
@@ -47,9 +51,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
   const f32x4 mu = (g_ok && p.mean) ? ld4(p.mean + g * 4) : zero;
   const f32x4 is = (g_ok && p.invstd) ? ld4(p.invstd + g * 4) : one;
   f32x4 s1 = zero, s2 = zero;
-  const long long p0 = (long long)blockIdx.x * kPixPerBlock;
+  const long long p0 = (long long)blockIdx.x * p.ppb;
   if (g_ok) {
-    for (int it = pl; it < kPixPerBlock; it += 4) {
+    for (int it = pl; it < p.ppb; it += NPL) {
       const long long pix = p0 + it;
       if (pix >= p.pixels) break;
       const int ix = (int)(pix % p.W);
@@ -115,8 +119,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
     float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      dst[2 * k] = s_red[0][gl][k] + s_red[1][gl][k] + s_red[2][gl][k] + s_red[3][gl][k];
-      dst[2 * k + 1] = s_red[0][gl][4 + k] + s_red[1][gl][4 + k] + s_red[2][gl][4 + k] + s_red[3][gl][4 + k];
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b += s_red[l][gl][4 + k]; }
+      dst[2 * k] = a;
+      dst[2 * k + 1] = b;
     }
   }
 }
@@ -124,10 +131,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
 // pool == 1 (2x2 stride 2) specialisation: one thread per 2x2 CELL and 4 channels, so every y is
 // read once, the argmax is decided once and the (up to) four dt values are written together.
 // Cells on the odd border (no pooling window) only carry the dz_full / zero gradient.
+template <int GL>
 __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
-  __shared__ float s_red[4][64][8];
-  const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int g = blockIdx.y * 64 + gl;
+  constexpr int NPL = 256 / GL;
+  __shared__ float s_red[NPL][GL][8];
+  const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
+  const int g = blockIdx.y * GL + gl;
   const int cg = p.C >> 2;
   const bool g_ok = g < cg;
   const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
@@ -138,9 +147,9 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
   const int CH = (p.H + 1) >> 1, CW = (p.W + 1) >> 1;
   const long long cells = (long long)(p.pixels / ((long long)p.H * p.W)) * CH * CW;
   f32x4 s1 = zero, s2 = zero;
-  const long long c0 = (long long)blockIdx.x * (kPixPerBlock / 4);
+  const long long c0 = (long long)blockIdx.x * (p.ppb / 4);
   if (g_ok) {
-    for (int it = pl; it < kPixPerBlock / 4; it += 4) {
+    for (int it = pl; it < p.ppb / 4; it += NPL) {
       const long long cell = c0 + it;
       if (cell >= cells) break;
       const int cx = (int)(cell % CW);
@@ -194,19 +203,53 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
     float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      dst[2 * k] = s_red[0][gl][k] + s_red[1][gl][k] + s_red[2][gl][k] + s_red[3][gl][k];
-      dst[2 * k + 1] = s_red[0][gl][4 + k] + s_red[1][gl][4 + k] + s_red[2][gl][4 + k] + s_red[3][gl][4 + k];
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b += s_red[l][gl][4 + k]; }
+      dst[2 * k] = a;
+      dst[2 * k + 1] = b;
     }
   }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ slots, int rows, int two_c) {
-  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+// [rows][two_c] float partials -> [n_slots][two_c] doubles.  Block = RL row lanes x CL columns; row lanes are
+// folded through LDS in a fixed order (deterministic).
+template <int RL>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ slots,
+                                                              int rows, int two_c, int n_slots) {
+  constexpr int CL = 256 / RL;
+  __shared__ double s_acc[RL][CL];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int e = blockIdx.y * CL + cl;
   const int s = blockIdx.x;
-  if (e >= two_c) return;
   double acc = 0.0;
-  for (int t = s; t < rows; t += kSlots) acc += (double)partial[(long long)t * two_c + e];
-  slots[(long long)s * two_c + e] = acc;
+  if (e < two_c) {
+    const long long step = (long long)n_slots * RL;
+    long long t = s + (long long)n_slots * rl;
+    for (; t + 3 * step < rows; t += 4 * step) {
+      const float v0 = partial[t * two_c + e], v1 = partial[(t + step) * two_c + e];
+      const float v2 = partial[(t + 2 * step) * two_c + e], v3 = partial[(t + 3 * step) * two_c + e];
+      acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+    }
+    for (; t < rows; t += step) acc += (double)partial[t * two_c + e];
+  }
+  if constexpr (RL > 1) {
+    s_acc[rl][cl] = acc;
+    __syncthreads();
+    if (rl != 0) return;
+#pragma unroll
+    for (int l = 1; l < RL; ++l) acc += s_acc[l][cl];
+  }
+  if (e < two_c) slots[(long long)s * two_c + e] = acc;
+}
+
+inline void launch_reduce_partials(const float* partial, double* slots, int rows, int two_c, int n_slots, hipStream_t stream) {
+  if (two_c <= 64)
+    hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
+  else if (two_c <= 128)
+    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
 }
 
 // dgamma/dbeta (or dbias) and the per-channel coefficients of  dy = c1 * (dt - c2 - xhat * c3)
@@ -216,6 +259,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ slots, int n_s
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= channels) return;
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
   for (int k = 0; k < n_slots; ++k) {
     s1 += slots[((long long)k * channels + c) * 2 + 0];
     s2 += slots[((long long)k * channels + c) * 2 + 1];
@@ -247,12 +291,13 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ dt, const float* __restr
 }
 
 // column sums of a (rows, ld) matrix, any C: partial[blocks][C][2] with the second slot zero
-__global__ void colsum_kernel(const float* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows) {
+__global__ void colsum_kernel(const float* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows,
+                              int ppb) {
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const long long r0 = (long long)blockIdx.x * kPixPerBlock;
+  const long long r0 = (long long)blockIdx.x * ppb;
   float s = 0.f;
-  for (int i = 0; i < kPixPerBlock && r0 + i < rows; ++i) s += m[(r0 + i) * ld + c];
+  for (int i = 0; i < ppb && r0 + i < rows; ++i) s += m[(r0 + i) * ld + c];
   partial[((long long)blockIdx.x * C + c) * 2] = s;
   partial[((long long)blockIdx.x * C + c) * 2 + 1] = 0.f;
 }
@@ -328,12 +373,21 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
 
 }  // namespace
 
-extern "C" int fsd_act_bwd_rows(long long pixels) { return (int)((pixels + kPixPerBlock - 1) / kPixPerBlock); }
+// small layers get shorter blocks so that the launch still covers the chip
+inline int pix_per_block(long long pixels) { return pixels <= 65536 ? 64 : kPixPerBlock; }
+
+inline int cells_per_block(long long cells) { return cells <= 16384 ? 32 : kPixPerBlock / 4; }
+
+extern "C" int fsd_act_bwd_rows(long long pixels) {
+  const int ppb = pix_per_block(pixels);
+  return (int)((pixels + ppb - 1) / ppb);
+}
 
 extern "C" int fsd_bn_act_pool_bwd_rows(int batch, int height, int width, int pool) {
   if (pool == 1) {
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
-    return (int)((cells + kPixPerBlock / 4 - 1) / (kPixPerBlock / 4));
+    const int cpb = cells_per_block(cells);
+    return (int)((cells + cpb - 1) / cpb);
   }
   return fsd_act_bwd_rows((long long)batch * height * width);
 }
@@ -355,15 +409,25 @@ extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float
   a.dt = dt; a.partial = partial; a.dz_ld = dz_ld; a.dzf_ld = dz_full_ld; a.y_ld = y_ld;
   a.H = height; a.W = width; a.OH = pool == 1 ? height / 2 : height; a.OW = pool == 1 ? width / 2 : width;
   a.C = channels; a.pool = pool; a.pixels = (long long)batch * height * width; a.slope = slope;
+  const int cg = channels / 4;
+  const int gl = cg <= 8 ? 8 : cg <= 16 ? 16 : cg <= 32 ? 32 : 64;    // channel-group lanes per block
   if (pool == 1) {
-    // window-major: a block covers kPixPerBlock/4 cells; partial rows = cells / (kPixPerBlock/4) <= fsd_act_bwd_rows(pixels)
+    // window-major: a block covers cells_per_block cells = one partial row (fsd_bn_act_pool_bwd_rows)
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
-    const dim3 grid(blocks_for(cells, kPixPerBlock / 4), (channels / 4 + 63) / 64);
-    hipLaunchKernelGGL(act_bwd_pool2_kernel, grid, dim3(256), 0, stream, a);
+    a.ppb = 4 * cells_per_block(cells);
+    const dim3 grid(blocks_for(cells, a.ppb / 4), (cg + gl - 1) / gl);
+    if (gl == 8) hipLaunchKernelGGL(act_bwd_pool2_kernel<8>, grid, dim3(256), 0, stream, a);
+    else if (gl == 16) hipLaunchKernelGGL(act_bwd_pool2_kernel<16>, grid, dim3(256), 0, stream, a);
+    else if (gl == 32) hipLaunchKernelGGL(act_bwd_pool2_kernel<32>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(act_bwd_pool2_kernel<64>, grid, dim3(256), 0, stream, a);
     return (int)hipGetLastError();
   }
-  const dim3 grid(blocks_for(a.pixels, kPixPerBlock), (channels / 4 + 63) / 64);
-  hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, stream, a);
+  a.ppb = pix_per_block(a.pixels);
+  const dim3 grid(blocks_for(a.pixels, a.ppb), (cg + gl - 1) / gl);
+  if (gl == 8) hipLaunchKernelGGL(act_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
+  else if (gl == 16) hipLaunchKernelGGL(act_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
+  else if (gl == 32) hipLaunchKernelGGL(act_bwd_kernel<32>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(act_bwd_kernel<64>, grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -373,8 +437,7 @@ extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long cou
   if (!partial || !workspace || rows < 1 || channels < 1 || count < 1) return FSD_ERR_ARG;
   const int n_slots = rows < kSlots ? rows : kSlots;
   const int two_c = 2 * channels;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial,
-                     reinterpret_cast<double*>(workspace), rows, two_c);
+  launch_reduce_partials(partial, reinterpret_cast<double*>(workspace), rows, two_c, n_slots, stream);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, scale, dgamma, dbeta,
                      coef);
@@ -395,8 +458,9 @@ extern "C" int fsd_colsum_partials(const float* m, long long ld, float* partial,
                                    hipStream_t stream) {
   (void)hipGetLastError();
   if (!m || !partial || rows < 1 || channels < 1) return FSD_ERR_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(rows, kPixPerBlock), (channels + 255) / 256), dim3(256), 0, stream, m,
-                     ld, partial, channels, rows);
+  const int ppb = pix_per_block(rows);      // partial rows = fsd_act_bwd_rows(rows)
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(rows, ppb), (channels + 255) / 256), dim3(256), 0, stream, m,
+                     ld, partial, channels, rows, ppb);
   return (int)hipGetLastError();
 }
 

@@ -320,10 +320,11 @@ struct TileCfg { int bm, bn; };
 constexpr TileCfg kCfgs[kNumTiles] = {{64, 64}, {128, 32}, {128, 128}, {128, 128}, {128, 128}, {64, 64}};
 constexpr int kSlots = 512;   // co-resident 128x128 workgroups on the chip (256 CUs x 2)
 
-inline int tile_cfg(int cin, int ksize) {
+inline int tile_cfg(int cin, int ksize, int cout, bool nchw = false) {
   static const char* env = getenv("FSD_CONV_TILE");
   if (env && env[0] >= 'a' && env[0] < 'a' + kNumTiles) return env[0] - 'a';
-  return ksize * ksize * cin <= 320 ? kTile128x32 : kTile64;
+  // short reductions, and outputs no wider than 32 channels (a 64-wide tile would idle half the MFMAs)
+  return (ksize * ksize * cin <= 320 || (cout <= 32 && !nchw)) ? kTile128x32 : kTile64;
 }
 
 template <typename K>
@@ -417,7 +418,7 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
 }
 
 extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize) {
-  const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize));
+  const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize, cout));
   return r.main_m_tiles + r.tail_m_tiles;
 }
 
@@ -444,9 +445,9 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   a.Kpad = round_up(ksize * ksize * cin, kBK);
   a.nk = a.Kpad / kBK;
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
-  const int cfg = tile_cfg(cin, ksize);
-  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   const bool nchw = out_nchw != 0;
+  const int cfg = tile_cfg(cin, ksize, cout, nchw);
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   const RowPlan plan = nchw ? RowPlan{(int)((pixels + bm - 1) / bm), 0} : plan_rows(pixels, cout, cfg);
   a.m_tiles = plan.main_m_tiles;
   a.n_tiles = (cout + bn - 1) / bn;

@@ -8,7 +8,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kBnSlots = 64;
+constexpr int kBnSlots = 256;
 
 inline unsigned blocks_for(long long n, int per) {
   long long b = (n + per - 1) / per;
@@ -16,15 +16,45 @@ inline unsigned blocks_for(long long n, int per) {
 }
 
 // ---- BN statistics -----------------------------------------------------------------------
-// stage 1: fold the [tiles][C][2] float partials of the conv epilogue into [64][C][2] doubles
-__global__ void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ slots, int tiles,
-                                 int two_c) {
-  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+// stage 1: fold the [tiles][C][2] float partials of the conv epilogue into [slots][C][2] doubles.
+// Block = RL row lanes x CL columns (CL = 256 / RL); row lanes are folded through LDS in a fixed order, so the
+// result does not depend on scheduling.
+template <int RL>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ slots,
+                                                        int tiles, int two_c, int n_slots) {
+  constexpr int CL = 256 / RL;
+  __shared__ double s_acc[RL][CL];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int e = blockIdx.y * CL + cl;
   const int s = blockIdx.x;
-  if (e >= two_c) return;
   double acc = 0.0;
-  for (int t = s; t < tiles; t += kBnSlots) acc += (double)partial[(long long)t * two_c + e];
-  slots[(long long)s * two_c + e] = acc;
+  if (e < two_c) {
+    const long long step = (long long)n_slots * RL;
+    long long t = s + (long long)n_slots * rl;
+    for (; t + 3 * step < tiles; t += 4 * step) {
+      const float v0 = partial[t * two_c + e], v1 = partial[(t + step) * two_c + e];
+      const float v2 = partial[(t + 2 * step) * two_c + e], v3 = partial[(t + 3 * step) * two_c + e];
+      acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+    }
+    for (; t < tiles; t += step) acc += (double)partial[t * two_c + e];
+  }
+  if constexpr (RL > 1) {
+    s_acc[rl][cl] = acc;
+    __syncthreads();
+    if (rl != 0) return;
+#pragma unroll
+    for (int l = 1; l < RL; ++l) acc += s_acc[l][cl];
+  }
+  if (e < two_c) slots[(long long)s * two_c + e] = acc;
+}
+
+inline void launch_bn_reduce(const float* partial, double* slots, int tiles, int two_c, int n_slots, hipStream_t stream) {
+  if (two_c <= 64)
+    hipLaunchKernelGGL(bn_reduce_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
+  else if (two_c <= 128)
+    hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
@@ -37,6 +67,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ slots, int n_slots
   double mean, var;
   if (training) {
     double s = 0.0, q = 0.0;
+#pragma unroll 8
     for (int k = 0; k < n_slots; ++k) {
       s += slots[((long long)k * channels + c) * 2 + 0];
       q += slots[((long long)k * channels + c) * 2 + 1];
@@ -212,8 +243,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
     if (!bn_partial || !workspace || row_tiles < 1 || count < 1) return FSD_ERR_ARG;
     n_slots = row_tiles < kBnSlots ? row_tiles : kBnSlots;
     const int two_c = 2 * channels;
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, bn_partial,
-                       reinterpret_cast<double*>(workspace), row_tiles, two_c);
+    launch_bn_reduce(bn_partial, reinterpret_cast<double*>(workspace), row_tiles, two_c, n_slots, stream);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, gamma, beta,

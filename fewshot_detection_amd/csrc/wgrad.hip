@@ -245,7 +245,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   float v = 0.f;
   if (col < ncols) {
     const float* src = ws + (long long)co * ncols + col;
-    for (int k = ty; k < splits; k += SY) v += src[k * slice];
+    int k = ty;
+    for (; k + 3 * SY < splits; k += 4 * SY) {
+      const float v0 = src[k * slice], v1 = src[(k + SY) * slice], v2 = src[(k + 2 * SY) * slice], v3 = src[(k + 3 * SY) * slice];
+      v += v0; v += v1; v += v2; v += v3;
+    }
+    for (; k < splits; k += SY) v += src[k * slice];
   }
   if constexpr (SY > 1) {
     s_part[ty][tx] = v;
@@ -271,10 +276,32 @@ inline int pick_splits(long long pixels, int tiles) {
   return s;
 }
 
-inline int tile_of(int bf16) {
+// fp32 tile variants: 0 = 64x64 single stage (17 KB LDS, 8 WGs/CU), 1 = 128x128 two stages, 2 = 128x128 single stage
+inline int f32_variant() {
   static const char* env = getenv("FSD_WGRAD_TILE");     // tuning aid
-  if (env && !bf16) return atoi(env) == 128 ? 128 : 64;
-  return bf16 ? 128 : 64;
+  if (!env) return 0;
+  const int v = atoi(env);
+  return v == 128 ? 1 : v == 1281 ? 2 : 0;
+}
+inline int tile_of(int bf16) { return (bf16 || f32_variant() != 0) ? 128 : 64; }
+
+int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
+  if (bf16) {
+    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
+    hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
+  } else if (f32_variant() == 1) {
+    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((wgrad_kernel<128, 2, false>), grid, dim3(kThreads), lds, stream, a);
+  } else if (f32_variant() == 2) {
+    const size_t lds = 1 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_kernel<128, 1, false>), grid, dim3(kThreads), lds, stream, a);
+  } else {
+    const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
+  }
+  return 0;
 }
 
 int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw, void* workspace,
@@ -301,18 +328,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
   a.dy_bs = a.x_bs = a.ws_bs = 0;
   const dim3 grid(a.m_tiles * a.n_tiles, splits);
-  if (bf16) {
-    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
-    hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
-  } else if (tile == 128) {
-    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((wgrad_kernel<128, 2, false>), grid, dim3(kThreads), lds, stream, a);
-  } else {
-    const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
-  }
+  if (int rc = launch_wgrad(a, bf16, grid, stream)) return rc;
   if (splits <= 8)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
@@ -336,19 +352,20 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
   a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;
   a.Cout = cout; a.cin4 = cin; a.ks = 1; a.pad = 0;
   a.ncols = cin;
-  a.m_tiles = (cout + 63) / 64;
-  a.n_tiles = (cin + 63) / 64;
+  const int tile = tile_of(0);
+  a.m_tiles = (cout + tile - 1) / tile;
+  a.n_tiles = (cin + tile - 1) / tile;
   const int splits = wgrad_batched_splits(rows, cin, cout, batches);
   a.pix_per_split = round_up((int)((rows + splits - 1) / splits), kBK);
   a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)splits * cout * cin;
-  const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
-  hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), dim3(a.m_tiles * a.n_tiles, splits, batches), dim3(kThreads), lds, stream, a);
+  if (int rc = launch_wgrad(a, 0, dim3(a.m_tiles * a.n_tiles, splits, batches), stream)) return rc;
   *splits_out = splits;
   return (int)hipGetLastError();
 }
 
 int fsd_conv::wgrad_batched_splits(long long rows, int cin, int cout, int batches) {
-  const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64) * batches;
+  const int tile = tile_of(0);
+  const int tiles = ((cout + tile - 1) / tile) * ((cin + tile - 1) / tile) * batches;
   return pick_splits(rows, tiles);
 }
 

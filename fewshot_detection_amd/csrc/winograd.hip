@@ -218,18 +218,31 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
-// ws[p][split][co][ci] -> dw[co][ci][3][3] = A3^T m A3,  A3^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
-__global__ void wino_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int cout, int cin) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over (co, ci), ci fastest
+// ws[p][split][co][ci] -> dw[co][ci][3][3] = A3^T m A3,  A3^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1].
+// Block = 16 outputs x 16 positions: every thread folds the splits of one position (fixed order), then the
+// first 16 threads apply the transform.
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                     int cout, int cin) {
+  __shared__ float s_m[16][17];
+  const int il = threadIdx.x & 15, pp = threadIdx.x >> 4;
   const long long n = (long long)cout * cin;
-  if (idx >= n) return;
+  const long long idx = (long long)blockIdx.x * 16 + il;      // over (co, ci), ci fastest
+  float v = 0.f;
+  if (idx < n) {
+    const float* src = ws + (long long)pp * splits * n + idx;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      const float v0 = src[k * n], v1 = src[(k + 1) * n], v2 = src[(k + 2) * n], v3 = src[(k + 3) * n];
+      v += v0; v += v1; v += v2; v += v3;
+    }
+    for (; k < splits; ++k) v += src[k * n];
+  }
+  s_m[pp][il] = v;
+  __syncthreads();
+  if (threadIdx.x >= 16 || idx >= n) return;
   float m[4][4];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    float v = 0.f;
-    for (int k = 0; k < splits; ++k) v += ws[((long long)p * splits + k) * n + idx];
-    m[p >> 2][p & 3] = v;
-  }
+  for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = s_m[p][il];
   float s[3][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -325,6 +338,6 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   int rc = fsd_conv::wgrad_gemm_batched(Wt, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, 16, &splits, stream);
   if (rc != 0) return rc;
   const long long n = (long long)cout * cin;
-  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }
