@@ -42,7 +42,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   BF16 = true : operands rounded to bf16 (RNE) on the LDS store, 32x32x16 MFMA with fp32 accumulation
 //                 (BASELINE C3/C5); fragments need 8 consecutive PIXELS per lane, which are LDS rows here, so
 //                 they are gathered with 16-bit LDS reads (pairs land in the two halves of one VGPR).
-template <int TILE, int STAGES, bool BF16>
+template <int TILE, int STAGES, bool BF16, bool PLAIN = false>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   typedef typename std::conditional<BF16, unsigned short, float>::type lds_t;
   constexpr int LDT = TILE + (BF16 ? 8 : 4);       // LDS row stride in elements (keeps 16-byte alignment)
@@ -53,16 +53,20 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   constexpr int STAGE = 2 * kBK * LDT;             // A tile + B tile, in elements
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   lds_t* smem = reinterpret_cast<lds_t*>(smem_raw);
+  // XCD-aware order: all tiles of one (split, batch) -- which read the same pixel rows -- land on one XCD / L2
+  const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int logical = fsd_conv::xcd_swizzle(flat, gridDim.x * gridDim.y * gridDim.z);
+  const int tile = logical % gridDim.x;
+  const int rest = logical / gridDim.x;
+  const int split = rest % gridDim.y;
+  const int zb = rest / gridDim.y;
   if (gridDim.z > 1) {
-    p.dy += (long long)blockIdx.z * p.dy_bs;
-    p.x += (long long)blockIdx.z * p.x_bs;
-    p.ws += (long long)blockIdx.z * p.ws_bs;
+    p.dy += (long long)zb * p.dy_bs;
+    p.x += (long long)zb * p.x_bs;
+    p.ws += (long long)zb * p.ws_bs;
   }
-
-  const int tile = blockIdx.x;
   const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
   const int m0 = mt * TILE, n0 = nt * TILE;
-  const int split = blockIdx.y;
   const int p_begin = split * p.pix_per_split;
   const int p_end = min(p.M, p_begin + p.pix_per_split);
   const int nk = (p_end - p_begin + kBK - 1) / kBK;
@@ -80,6 +84,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   const int dyy = ky - p.pad, dxx = kx - p.pad;
   const int shift = dyy * p.W + dxx;
 
+  // image coordinates of this thread's pixels, advanced by kBK pixels per chunk (no divisions in the loop)
+  int yy_[PASSES], xx_[PASSES];
+  const int step_y = kBK / p.W, step_x = kBK - step_y * p.W;
+  if constexpr (!PLAIN) {
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const int pix0 = p_begin + kr + RPP * j;
+      const int rem = pix0 % p.HW;
+      yy_[j] = rem / p.W;
+      xx_[j] = rem - yy_[j] * p.W;
+    }
+  }
   f32x4 ra[PASSES], rb[PASSES];
   unsigned okmask = 0;
   auto gload = [&](int kc) {
@@ -90,10 +106,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       const bool pv = pix < p_end;
       const bool aok = pv && a_ok;
       ra[j] = *reinterpret_cast<const f32x4*>(p.dy + (aok ? (long long)pix * p.dy_ld + a_col : 0));
-      const int b = pix / p.HW;
-      const int rem = pix - b * p.HW;
-      const int yy = rem / p.W, xx = rem - yy * p.W;
-      const bool bok = pv && b_colok && (unsigned)(yy + dyy) < (unsigned)p.H && (unsigned)(xx + dxx) < (unsigned)p.W;
+      bool bok;
+      if constexpr (PLAIN) {       // 1x1 taps: a plain GEMM over rows, no image geometry
+        bok = pv && b_colok;
+      } else {
+        const int yy = yy_[j], xx = xx_[j];
+        bok = pv && b_colok && (unsigned)(yy + dyy) < (unsigned)p.H && (unsigned)(xx + dxx) < (unsigned)p.W;
+        xx_[j] = xx + step_x;
+        yy_[j] = yy + step_y;
+        while (xx_[j] >= p.W) { xx_[j] -= p.W; ++yy_[j]; }
+        while (yy_[j] >= p.H) yy_[j] -= p.H;
+      }
       rb[j] = *reinterpret_cast<const f32x4*>(p.x + (bok ? (long long)(pix + shift) * p.x_ld + ci : 0));
       okmask |= (aok ? 1u : 0u) << j;
       okmask |= (bok ? 256u : 0u) << j;
@@ -281,9 +304,9 @@ inline int f32_variant() {
   static const char* env = getenv("FSD_WGRAD_TILE");     // tuning aid
   if (!env) return 0;
   const int v = atoi(env);
-  return v == 128 ? 1 : v == 1281 ? 2 : 0;
+  return v == 128 ? 1 : v == 1281 ? 2 : v == 642 ? 3 : v == 640 ? 4 : 0;     // 642: 64x64 two stages, 640: no 1x1 specialisation
 }
-inline int tile_of(int bf16) { return (bf16 || f32_variant() != 0) ? 128 : 64; }
+inline int tile_of(int bf16) { return (bf16 || f32_variant() == 1 || f32_variant() == 2) ? 128 : 64; }
 
 int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
   if (bf16) {
@@ -297,9 +320,14 @@ int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
   } else if (f32_variant() == 2) {
     const size_t lds = 1 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
     hipLaunchKernelGGL((wgrad_kernel<128, 1, false>), grid, dim3(kThreads), lds, stream, a);
+  } else if (f32_variant() == 3) {
+    const size_t lds = 2 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+    if (a.ks == 1) hipLaunchKernelGGL((wgrad_kernel<64, 2, false, true>), grid, dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 2, false>), grid, dim3(kThreads), lds, stream, a);
   } else {
     const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
+    if (a.ks == 1 && f32_variant() != 4) hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true>), grid, dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
   }
   return 0;
 }

@@ -1,0 +1,55 @@
+"""Per-layer timing of the conv kernels on the shapes of the C2 episode (B=64, 416x416).
+
+    python tools/layer_bench.py [fwd|wgrad|all]
+
+Prints ms and direct-convolution-equivalent TFLOP/s per shape; used for kernel tuning (env knobs
+FSD_CONV_TILE / FSD_WGRAD_TILE select kernel variants)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from fewshot_detection_amd import ops  # noqa: E402
+
+SHAPES = [  # B, H, W, cin, cout, k
+    (64, 208, 208, 32, 64, 3), (64, 104, 104, 64, 128, 3), (64, 104, 104, 128, 64, 1), (64, 52, 52, 128, 256, 3),
+    (64, 26, 26, 256, 512, 3), (64, 13, 13, 512, 1024, 3), (64, 13, 13, 1024, 1024, 3), (64, 13, 13, 1280, 1024, 3),
+]
+
+
+def timed(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    dev = torch.device("cuda:0")
+    for B, H, W, cin, cout, k in SHAPES:
+        x = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, device=dev))
+        dy = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, device=dev))
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        flops = 2.0 * k * k * cin * cout * B * H * W
+        line = "%3dx%3d %4d->%4d k%d:" % (H, W, cin, cout, k)
+        if what in ("fwd", "all"):
+            if ops.wino_eligible(cin, cout, k):
+                wp = ops.pack_weight_wino(w)
+                ms = timed(lambda: ops.conv3x3_wino(x, wp, cout))
+            else:
+                wp = ops.pack_weight(w)
+                ms = timed(lambda: ops.conv2d(x, wp, cout, k))
+            line += "  fwd %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
+        if what in ("wgrad", "all"):
+            ms = timed(lambda: ops.conv2d_wgrad(dy, cout, x, cin, k))
+            line += "  wgrad %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
