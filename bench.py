@@ -16,6 +16,7 @@ like the reference's per-GPU MetaDataset draw) -> weak scaling; in train mode gr
 all-reduced over RCCL.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import random
@@ -116,6 +117,49 @@ def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
                          sample_flops / 1e9, full_flops / 1e9)}
 
 
+def extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, det_flops_img, rw224_flops_img):
+    """Two more timings of the same model on the same device (N=1 only, ~1 s): the forward pass alone (the
+    north_star's ">= 0.6x MFMA roofline on the forward" target) and the episode shape quoted in BASELINE.json's
+    metric string (20 supports of 224x224 instead of configs[1]'s 15 classes at the cfg's 416x416)."""
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+
+    def timed(fn, n=5, w=2):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    def fwd():
+        with torch.no_grad():
+            region(net(x, metax, mask), target)
+
+    out = {}
+    t = timed(fwd)
+    out["forward_only"] = {"what": "forward (train-mode BN) + RegionLoss forward/grad kernel, no backward, same episode",
+                           "ms": t * 1e3, "episodes_per_s": 1.0 / t, "algorithmic_tflops": full_flops / t / 1e12,
+                           "frac_of_mfma_peak": full_flops / t / 1e12 / peak}
+    if args.mode == "train" and opt is not None:
+        x2, metax2, mask2, target2 = synth_episode(2000, args.batch, 20, args.size, 224)
+        metax2, mask2 = metax2.to(dev), mask2.to(dev)
+
+        def train20():
+            region.seen += args.batch
+            opt.backward_and_step(region(net(x, metax2, mask2), target2))
+
+        t = timed(train20)
+        g = args.size // 32
+        fl = args.batch * det_flops_img + 20 * rw224_flops_img + 2.0 * 1024 * 30 * (20 - 1) * args.batch * g * g
+        out["metric_string_episode"] = {"what": "train step on B=%d queries %dx%d + 20 supports 224x224 (the shape in "
+                                                "BASELINE.json's metric string)" % (args.batch, args.size, args.size),
+                                        "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t,
+                                        "img_per_s": args.batch / t, "episode_forward_gflop": fl / 1e9}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/r01_conv_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE
@@ -142,6 +186,7 @@ def main():
                     help="conv compute mode: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, fp32 "
                          "accumulate, fp32 BN/loss/master weights and fp32 weight gradients (BASELINE C3/C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / metric-string-episode timings")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
     args = ap.parse_args()
 
@@ -175,7 +220,8 @@ def main():
     dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(tmp)
     torch.manual_seed(0)
     random.seed(0)
-    net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(args.dtype)
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints like the reference; stdout carries ONE JSON line
+        net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(args.dtype)
     region = net.models[len(net.models) - 1]
     region.verbose = False
     x, metax, mask, target = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
@@ -221,8 +267,9 @@ def main():
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:
-        conv_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
-        conv_flops = sum(f for _, _, f in prof)
+        conv_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
+        conv_flops = sum(e[2] for e in prof)
+        exec_flops = sum(e[3] for e in prof)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         if args.per_layer:
             per = len(prof) // max(1, args.steps)
@@ -256,17 +303,24 @@ def main():
                                    "run as wino_input_kernel + conv_gemm_kernel (16 batched GEMMs) + wino_output_kernel"
                          if args.dtype == "f32" else "conv_gemm_bf16_kernel (bf16 implicit-GEMM conv, all launches)",
                          "note": "achieved = ALGORITHMIC direct-convolution FLOPs (2*k*k*Cin*Cout*pixels) / HIP-event time of "
-                                 "the conv launches; Winograd executes 2.25x fewer MFMA FLOPs than that on its layers. "
+                                 "the conv launches (Winograd transforms included in that time); Winograd executes 2.25x fewer multiplications "
+                                 "on its layers, so executed_mfma_tflops / executed_frac report the MFMA work really issued. "
                                  "rocprof check: conv_ms_per_step == per-step sum of the kernels named in `kernel`",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s",
                          "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
                          "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 and args.dtype == "f32" else None,
+                         "executed_mfma_tflops": exec_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                         "executed_frac": (exec_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0)
+                         / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
                          "flop_per_launch": conv_flops / max(1, len(prof)),
                          "avg_launch_ms": conv_ms / max(1, len(prof)),
                          "launches_per_step": len(prof) // max(1, args.steps),
                          "conv_ms_per_step": conv_ms / max(1, args.steps)},
         }
+        if world == 1 and not args.no_extras:
+            res["also_measured"] = extras(net, region, opt, args, dev, x, metax, mask, target, full_flops,
+                                          conv_flops_per_image(blocks, args.size), conv_flops_per_image(lblocks, 224))
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(dyn_cfg, rw_cfg, args, full_flops)
         print(json.dumps(res))

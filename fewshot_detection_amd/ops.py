@@ -129,7 +129,8 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False):
           "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels))
+        tiles = xv.B * ((xv.H + 1) // 2) * ((xv.W + 1) // 2)
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * 16 * xv.C * cout * tiles))
     return y, partial
 
 
@@ -140,7 +141,7 @@ def wino_eligible(cin, cout, ksize):
 
 
 WINOGRAD = True     # Winograd F(2x2,3x3) for eligible fp32 3x3 layers (forward + data gradient)
-PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops) per conv launch
+PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops, executed_mfma_flops) per conv launch
 
 
 def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None):
@@ -167,7 +168,8 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
           "fsd_conv2d_fwd_bf16" if bf16 else "fsd_conv2d_fwd")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels))
+        PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
+                        2.0 * ksize * ksize * xv.C * cout * xv.pixels))
     return y, partial
 
 
