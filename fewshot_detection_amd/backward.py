@@ -4,7 +4,8 @@ w.r.t. its parameters and its reweighting vectors, entirely on the HIP kernels.
 Per fused conv block (reverse of engine.Network._conv):
     dz (+ dz_full) --fsd_bn_act_pool_bwd--> dt, partial sums     (maxpool argmax recomputed from y)
     partial sums   --fsd_bn_bwd_finalize--> dgamma, dbeta, coefficients
-    dt             --fsd_bn_bwd_apply-----> dy                  (in place)
+    dt             --fsd_bn_bwd_apply-----> dy                  (in place; first layer: fused into its weight gradient,
+                                                                 fsd_conv3x3_wgrad_c4_bnfused)
     dy, x          --fsd_conv2d_wgrad-----> dW                  (split-K MFMA GEMM over pixels)
     dy, W flipped  --fsd_conv2d_fwd-------> dx                  (same implicit-GEMM kernel as the forward)
 """
@@ -49,6 +50,11 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
             pgrads[id(bn.weight)] = s2
             if not rec["training"]:          # frozen statistics: dy = scale * dt
                 coef[1:].zero_()
+            if xv is first_input and net.compute_dtype == "f32" and ops.c4_bnfused_eligible(xv, cout, k):
+                # first layer: no data gradient is needed, so dy is formed inside the weight-gradient kernel
+                pgrads[id(conv.weight)] = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv,
+                                                                       cin, cout)
+                return
             ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
         elif conv.bias is not None:
             pgrads[id(conv.bias)] = s1

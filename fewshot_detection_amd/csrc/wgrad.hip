@@ -288,6 +288,141 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// ---- first layer: 3x3 weight gradient of a <=4-channel input, BatchNorm backward fused into the operand load ----
+// dW[co][ci][ky][kx] = sum_pix dy[pix][co] * x[pix + (ky-1, kx-1)][ci],   dy = c1*(dt - c2 - xhat*c3)  (bn_bwd_apply).
+// The first layer needs no data gradient, so dy is formed in registers and never written (saves a 3-pass
+// elementwise kernel over the largest activation of the network).  HBM-bound: dt and y are read once.
+// No LDS staging: every lane loads its own MFMA operands (32x32x2: lane = (column, k) with k = one of 2 pixels):
+//   A[co][k]      = dy[pix + k][co]                   co = lane & 31          (128-B coalesced rows of dt / y)
+//   B[k][(tap,ci)] = x[pix + k + shift(tap)][ci]      taps 0..7 = 32 columns  (L1/L2-resident 16-B pixels)
+// and the ninth tap (4 columns) is a 4-FMA side sum per lane.  One wave owns a contiguous run of pixels.
+struct FirstArgs {
+  const float* dt; const float* y; const float* coef; const float* mean; const float* invstd; const float* x;
+  float* ws;                        // [blocks][Cout][36]
+  unsigned dt_ld, y_ld, x_ld;
+  int H, W, Cout;
+  long long pixels;
+  int ppw;                          // pixels per wave (multiple of 16)
+};
+
+// SIDE = false: 3 input channels, the 27 (tap, ci) columns fit one 32-wide MFMA tile.
+// SIDE = true : 4 input channels, taps 0..7 in the tile and the ninth tap as a 4-FMA side sum per lane.
+template <bool SIDE>
+__global__ __launch_bounds__(256) void wgrad_first_kernel(FirstArgs p) {
+  __shared__ float s_out[4][32 * 36];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int co = blockIdx.y * 32 + c;
+  const float c1 = p.coef[co], c2 = p.coef[p.Cout + co], c3 = p.coef[2 * p.Cout + co];
+  const float mu = p.mean[co], is = p.invstd[co];
+  const int tap = SIDE ? c >> 2 : c / 3, ci = SIDE ? c & 3 : c - 3 * (c / 3);
+  const bool col_ok = SIDE || c < 27;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  const int dyo = ky - 1, dxo = kx - 1;
+  const long long p_begin = ((long long)blockIdx.x * 4 + wave) * p.ppw;
+  const long long p_end = p_begin + p.ppw < p.pixels ? p_begin + p.ppw : p.pixels;
+  const int len = (int)(p_end - p_begin);                    // pixels of this wave (<= ppw)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float acc8[4] = {0.f, 0.f, 0.f, 0.f};
+  if (len > 0) {
+    // image coordinates of this lane's first pixel; afterwards +2 pixels per k-step
+    const long long pix0 = p_begin + h;
+    const int rem = (int)(pix0 % ((long long)p.H * p.W));
+    int yy = rem / p.W, xx = rem - yy * p.W;
+    // 32-bit BYTE offsets from the (uniform) base pointers; the launcher guarantees they fit
+    const char* dt_b = reinterpret_cast<const char*>(p.dt);
+    const char* y_b = reinterpret_cast<const char*>(p.y);
+    const char* x_b = reinterpret_cast<const char*>(p.x);
+    unsigned off_dt = ((unsigned)pix0 * p.dt_ld + co) * 4u, off_y = ((unsigned)pix0 * p.y_ld + co) * 4u;
+    unsigned off_x = (unsigned)pix0 * p.x_ld * 4u;
+    const unsigned safe_dt = ((unsigned)p_begin * p.dt_ld + co) * 4u, safe_y = ((unsigned)p_begin * p.y_ld + co) * 4u;
+    const unsigned step_dt = 8u * p.dt_ld, step_y = 8u * p.y_ld, step_x = 8u * p.x_ld;      // two pixels, in bytes
+    const int kb = ((dyo * p.W + dxo) * (int)p.x_ld + ci) * 4, k8 = (p.W + 1) * (int)p.x_ld * 4;
+    int rel = h;                                             // pixel index of this lane within the wave's run
+    // Operands of 4 k-steps (8 pixels).  Loads are unconditional from clamped (always mapped) offsets and the
+    // zero-selects happen at use, so all loads of a group are in flight together, one group ahead of the MFMAs.
+    struct Group { float dtv[4], yv[4], bv[4]; f32x4 x8[SIDE ? 4 : 1]; unsigned mask; };
+    auto load = [&](Group& g) {
+      g.mask = 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool valid = rel < len;
+        g.dtv[s] = *reinterpret_cast<const float*>(dt_b + (valid ? off_dt : safe_dt));
+        g.yv[s] = *reinterpret_cast<const float*>(y_b + (valid ? off_y : safe_y));
+        const bool okb = valid && col_ok && (unsigned)(yy + dyo) < (unsigned)p.H && (unsigned)(xx + dxo) < (unsigned)p.W;
+        g.bv[s] = *reinterpret_cast<const float*>(x_b + (okb ? off_x + (unsigned)kb : 0u));
+        g.mask |= (valid ? 1u : 0u) << s;
+        g.mask |= (okb ? 16u : 0u) << s;
+        if constexpr (SIDE) {
+          const bool ok8 = valid && yy + 1 < p.H && xx + 1 < p.W;
+          g.x8[s] = *reinterpret_cast<const f32x4*>(x_b + (ok8 ? off_x + (unsigned)k8 : 0u));
+          g.mask |= (ok8 ? 256u : 0u) << s;
+        }
+        rel += 2; off_dt += step_dt; off_y += step_y; off_x += step_x;
+        xx += 2;                              // W >= 2 (checked by the launcher): at most one wrap
+        if (xx >= p.W) { xx -= p.W; if (++yy >= p.H) yy = 0; }
+      }
+    };
+    auto compute = [&](const Group& g) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = c1 * (g.dtv[s] - c2 - (g.yv[s] - mu) * is * c3);
+        const float a = ((g.mask >> s) & 1u) ? av : 0.f;
+        const float b = ((g.mask >> (4 + s)) & 1u) ? g.bv[s] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        if constexpr (SIDE) {
+          const float a8 = ((g.mask >> (8 + s)) & 1u) ? a : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc8[j] += a8 * g.x8[s][j];
+        }
+      }
+    };
+    Group g0, g1;
+    load(g0);
+    for (int done = 0; done < len; done += 16) {
+      load(g1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(g0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(g0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(g1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // fold the two pixel-halves of the side sum, then the 4 waves through LDS
+  float* so = s_out[wave];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;        // output channel within the 32-tile
+    if (col_ok) so[row * 36 + tap * 4 + ci] = acc[r];
+  }
+  if constexpr (SIDE) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc8[j] += __shfl_xor(acc8[j], 32, 64);
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) so[c * 36 + 32 + j] = acc8[j];
+    }
+  } else {
+    if (c < 9) {                                             // unused ci = 3 columns: keep them defined
+#pragma unroll
+      for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + c * 4 + 3] = 0.f;
+    }
+  }
+  __syncthreads();
+  float* out = p.ws + ((size_t)blockIdx.x * p.Cout + (size_t)blockIdx.y * 32) * 36;
+  for (int e = threadIdx.x; e < 32 * 36; e += 256) out[e] = s_out[0][e] + s_out[1][e] + s_out[2][e] + s_out[3][e];
+}
+
+inline int first_blocks(long long pixels) {
+  long long b = (pixels + 4 * 256 - 1) / (4 * 256);        // at least 256 pixels per wave
+  return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 inline int pick_splits(long long pixels, int tiles) {
@@ -395,6 +530,39 @@ int fsd_conv::wgrad_batched_splits(long long rows, int cin, int cout, int batche
   const int tile = tile_of(0);
   const int tiles = ((cout + tile - 1) / tile) * ((cin + tile - 1) / tile) * batches;
   return pick_splits(rows, tiles);
+}
+
+extern "C" size_t fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(int batch, int height, int width, int cout) {
+  return (size_t)first_blocks((long long)batch * height * width) * cout * 36 * sizeof(float);
+}
+
+extern "C" int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* y, long long y_ld,
+                                            const float* coef, const float* mean, const float* invstd, const float* x,
+                                            long long x_ld, float* dw_oihw, void* workspace, size_t workspace_bytes,
+                                            int batch, int height, int width, int cin, int cout, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dt || !y || !coef || !mean || !invstd || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1)
+    return FSD_ERR_ARG;
+  if (cin < 1 || cin > 4 || cout % 32 || width < 2 || x_ld < 4 || (x_ld & 3) || dt_ld < cout || y_ld < cout) return FSD_ERR_UNSUPPORTED;
+  const long long pixels = (long long)batch * height * width;
+  if ((pixels + width + 18) * (dt_ld > y_ld ? (dt_ld > x_ld ? dt_ld : x_ld) : (y_ld > x_ld ? y_ld : x_ld)) * 4 >= 0xffffffffLL)
+    return FSD_ERR_UNSUPPORTED;                              // 32-bit byte offsets in the kernel
+  if ((reinterpret_cast<uintptr_t>(x) & 15)) return FSD_ERR_ARG;
+  const int blocks = first_blocks(pixels);
+  if (workspace_bytes < (size_t)blocks * cout * 36 * sizeof(float)) return FSD_ERR_WORKSPACE;
+  FirstArgs a;
+  a.dt = dt; a.y = y; a.coef = coef; a.mean = mean; a.invstd = invstd; a.x = x;
+  a.ws = reinterpret_cast<float*>(workspace);
+  a.dt_ld = (unsigned)dt_ld; a.y_ld = (unsigned)y_ld; a.x_ld = (unsigned)x_ld;
+  a.H = height; a.W = width; a.Cout = cout; a.pixels = pixels;
+  a.ppw = round_up((int)((pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 16);
+  if (cin == 4) hipLaunchKernelGGL(wgrad_first_kernel<true>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad_first_kernel<false>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  if (blocks <= 8)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(1, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(2, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
+  return (int)hipGetLastError();
 }
 
 extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {

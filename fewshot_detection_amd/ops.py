@@ -269,6 +269,24 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32"):
     return dw
 
 
+def c4_bnfused_eligible(xv, cout, ksize):
+    """First-layer shape: NHWC4 input, 3x3, cout a multiple of 32 (darknet L0, reweighting-net L0)."""
+    return ksize == 3 and xv.C == 4 and xv.ld == 4 and cout % 32 == 0 and xv.W >= 2
+
+
+def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout):
+    """dW of a first layer straight from dt (gradient w.r.t. the BN output): BN backward fused, dy never stored."""
+    L = lib()
+    dev = xv.t.device
+    ws_bytes = L.fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(xv.B, xv.H, xv.W, cout)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    check(L.fsd_conv3x3_wgrad_c4_bnfused(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(),
+                                         invstd.data_ptr(), xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes,
+                                         xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_wgrad_c4_bnfused")
+    return dw
+
+
 def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     """-> (dt View dense (pixels, C), partial [rows][C][2])."""
     L = lib()

@@ -117,6 +117,16 @@ int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, 
                          long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
                          int height, int width, int cin, int cout, hipStream_t stream);
 
+/* First-layer 3x3 weight gradient (input with <= 4 channels stored as NHWC4, cout % 32 == 0) with the BatchNorm
+ * backward fused into the operand load: dy = c1*(dt - c2 - xhat*c3) is formed in registers from dt (gradient w.r.t.
+ * the BN output, fsd_bn_act_pool_bwd) and the raw conv output y, coef = [3][cout] from fsd_bn_bwd_finalize.  Replaces
+ * fsd_bn_bwd_apply + fsd_conv2d_wgrad for a layer whose input needs no gradient. */
+size_t fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(int batch, int height, int width, int cout);
+int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
+                                 const float* mean, const float* invstd, const float* x, long long x_ld, float* dw_oihw,
+                                 void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                 int cout, hipStream_t stream);
+
 /* Winograd F(3x3,2x2) form of the fp32 weight gradient of a 3x3 convolution: dW = sum over 2x2 tiles,
  * 16 batched reduction GEMMs over tiles instead of 9 taps x pixels (2.25x fewer multiplications). */
 size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout);

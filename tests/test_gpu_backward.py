@@ -36,6 +36,31 @@ def test_wgrad_matches_fp64_autograd(dev, B, H, W, cin, cout, k):
     assert torch.allclose(dw, ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max())), float((dw - ref).abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 13, 13, 3, 32), (3, 7, 2, 4, 64), (5, 64, 48, 3, 32), (1, 1, 2, 3, 32)])
+def test_first_layer_fused_wgrad_matches_unfused_path(dev, B, H, W, cin, cout):
+    """fsd_conv3x3_wgrad_c4_bnfused == fsd_bn_bwd_apply + fsd_conv2d_wgrad (and fp64 autograd of dy (*) x)."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.zeros(B, 4, H, W)
+    x[:, :cin] = torch.randn(B, cin, H, W, generator=g)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    yv = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev))
+    dt = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev))
+    coef = (torch.rand(3, cout, generator=g) + 0.5).to(dev)
+    mean, invstd = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev)
+    assert ops.c4_bnfused_eligible(xv, cout, 3)
+    dw = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout)
+    dy = ops.View(dt.t.clone(), B, H, W, cout)
+    ops.bn_bwd_apply(dy, yv, coef, mean, invstd)
+    ref = ops.conv2d_wgrad(dy, cout, xv, cin, 3)
+    assert dw.shape == ref.shape == (cout, cin, 3, 3)
+    assert torch.allclose(dw, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), float((dw - ref).abs().max())
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy64 = dy.t.view(B, H, W, cout).permute(0, 3, 1, 2).double().cpu()
+    F.conv2d(x[:, :cin].double(), w, None, 1, 1).backward(dy64)
+    assert torch.allclose(dw.cpu(), w.grad.float(), rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()))
+
+
 def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(5)
