@@ -59,7 +59,9 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         elif conv.bias is not None:
             pgrads[id(conv.bias)] = s1
         dy = dt
-    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype)
+    kept = rec.get("wino_v")
+    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype,
+                                               wino_v=kept[0] if kept else None)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         if net.compute_dtype == "f32" and ops.wino_eligible(dyv.C, xv.C, k):

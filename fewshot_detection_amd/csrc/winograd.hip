@@ -287,17 +287,22 @@ extern "C" int fsd_wino_partial_rows(int batch, int height, int width) {
   return (int)((tiles_of(batch, height, width) + kTilesPerBlock - 1) / kTilesPerBlock);
 }
 
+extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin) {
+  return (size_t)16 * tiles_of(batch, height, width) * cin;
+}
+
 extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
-                                    long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
-                                    int height, int width, int cin, int cout, hipStream_t stream) {
+                                    long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
+                                    float* v_keep, int batch, int height, int width, int cin, int cout,
+                                    hipStream_t stream) {
   (void)hipGetLastError();
   if (!x || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
   if (cin % 32 || (cout & 3) || (x_ld & 3) || (y_ld & 3) || x_ld < cin || y_ld < cout) return FSD_ERR_UNSUPPORTED;
   if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
   const int TH = (height + 1) / 2, TW = (width + 1) / 2;
   const long long T = tiles_of(batch, height, width);
-  float* V = reinterpret_cast<float*>(workspace);
-  float* Mb = V + (size_t)16 * T * cin;
+  float* V = v_keep ? v_keep : reinterpret_cast<float*>(workspace);     // kept for the weight gradient if asked
+  float* Mb = reinterpret_cast<float*>(workspace) + (size_t)16 * T * cin;
   const long long n_in = T * (cin / 4);
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
                      width, TH, TW, cin, T);
@@ -317,21 +322,26 @@ extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int widt
   return ((size_t)16 * T * (size_t)(cin + cout) + (size_t)16 * splits * cout * cin) * sizeof(float);
 }
 
-extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
-                                      void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
-                                      int cout, hipStream_t stream) {
+extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld,
+                                      const float* v_kept, float* dw_oihw, void* workspace, size_t workspace_bytes,
+                                      int batch, int height, int width, int cin, int cout, hipStream_t stream) {
   (void)hipGetLastError();
-  if (!dy || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
-  if ((cin & 3) || (cout & 3) || (x_ld & 3) || (dy_ld & 3) || x_ld < cin || dy_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if (!dy || (!x && !v_kept) || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if ((cin & 3) || (cout & 3) || (dy_ld & 3) || dy_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if (!v_kept && ((x_ld & 3) || x_ld < cin)) return FSD_ERR_UNSUPPORTED;
   if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
   const int TH = (height + 1) / 2, TW = (width + 1) / 2;
   const long long T = tiles_of(batch, height, width);
-  float* V = reinterpret_cast<float*>(workspace);
-  float* Wt = V + (size_t)16 * T * cin;
+  float* Vw = reinterpret_cast<float*>(workspace);
+  float* Wt = Vw + (size_t)16 * T * cin;
   float* ws = Wt + (size_t)16 * T * cout;
   const long long n_in = T * (cin / 4), n_dy = T * (cout / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
-                     width, TH, TW, cin, T);
+  const float* V = v_kept;                                   // the forward pass's B^T d B, if the caller kept it
+  if (!V) {
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw, height,
+                       width, TH, TW, cin, T);
+    V = Vw;
+  }
   hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
                      width, TH, TW, cout, T);
   int splits = 0;

@@ -193,7 +193,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, net, training, n_inputs, has_dyn, *tensors):
         inputs = list(tensors[:n_inputs])
         dyn = [tensors[n_inputs]] if has_dyn else None
-        out, tape = net.forward(inputs, dyn=dyn, training=training)
+        out, tape = net.forward(inputs, dyn=dyn, training=training, record=any(ctx.needs_input_grad))
         ctx.net, ctx.tape, ctx.n_inputs, ctx.has_dyn = net, tape, n_inputs, has_dyn
         ctx.params = tensors[n_inputs + (1 if has_dyn else 0):]
         return out

@@ -126,11 +126,13 @@ class Network(object):
         wp = self.cache.get(conv.weight, 0, "wino" if wino else self.compute_dtype)
         dev = xv.t.device
         cin_true = conv.weight.shape[1]
-        rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool)
+        # Winograd layers keep their transformed input for the weight gradient when a backward pass will follow
+        keep = [] if (wino and self._record) else None
+        rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool, wino_v=keep)
         if bn is None and slope == 1.0 and pool == 0:
             z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
             if wino:
-                ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z)
+                ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z, keep_v=keep)
             else:
                 ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
             rec.update(y=z, z=z, z_full=None)
@@ -138,7 +140,7 @@ class Network(object):
             return z, None
         if wino:
             y, partial = ops.conv3x3_wino(xv, wp, cout, bias=None if bn is not None else conv.bias,
-                                          bn_partial=bn is not None and training)
+                                          bn_partial=bn is not None and training, keep_v=keep)
         else:
             y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
                                     bn_partial=bn is not None and training, cin_true=cin_true)
@@ -158,9 +160,10 @@ class Network(object):
         return z, z_full
 
     # ---- forward ---------------------------------------------------------------------------
-    def forward(self, inputs, dyn=None, training=False, tape=None):
+    def forward(self, inputs, dyn=None, training=False, tape=None, record=False):
         """inputs: list of NCHW tensors concatenated along channels (e.g. [metax, mask]).
         Returns an NCHW tensor (detector: (B*N, A*(5+C), G, G)) or (N, C, 1, 1) after [globalmax]."""
+        self._record = bool(record)          # a backward pass will replay the tape: keep what it can reuse
         if tape is None:
             tape = []
         ops.require_device(*inputs)

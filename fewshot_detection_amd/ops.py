@@ -111,8 +111,9 @@ def pack_weight_wino(w, mode=0):
     return out
 
 
-def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False):
-    """Winograd F(2x2,3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3)."""
+def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None):
+    """Winograd F(2x2,3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3).
+    keep_v: a list; the transformed input is appended to it (kept for the weight gradient)."""
     L = lib()
     dev = xv.t.device
     y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
@@ -124,8 +125,12 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    v = None
+    if keep_v is not None:
+        v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C), dtype=torch.float32, device=dev)
+        keep_v.append(v)
     check(L.fsd_wino_conv3x3_fwd(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                                 ws.data_ptr(), ws_bytes, xv.B, xv.H, xv.W, xv.C, cout, _stream()),
+                                 ws.data_ptr(), ws_bytes, _ptr(v), xv.B, xv.H, xv.W, xv.C, cout, _stream()),
           "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
@@ -249,16 +254,17 @@ def _fold_reweight_head_f32(head_w, head_b, dyn):
 
 # ---- backward ------------------------------------------------------------------------------
 
-def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32"):
-    """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv."""
+def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None):
+    """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv.
+    wino_v: the forward pass's transformed input (conv3x3_wino keep_v), saves its recomputation."""
     L = lib()
     dev = xv.t.device
     if dtype == "f32" and wino_eligible(cin, cout, ksize) and cin == xv.C:
         ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
-        check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B,
-                                       xv.H, xv.W, cin, cout, _stream()), "fsd_wino_conv3x3_wgrad")
+        check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, _ptr(wino_v), dw.data_ptr(), ws.data_ptr(),
+                                       ws_bytes, xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_wino_conv3x3_wgrad")
         return dw
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)

@@ -113,9 +113,12 @@ size_t fsd_wino_packed_weight_elems(int rows, int red);
 int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode, hipStream_t stream);
 size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout);
 int fsd_wino_partial_rows(int batch, int height, int width);
+/* v_keep (nullable): if given, the transformed input B^T d B (fsd_wino_v_elems floats) is written there instead of
+ * into the workspace, so that the weight gradient can reuse it (v_kept of fsd_wino_conv3x3_wgrad). */
+size_t fsd_wino_v_elems(int batch, int height, int width, int cin);
 int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
-                         long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, int batch,
-                         int height, int width, int cin, int cout, hipStream_t stream);
+                         long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
+                         int batch, int height, int width, int cin, int cout, hipStream_t stream);
 
 /* First-layer 3x3 weight gradient (input with <= 4 channels stored as NHWC4, cout % 32 == 0) with the BatchNorm
  * backward fused into the operand load: dy = c1*(dt - c2 - xhat*c3) is formed in registers from dt (gradient w.r.t.
@@ -128,11 +131,12 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
                                  int cout, hipStream_t stream);
 
 /* Winograd F(3x3,2x2) form of the fp32 weight gradient of a 3x3 convolution: dW = sum over 2x2 tiles,
- * 16 batched reduction GEMMs over tiles instead of 9 taps x pixels (2.25x fewer multiplications). */
+ * 16 batched reduction GEMMs over tiles instead of 9 taps x pixels (2.25x fewer multiplications).  v_kept (nullable):
+ * the forward pass's transformed input; when given, x is not read. */
 size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout);
-int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
-                           void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
-                           int cout, hipStream_t stream);
+int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, const float* v_kept,
+                           float* dw_oihw, void* workspace, size_t workspace_bytes, int batch, int height, int width,
+                           int cin, int cout, hipStream_t stream);
 
 /* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
  * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;

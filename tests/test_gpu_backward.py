@@ -72,6 +72,12 @@ def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
     b = ops.conv2d_wgrad(gv, 512, xv, 256, 3)
     assert not torch.equal(a, b)                      # really two different code paths
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    # the transformed input kept by the forward pass gives the same weight gradient bit for bit
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    kept = []
+    ops.conv3x3_wino(xv, ops.pack_weight_wino(torch.randn(512, 256, 3, 3, generator=g).to(dev)), 512, keep_v=kept)
+    c = ops.conv2d_wgrad(gv, 512, xv, 256, 3, wino_v=kept[0])
+    assert torch.equal(a, c)
 
 
 @pytest.mark.parametrize("pool,B,H,W,cin,cout", [(0, 2, 13, 13, 8, 16), (1, 2, 13, 13, 8, 16), (2, 2, 13, 13, 8, 16),
