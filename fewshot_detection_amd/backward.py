@@ -36,7 +36,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
     if direct:
         dy = gz
         if conv.bias is not None:
-            pgrads[id(conv.bias)] = ops.colsum(dy, cout)
+            pgrads[id(conv.bias)] = ops.colsum(dy, cout, param=conv.bias)
     else:
         yv = rec["y"]
         pool = rec["pool"]
@@ -44,7 +44,9 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
             gz, gzf, pool = gzf, None, 0
         dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, rec.get("scale"), rec.get("shift"), rec.get("mean"),
                                           rec.get("invstd"), rec["slope"], pool)
-        s1, s2, coef = ops.reduce_partials(partial, yv.pixels, cout, scale=rec.get("scale"), want_coef=bn is not None)
+        s1, s2, coef = ops.reduce_partials(partial, yv.pixels, cout, scale=rec.get("scale"), want_coef=bn is not None,
+                                           param0=bn.bias if bn is not None else conv.bias,
+                                           param1=bn.weight if bn is not None else None)
         if bn is not None:
             pgrads[id(bn.bias)] = s1
             pgrads[id(bn.weight)] = s2
@@ -53,7 +55,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
             if xv is first_input and net.compute_dtype == "f32" and ops.c4_bnfused_eligible(xv, cout, k):
                 # first layer: no data gradient is needed, so dy is formed inside the weight-gradient kernel
                 pgrads[id(conv.weight)] = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv,
-                                                                       cin, cout)
+                                                                       cin, cout, param=conv.weight)
                 return
             ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
         elif conv.bias is not None:
@@ -61,7 +63,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         dy = dt
     kept = rec.get("wino_v")
     pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype,
-                                               wino_v=kept[0] if kept else None)
+                                               wino_v=kept[0] if kept else None, param=conv.weight)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         if net.compute_dtype == "f32" and ops.wino_eligible(dyv.C, xv.C, k):
@@ -92,7 +94,7 @@ def run(net, tape, grad_out, params):
             dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, net.compute_dtype), x.C, 1)
             _accumulate(grads, x, dx)
             dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1, net.compute_dtype)
-            d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach())
+            d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach(), param=head.weight)
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn
             if head.bias is not None:
@@ -123,4 +125,5 @@ def run(net, tape, grad_out, params):
             pass
         else:
             raise NotImplementedError("backward of tape record %r" % kind)
-    return {"params": [pgrads.get(id(p)) for p in params], "dyn": grad_dyn}
+    # gradients the kernels wrote straight into a trainer's flat buffer are not handed to autograd again
+    return {"params": [None if id(p) in ops.GRAD_SUNK else pgrads.get(id(p)) for p in params], "dyn": grad_dyn}

@@ -390,12 +390,19 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.Kpad = cin;
   a.nk = cin / kBK;
   a.cpt = cin / kBK;
-  a.m_tiles = (int)((rows + 63) / 64);
-  a.n_tiles = (cout + 63) / 64;
+  // 64x64 single-stage tiles win up to K = 512; for the K >= 1024 GEMMs the 128x128 tile with DMA staging
+  // (global_load_lds, two stages) is ~3 % faster (measured, tools/layer_bench.py).  FSD_WINO_TILE = a|c|d overrides.
+  static const char* env = getenv("FSD_WINO_TILE");
+  const char pick = env ? env[0] : (cin >= 1024 && cout % 128 == 0 ? 'd' : 'a');
+  const int big = pick == 'c' || pick == 'd';
+  const int bm = big ? 128 : 64;
+  a.m_tiles = (int)((rows + bm - 1) / bm);
+  a.n_tiles = (cout + bm - 1) / bm;
   a.m_base = 0;
   a.part_base = 0;
   a.batches = batches;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
+  if (big) return pick == 'c' ? launch<128, 128, 2, 2, 2>(a, false, stream) : launch<128, 128, 2, 2, 2, true>(a, false, stream);
   return launch<64, 64, 2, 2, 1>(a, false, stream);
 }
 

@@ -48,6 +48,10 @@ class EpisodeTrainer(object):
         self.grad = torch.zeros_like(self.flat)
         self.mom = torch.zeros_like(self.flat)
         self.buckets = bucket_bounds(self.flat.numel(), n_buckets)
+        self.sink, off = {}, 0               # parameter -> its slice of the flat gradient buffer
+        for p in self.params:
+            self.sink[id(p)] = self.grad[off:off + p.numel()]
+            off += p.numel()
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
 
@@ -55,12 +59,15 @@ class EpisodeTrainer(object):
         ops.sgd_step(self.flat[lo:hi], self.grad[lo:hi], self.mom[lo:hi], self.lr, self.momentum,
                      self.weight_decay, self.steps == 0)
 
-    def gather_grads(self):
-        """Copy p.grad of every parameter into the flat gradient buffer (missing grads count as zero)."""
+    def gather_grads(self, sunk=()):
+        """Copy p.grad of every parameter into the flat gradient buffer (missing grads count as zero); parameters
+        in `sunk` already had their gradient written there by the backward kernels."""
         off = 0
         for p in self.params:
             n = p.numel()
-            if p.grad is None:
+            if id(p) in sunk:
+                pass
+            elif p.grad is None:
                 self.grad[off:off + n].zero_()
             else:
                 self.grad[off:off + n].copy_(p.grad.reshape(-1))
@@ -81,6 +88,13 @@ class EpisodeTrainer(object):
         bump_weight_epoch()
 
     def backward_and_step(self, loss):
-        loss.backward()
-        self.gather_grads()
+        # While this backward runs, the HIP gradient kernels write dW / dgamma / dbeta straight into the flat
+        # buffer (ops.GRAD_SINK); whatever still arrives through autograd is gathered afterwards.
+        ops.GRAD_SINK, ops.GRAD_SUNK = self.sink, set()
+        try:
+            loss.backward()
+            sunk = ops.GRAD_SUNK
+        finally:
+            ops.GRAD_SINK, ops.GRAD_SUNK = None, set()
+        self.gather_grads(sunk)
         self.reduce_and_step()

@@ -254,21 +254,36 @@ def _fold_reweight_head_f32(head_w, head_b, dyn):
 
 # ---- backward ------------------------------------------------------------------------------
 
-def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None):
+GRAD_SINK = None    # dp.EpisodeTrainer: {id(param): 1-D view into its flat gradient buffer} while a step's backward runs
+GRAD_SUNK = set()   # ids of the parameters whose gradient the kernels wrote straight into the sink
+
+
+def grad_dst(param, shape, device):
+    """Where a parameter-gradient kernel should write: the trainer's flat buffer slice, or a fresh tensor."""
+    if GRAD_SINK is not None and param is not None:
+        v = GRAD_SINK.get(id(param))
+        if v is not None and v.numel() == int(torch.Size(shape).numel()):
+            GRAD_SUNK.add(id(param))
+            return v.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None):
     """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv.
-    wino_v: the forward pass's transformed input (conv3x3_wino keep_v), saves its recomputation."""
+    wino_v: the forward pass's transformed input (conv3x3_wino keep_v), saves its recomputation.
+    param: the parameter this is the gradient of (lets a trainer's gradient sink receive it directly)."""
     L = lib()
     dev = xv.t.device
     if dtype == "f32" and wino_eligible(cin, cout, ksize) and cin == xv.C:
         ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+        dw = grad_dst(param, (cout, cin, 3, 3), dev)
         check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, _ptr(wino_v), dw.data_ptr(), ws.data_ptr(),
                                        ws_bytes, xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_wino_conv3x3_wgrad")
         return dw
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=dev)
+    dw = grad_dst(param, (cout, cin, ksize, ksize), dev)
     fn = L.fsd_conv2d_wgrad_bf16 if dtype == "bf16" else L.fsd_conv2d_wgrad
     check(fn(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
              xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
@@ -280,13 +295,13 @@ def c4_bnfused_eligible(xv, cout, ksize):
     return ksize == 3 and xv.C == 4 and xv.ld == 4 and cout % 32 == 0 and xv.W >= 2
 
 
-def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout):
+def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout, param=None):
     """dW of a first layer straight from dt (gradient w.r.t. the BN output): BN backward fused, dy never stored."""
     L = lib()
     dev = xv.t.device
     ws_bytes = L.fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(xv.B, xv.H, xv.W, cout)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    dw = grad_dst(param, (cout, cin, 3, 3), dev)
     check(L.fsd_conv3x3_wgrad_c4_bnfused(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(),
                                          invstd.data_ptr(), xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes,
                                          xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_wgrad_c4_bnfused")
@@ -307,16 +322,17 @@ def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     return dt, partial
 
 
-def reduce_partials(partial, count, channels, scale=None, want_coef=False):
-    """-> (sum_col0 [C], sum_col1 [C], coef [3,C] or None)."""
+def reduce_partials(partial, count, channels, scale=None, want_coef=False, param0=None, param1=None):
+    """-> (sum_col0 [C], sum_col1 [C], coef [3,C] or None).  param0 / param1: the parameters the two sums are the
+    gradients of (BN bias / weight, or a conv bias), for the trainer's gradient sink."""
     L = lib()
     dev = partial.device
-    out = torch.empty((2, channels), dtype=torch.float32, device=dev)
+    s0, s1 = grad_dst(param0, (channels,), dev), grad_dst(param1, (channels,), dev)
     coef = torch.empty((3, channels), dtype=torch.float32, device=dev) if want_coef else None
     ws = torch.empty(L.fsd_reduce_workspace_bytes(channels) // 8, dtype=torch.float64, device=dev)
-    check(L.fsd_bn_bwd_finalize(partial.data_ptr(), partial.shape[0], count, channels, _ptr(scale), out[1].data_ptr(),
-                                out[0].data_ptr(), _ptr(coef), ws.data_ptr(), _stream()), "fsd_bn_bwd_finalize")
-    return out[0], out[1], coef
+    check(L.fsd_bn_bwd_finalize(partial.data_ptr(), partial.shape[0], count, channels, _ptr(scale), s1.data_ptr(),
+                                s0.data_ptr(), _ptr(coef), ws.data_ptr(), _stream()), "fsd_bn_bwd_finalize")
+    return s0, s1, coef
 
 
 def bn_bwd_apply(dt, yv, coef, mean, invstd):
@@ -325,12 +341,12 @@ def bn_bwd_apply(dt, yv, coef, mean, invstd):
     return dt
 
 
-def colsum(v, channels):
+def colsum(v, channels, param=None):
     L = lib()
     partial = torch.empty((L.fsd_act_bwd_rows(v.pixels), channels, 2), dtype=torch.float32, device=v.t.device)
     check(L.fsd_colsum_partials(v.ptr, v.ld, partial.data_ptr(), v.pixels, channels, _stream()),
           "fsd_colsum_partials")
-    s, _, _ = reduce_partials(partial, v.pixels, channels)
+    s, _, _ = reduce_partials(partial, v.pixels, channels, param0=param)
     return s
 
 
@@ -353,10 +369,10 @@ def add_inplace(dst, src):
     return dst
 
 
-def head_unfold_bwd(dweff, head_w, dyn):
+def head_unfold_bwd(dweff, head_w, dyn, param=None):
     O, Cc = head_w.shape[0], head_w.shape[1]
     N = dyn.shape[0]
-    d_head = torch.empty((O, Cc, 1, 1), dtype=torch.float32, device=dyn.device)
+    d_head = grad_dst(param, (O, Cc, 1, 1), dyn.device)
     d_dyn = torch.empty((N, Cc, 1, 1), dtype=torch.float32, device=dyn.device)
     check(lib().fsd_head_unfold_bwd(dweff.data_ptr(), head_w.contiguous().data_ptr(), dyn.contiguous().data_ptr(),
                                     d_head.data_ptr(), d_dyn.data_ptr(), N, O, Cc, _stream()), "fsd_head_unfold_bwd")
