@@ -63,11 +63,13 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         dy = dt
     kept = rec.get("wino_v")
     pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype,
-                                               wino_v=kept[0] if kept else None, param=conv.weight)
+                                               wino_v=kept[0] if kept else None, param=conv.weight,
+                                               tile=rec.get("wino_tile") if kept else None)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
-        if net.compute_dtype == "f32" and ops.wino_eligible(dyv.C, xv.C, k):
-            dx, _ = ops.conv3x3_wino(dyv, net.cache.get(conv.weight, 1, "wino"), xv.C)
+        tile = ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W) if net.compute_dtype == "f32" else 0
+        if tile:
+            dx, _ = ops.conv3x3_wino(dyv, net.cache.get(conv.weight, 1, "wino%d" % tile), xv.C, tile=tile)
         else:
             dx, _ = ops.conv2d(dyv, net.cache.get(conv.weight, 1, net.compute_dtype), xv.C, k)
         _accumulate(grads, xv, dx)

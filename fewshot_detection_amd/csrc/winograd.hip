@@ -259,95 +259,418 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
   }
 }
 
+// =====================================================================================================
+// F(4x4, 3x3): 36 multiplications per 4x4 outputs (4x fewer than direct, 1.78x fewer than F(2x2,3x3)) and a
+// transformed input of only 2.25x the activation (F(2x2): 4x).  Interpolation points 0, +-1, +-2, inf:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Weight gradient F(3x3, 4x4) shares B^T:  G4 = [1/4 0 0 0; -1/6(1 1 1 1); -1/6(1 -1 1 -1); 1/24(1 2 4 8);
+//   1/24(1 -2 4 -8); 0 0 0 1],  A3^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1].
+// fp32 round-off of this variant is ~1.5e-5 of the output magnitude (F(2x2): ~1e-6), see DESIGN.md.
+template <typename T>
+__device__ __forceinline__ void bt6(const T& d0, const T& d1, const T& d2, const T& d3, const T& d4, const T& d5, T (&r)[6]) {
+  r[0] = 4.f * d0 - 5.f * d2 + d4;
+  r[1] = d4 + d3 - 4.f * (d1 + d2);
+  r[2] = d4 - d3 + 4.f * (d1 - d2);
+  r[3] = d4 - d2 + 2.f * (d3 - d1);
+  r[4] = d4 - d2 - 2.f * (d3 - d1);
+  r[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+template <typename T>
+__device__ __forceinline__ void at4(const T& m0, const T& m1, const T& m2, const T& m3, const T& m4, const T& m5, T (&o)[4]) {
+  const T a = m1 + m2, b = m1 - m2, c = m3 + m4, d = m3 - m4;
+  o[0] = m0 + a + c;
+  o[1] = b + 2.f * d;
+  o[2] = a + 4.f * c;
+  o[3] = b + 8.f * d + m5;
+}
+template <typename T>
+__device__ __forceinline__ void g6(const T& g0, const T& g1, const T& g2, T (&r)[6]) {
+  const T e = g0 + g2, f = g0 + 4.f * g2;
+  r[0] = 0.25f * g0;
+  r[1] = (-1.f / 6.f) * (e + g1);
+  r[2] = (-1.f / 6.f) * (e - g1);
+  r[3] = (1.f / 24.f) * (f + 2.f * g1);
+  r[4] = (1.f / 24.f) * (f - 2.f * g1);
+  r[5] = g2;
+}
+template <typename T>
+__device__ __forceinline__ void g6x4(const T& q0, const T& q1, const T& q2, const T& q3, T (&r)[6]) {
+  const T e = q0 + q2, o = q1 + q3, f = q0 + 4.f * q2, h = 2.f * q1 + 8.f * q3;
+  r[0] = 0.25f * q0;
+  r[1] = (-1.f / 6.f) * (e + o);
+  r[2] = (-1.f / 6.f) * (e - o);
+  r[3] = (1.f / 24.f) * (f + h);
+  r[4] = (1.f / 24.f) * (f - h);
+  r[5] = q3;
+}
+template <typename T>
+__device__ __forceinline__ void a3(const T& m0, const T& m1, const T& m2, const T& m3, const T& m4, const T& m5, T (&o)[3]) {
+  const T a = m1 + m2, b = m1 - m2, c = m3 + m4, d = m3 - m4;
+  o[0] = m0 + a + c;
+  o[1] = b + 2.f * d;
+  o[2] = a + 4.f * c + m5;
+}
+
+// One thread: one 4x4-output tile (6x6 patch) x 4 channels.
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
+                                                         int H, int W, int TH, int TW, int C, long long T) {
+  const int cg = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * cg) return;
+  const int g = (int)(idx % cg);
+  const long long tile = idx / cg;
+  const int tx = (int)(tile % TW);
+  const long long t2 = tile / TW;
+  const int ty = (int)(t2 % TH);
+  const long long b = t2 / TH;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int iy = 4 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = 4 * tx - 1 + j;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      d[i][j] = ok ? ld4(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4) : zero;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {            // columns: t = B^T d (in place)
+    f32x4 r[6];
+    bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i][j] = r[i];
+  }
+  float* dst = V + tile * C + g * 4;
+  const long long ps = T * C;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {            // rows: V = t B
+    f32x4 r[6];
+    bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) st4(dst + (i * 6 + j) * ps, r[j]);
+  }
+}
+
+// dy (4x4 tile) -> G4 dy G4^T  (36 positions)
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
+                                                      int H, int W, int TH, int TW, int C, long long T) {
+  const int cg = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * cg) return;
+  const int g = (int)(idx % cg);
+  const long long tile = idx / cg;
+  const int tx = (int)(tile % TW);
+  const long long t2 = tile / TW;
+  const int ty = (int)(t2 % TH);
+  const long long b = t2 / TH;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 q[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oy = 4 * ty + i, ox = 4 * tx + j;
+      q[i][j] = (oy < H && ox < W) ? ld4(dy + ((b * H + oy) * (long long)W + ox) * dy_ld + g * 4) : zero;
+    }
+  f32x4 t[6][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 r[6];
+    g6x4(q[0][j], q[1][j], q[2][j], q[3][j], r);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = r[i];
+  }
+  float* dst = Wt + tile * C + g * 4;
+  const long long ps = T * C;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x4 r[6];
+    g6x4(t[i][0], t[i][1], t[i][2], t[i][3], r);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) st4(dst + (i * 6 + j) * ps, r[j]);
+  }
+}
+
+// One block: GL channel groups x 256/GL tile lanes over kTilesPerBlock tiles; writes y (+bias) and the BN partial sums.
+template <int GL>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+                                                          float* __restrict__ y, long long y_ld, float* __restrict__ partial,
+                                                          int H, int W, int TH, int TW, int C, long long T) {
+  constexpr int NPL = 256 / GL;
+  __shared__ float s_red[NPL][GL][8];
+  const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
+  const int g = blockIdx.y * GL + gl;
+  const int cg = C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
+  f32x4 s1 = zero, s2 = zero;
+  const long long t0 = (long long)blockIdx.x * kTilesPerBlock;
+  const long long ps = T * C;
+  if (g_ok) {
+    for (int it = pl; it < kTilesPerBlock; it += NPL) {
+      const long long tile = t0 + it;
+      if (tile >= T) break;
+      const int tx = (int)(tile % TW);
+      const long long t2 = tile / TW;
+      const int ty = (int)(t2 % TH);
+      const long long b = t2 / TH;
+      const float* src = Mb + tile * C + g * 4;
+      f32x4 s[4][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {          // columns: s = A^T m
+        f32x4 r[4];
+        at4(ld4(src + (0 * 6 + j) * ps), ld4(src + (1 * 6 + j) * ps), ld4(src + (2 * 6 + j) * ps),
+            ld4(src + (3 * 6 + j) * ps), ld4(src + (4 * 6 + j) * ps), ld4(src + (5 * 6 + j) * ps), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = r[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = 4 * ty + i;
+        if (oy >= H) continue;
+        f32x4 o[4];
+        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
+        float* dst = y + ((b * H + oy) * (long long)W + 4 * tx) * y_ld + g * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (4 * tx + j >= W) continue;
+          st4(dst + j * y_ld, o[j] + bv);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s1[k] += o[j][k]; s2[k] += o[j][k] * o[j][k]; }
+        }
+      }
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_red[pl][gl][k] = s1[k];
+    s_red[pl][gl][4 + k] = s2[k];
+  }
+  __syncthreads();
+  if (pl == 0 && g_ok) {
+    float* dst = partial + ((long long)blockIdx.x * C + g * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.f, b2 = 0.f;
+#pragma unroll
+      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b2 += s_red[l][gl][4 + k]; }
+      dst[2 * k] = a;
+      dst[2 * k + 1] = b2;
+    }
+  }
+}
+
+// U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.
+__global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int mode,
+                                    int rows, int red, int rows_pad) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows_pad * red) return;
+  const int row = (int)(idx / red), k = (int)(idx - (long long)row * red);
+  float gk[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (row < rows) {
+        v = mode == 0 ? w[(((long long)row * cin + k) * 3 + a) * 3 + b]
+                      : w[(((long long)k * cin + row) * 3 + (2 - a)) * 3 + (2 - b)];
+      }
+      gk[a][b] = v;
+    }
+  float t[6][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float r[6];
+    g6(gk[0][b], gk[1][b], gk[2][b], r);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][b] = r[a];
+  }
+  const long long ps = (long long)rows_pad * red;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    float r[6];
+    g6(t[a][0], t[a][1], t[a][2], r);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) U[(a * 6 + b) * ps + idx] = r[b];
+  }
+}
+
+// ws[p][split][co][ci] (36 positions) -> dw[co][ci][3][3] = A3^T m A3.  Block = 16 outputs x 36 positions.
+__global__ __launch_bounds__(576) void wino4_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                      int cout, int cin) {
+  __shared__ float s_m[36][17];
+  const int il = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  const long long n = (long long)cout * cin;
+  const long long idx = (long long)blockIdx.x * 16 + il;
+  float v = 0.f;
+  if (idx < n) {
+    const float* src = ws + (long long)pp * splits * n + idx;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      const float v0 = src[k * n], v1 = src[(k + 1) * n], v2 = src[(k + 2) * n], v3 = src[(k + 3) * n];
+      v += v0; v += v1; v += v2; v += v3;
+    }
+    for (; k < splits; ++k) v += src[k * n];
+  }
+  s_m[pp][il] = v;
+  __syncthreads();
+  if (threadIdx.x >= 16 || idx >= n) return;
+  float s[3][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float r[3];
+    a3(s_m[0 * 6 + j][il], s_m[1 * 6 + j][il], s_m[2 * 6 + j][il], s_m[3 * 6 + j][il], s_m[4 * 6 + j][il],
+       s_m[5 * 6 + j][il], r);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i][j] = r[i];
+  }
+  float* dst = dw + idx * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float r[3];
+    a3(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], r);
+    dst[i * 3 + 0] = r[0];
+    dst[i * 3 + 1] = r[1];
+    dst[i * 3 + 2] = r[2];
+  }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-inline long long tiles_of(int batch, int h, int w) { return (long long)batch * ((h + 1) / 2) * ((w + 1) / 2); }
+inline long long tiles_of(int batch, int h, int w, int m) { return (long long)batch * ((h + m - 1) / m) * ((w + m - 1) / m); }
+inline bool tile_ok(int m) { return m == 2 || m == 4; }
+inline int npos(int m) { return (m + 2) * (m + 2); }       // 16 or 36 transformed positions
 
 }  // namespace
 
-extern "C" size_t fsd_wino_packed_weight_elems(int rows, int red) { return (size_t)16 * round_up(rows, 128) * red; }
+extern "C" size_t fsd_wino_packed_weight_elems(int rows, int red, int tile) {
+  return (size_t)npos(tile) * round_up(rows, 128) * red;
+}
 
-extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode,
+extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode, int tile,
                                     hipStream_t stream) {
   (void)hipGetLastError();
-  if (!w_oihw || !u_packed || cout < 1 || cin < 1 || (mode != 0 && mode != 1)) return FSD_ERR_ARG;
+  if (!w_oihw || !u_packed || cout < 1 || cin < 1 || (mode != 0 && mode != 1) || !tile_ok(tile)) return FSD_ERR_ARG;
   const int rows = mode == 0 ? cout : cin, red = mode == 0 ? cin : cout;
   if (red % 32) return FSD_ERR_UNSUPPORTED;
   const int rows_pad = round_up(rows, 128);
   const long long total = (long long)rows_pad * red;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
-                     cout, cin, mode, rows, red, rows_pad);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
+                       cout, cin, mode, rows, red, rows_pad);
+  else
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
+                       cout, cin, mode, rows, red, rows_pad);
   return (int)hipGetLastError();
 }
 
-extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout) {
-  return (size_t)16 * tiles_of(batch, height, width) * (size_t)(cin + cout) * sizeof(float);
+extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
+  return (size_t)npos(tile) * tiles_of(batch, height, width, tile) * (size_t)(cin + cout) * sizeof(float);
 }
 
-extern "C" int fsd_wino_partial_rows(int batch, int height, int width) {
-  return (int)((tiles_of(batch, height, width) + kTilesPerBlock - 1) / kTilesPerBlock);
+extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
+  return (int)((tiles_of(batch, height, width, tile) + kTilesPerBlock - 1) / kTilesPerBlock);
 }
 
-extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin) {
-  return (size_t)16 * tiles_of(batch, height, width) * cin;
+extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin, int tile) {
+  return (size_t)npos(tile) * tiles_of(batch, height, width, tile) * cin;
 }
 
 extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
                                     long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
-                                    float* v_keep, int batch, int height, int width, int cin, int cout,
+                                    float* v_keep, int batch, int height, int width, int cin, int cout, int tile,
                                     hipStream_t stream) {
   (void)hipGetLastError();
-  if (!x || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (!x || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile)) return FSD_ERR_ARG;
   if (cin % 32 || (cout & 3) || (x_ld & 3) || (y_ld & 3) || x_ld < cin || y_ld < cout) return FSD_ERR_UNSUPPORTED;
-  if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
-  const int TH = (height + 1) / 2, TW = (width + 1) / 2;
-  const long long T = tiles_of(batch, height, width);
+  if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
+  const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
+  const long long T = tiles_of(batch, height, width, tile);
+  const int P = npos(tile);
   float* V = v_keep ? v_keep : reinterpret_cast<float*>(workspace);     // kept for the weight gradient if asked
-  float* Mb = reinterpret_cast<float*>(workspace) + (size_t)16 * T * cin;
+  float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * T * cin;
   const long long n_in = T * (cin / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
-                     width, TH, TW, cin, T);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
+                       width, TH, TW, cin, T);
+  else
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
+                       width, TH, TW, cin, T);
   const int rows_pad = round_up(cout, 128);
   int rc = fsd_conv::conv_gemm_batched(V, cin, T * cin, u_packed, (long long)rows_pad * cin, Mb, cout, T * cout, T, cin, cout,
-                                       16, stream);
+                                       P, stream);
   if (rc != 0) return rc;
-  const dim3 grid((unsigned)((T + kTilesPerBlock - 1) / kTilesPerBlock), (cout / 4 + 63) / 64);
-  hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial, height, width, TH, TW,
-                     cout, T);
+  const unsigned bx = (unsigned)((T + kTilesPerBlock - 1) / kTilesPerBlock);
+  const int cg = cout / 4;
+  if (tile == 2) {
+    hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial,
+                       height, width, TH, TW, cout, T);
+  } else if (cg <= 16) {
+    hipLaunchKernelGGL(wino4_output_kernel<16>, dim3(bx, (cg + 15) / 16), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                       bn_partial, height, width, TH, TW, cout, T);
+  } else if (cg <= 32) {
+    hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, 1), dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial, height,
+                       width, TH, TW, cout, T);
+  } else {
+    hipLaunchKernelGGL(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                       bn_partial, height, width, TH, TW, cout, T);
+  }
   return (int)hipGetLastError();
 }
 
-extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout) {
-  const long long T = tiles_of(batch, height, width);
-  const int splits = fsd_conv::wgrad_batched_splits(T, cin, cout, 16);
-  return ((size_t)16 * T * (size_t)(cin + cout) + (size_t)16 * splits * cout * cin) * sizeof(float);
+extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
+  const long long T = tiles_of(batch, height, width, tile);
+  const int P = npos(tile);
+  const int splits = fsd_conv::wgrad_batched_splits(T, cin, cout, P);
+  return ((size_t)P * T * (size_t)(cin + cout) + (size_t)P * splits * cout * cin) * sizeof(float);
 }
 
 extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld,
                                       const float* v_kept, float* dw_oihw, void* workspace, size_t workspace_bytes,
-                                      int batch, int height, int width, int cin, int cout, hipStream_t stream) {
+                                      int batch, int height, int width, int cin, int cout, int tile,
+                                      hipStream_t stream) {
   (void)hipGetLastError();
-  if (!dy || (!x && !v_kept) || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (!dy || (!x && !v_kept) || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile))
+    return FSD_ERR_ARG;
   if ((cin & 3) || (cout & 3) || (dy_ld & 3) || dy_ld < cout) return FSD_ERR_UNSUPPORTED;
   if (!v_kept && ((x_ld & 3) || x_ld < cin)) return FSD_ERR_UNSUPPORTED;
-  if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout)) return FSD_ERR_WORKSPACE;
-  const int TH = (height + 1) / 2, TW = (width + 1) / 2;
-  const long long T = tiles_of(batch, height, width);
+  if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
+  const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
+  const long long T = tiles_of(batch, height, width, tile);
+  const int P = npos(tile);
   float* Vw = reinterpret_cast<float*>(workspace);
-  float* Wt = Vw + (size_t)16 * T * cin;
-  float* ws = Wt + (size_t)16 * T * cout;
+  float* Wt = Vw + (size_t)P * T * cin;
+  float* ws = Wt + (size_t)P * T * cout;
   const long long n_in = T * (cin / 4), n_dy = T * (cout / 4);
   const float* V = v_kept;                                   // the forward pass's B^T d B, if the caller kept it
   if (!V) {
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw, height,
-                       width, TH, TW, cin, T);
+    if (tile == 2)
+      hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T);
+    else
+      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T);
     V = Vw;
   }
-  hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
-                     width, TH, TW, cout, T);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
+                       width, TH, TW, cout, T);
+  else
+    hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
+                       width, TH, TW, cout, T);
   int splits = 0;
-  int rc = fsd_conv::wgrad_gemm_batched(Wt, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, 16, &splits, stream);
+  int rc = fsd_conv::wgrad_gemm_batched(Wt, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, P, &splits, stream);
   if (rc != 0) return rc;
   const long long n = (long long)cout * cin;
-  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+  else
+    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(576), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }

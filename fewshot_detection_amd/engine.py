@@ -53,7 +53,10 @@ class _WeightCache(object):
         tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
-            packed = ops.pack_weight_wino(w.detach(), mode) if dtype == "wino" else ops.pack_weight(w.detach(), mode, dtype)
+            if dtype in ("wino2", "wino4"):
+                packed = ops.pack_weight_wino(w.detach(), mode, int(dtype[4]))
+            else:
+                packed = ops.pack_weight(w.detach(), mode, dtype)
             hit = (tag, packed)
             self._store[key] = hit
         return hit[1]
@@ -122,17 +125,18 @@ class Network(object):
             raise NotImplementedError("conv size=%d pad=%s" % (k, blk["pad"]))
         cout = int(blk["filters"])
         slope = _slope(blk["activation"])
-        wino = self.compute_dtype == "f32" and ops.wino_eligible(xv.C, cout, k)
-        wp = self.cache.get(conv.weight, 0, "wino" if wino else self.compute_dtype)
+        wino = ops.wino_tile(xv.C, cout, k, xv.H, xv.W) if self.compute_dtype == "f32" else 0
+        wp = self.cache.get(conv.weight, 0, "wino%d" % wino if wino else self.compute_dtype)
         dev = xv.t.device
         cin_true = conv.weight.shape[1]
         # Winograd layers keep their transformed input for the weight gradient when a backward pass will follow
         keep = [] if (wino and self._record) else None
-        rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool, wino_v=keep)
+        rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool, wino_v=keep,
+                   wino_tile=wino)
         if bn is None and slope == 1.0 and pool == 0:
             z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
             if wino:
-                ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z, keep_v=keep)
+                ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z, keep_v=keep, tile=wino)
             else:
                 ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
             rec.update(y=z, z=z, z_full=None)
@@ -140,7 +144,7 @@ class Network(object):
             return z, None
         if wino:
             y, partial = ops.conv3x3_wino(xv, wp, cout, bias=None if bn is not None else conv.bias,
-                                          bn_partial=bn is not None and training, keep_v=keep)
+                                          bn_partial=bn is not None and training, keep_v=keep, tile=wino)
         else:
             y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
                                     bn_partial=bn is not None and training, cin_true=cin_true)

@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C-ABI.  Every function launches on the current torch HIP
 stream and never synchronises.  Tensors are raw storage here: layouts are documented per op."""
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -99,53 +101,70 @@ def pack_weight(w, mode=0, dtype="f32"):
     return out
 
 
-def pack_weight_wino(w, mode=0):
-    """(Cout,Cin,3,3) -> 16 transformed (G g G^T) matrices in the GEMM kernel's packed layout."""
+def pack_weight_wino(w, mode=0, tile=2):
+    """(Cout,Cin,3,3) -> the (tile+2)^2 transformed (G g G^T) matrices in the GEMM kernel's packed layout."""
     require_device(w)
     cout, cin, k, _ = w.shape
     assert k == 3
     rows, red = (cout, cin) if mode == 0 else (cin, cout)
-    out = torch.empty(lib().fsd_wino_packed_weight_elems(rows, red), dtype=torch.float32, device=w.device)
-    check(lib().fsd_wino_pack_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, mode, _stream()),
+    out = torch.empty(lib().fsd_wino_packed_weight_elems(rows, red, tile), dtype=torch.float32, device=w.device)
+    check(lib().fsd_wino_pack_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, mode, tile, _stream()),
           "fsd_wino_pack_weight")
     return out
 
 
-def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None):
-    """Winograd F(2x2,3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3).
+def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None, tile=2):
+    """Winograd F(tile x tile, 3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3).
     keep_v: a list; the transformed input is appended to it (kept for the weight gradient)."""
     L = lib()
     dev = xv.t.device
     y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
     partial = None
     if bn_partial:
-        partial = torch.empty((L.fsd_wino_partial_rows(xv.B, xv.H, xv.W), cout, 2), dtype=torch.float32, device=dev)
-    ws_bytes = L.fsd_wino_workspace_bytes(xv.B, xv.H, xv.W, xv.C, cout)
+        partial = torch.empty((L.fsd_wino_partial_rows(xv.B, xv.H, xv.W, tile), cout, 2), dtype=torch.float32,
+                              device=dev)
+    ws_bytes = L.fsd_wino_workspace_bytes(xv.B, xv.H, xv.W, xv.C, cout, tile)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     v = None
     if keep_v is not None:
-        v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C), dtype=torch.float32, device=dev)
+        v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C, tile), dtype=torch.float32, device=dev)
         keep_v.append(v)
     check(L.fsd_wino_conv3x3_fwd(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                                 ws.data_ptr(), ws_bytes, _ptr(v), xv.B, xv.H, xv.W, xv.C, cout, _stream()),
+                                 ws.data_ptr(), ws_bytes, _ptr(v), xv.B, xv.H, xv.W, xv.C, cout, tile, _stream()),
           "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
-        tiles = xv.B * ((xv.H + 1) // 2) * ((xv.W + 1) // 2)
-        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * 16 * xv.C * cout * tiles))
+        tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles))
     return y, partial
 
 
 def wino_eligible(cin, cout, ksize):
-    """Measured on MI355X: the transforms cost ~16x(Cin+Cout) floats of HBM traffic per tile, which only pays
-    once both channel counts reach 128 (the 104x104 layers with 64 channels are faster on the direct kernel)."""
+    """F(2x2,3x3) rule.  Measured on MI355X: the transforms cost ~16x(Cin+Cout) floats of HBM traffic per tile, which
+    only pays once both channel counts reach 128 (the 104x104 layers with 64 channels are faster on the direct kernel)."""
     return WINOGRAD and ksize == 3 and cin % 32 == 0 and cout % 4 == 0 and min(cin, cout) >= 128
 
 
-WINOGRAD = True     # Winograd F(2x2,3x3) for eligible fp32 3x3 layers (forward + data gradient)
+def wino_tile(cin, cout, ksize, H, W):
+    """Which form a 3x3 fp32 convolution takes: 0 = direct implicit GEMM, 2 = F(2x2,3x3), 4 = F(4x4,3x3).
+    F(4x4) needs 36 multiplications per 4x4 tile against 16 per 2x2 tile, so it wins when the feature map does not
+    waste too much of its 4x4 tiles (13x13 -> 16x16: 0.73 of the F(2x2) work; 26x26: 0.65; 52x52: 0.56)."""
+    if not (WINOGRAD and ksize == 3 and cin % 32 == 0 and cout % 4 == 0):
+        return 0
+    lo = min(cin, cout)
+    m2 = 16 * ((H + 1) // 2) * ((W + 1) // 2)
+    m4 = 36 * ((H + 3) // 4) * ((W + 3) // 4)
+    if WINOGRAD4 and lo >= WINO4_MIN_CH and m4 <= 0.85 * m2:
+        return 4
+    return 2 if lo >= 128 else 0
+
+
+WINOGRAD = True     # Winograd for eligible fp32 3x3 layers (forward, data gradient, weight gradient)
+WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
+WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
 PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops, executed_mfma_flops) per conv launch
 
 
@@ -268,18 +287,21 @@ def grad_dst(param, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None):
+def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None, tile=None):
     """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv.
-    wino_v: the forward pass's transformed input (conv3x3_wino keep_v), saves its recomputation.
+    wino_v: the forward pass's transformed input (conv3x3_wino keep_v, same tile), saves its recomputation.
+    tile: 0 direct / 2 / 4 Winograd form (default: wino_tile's choice for this shape).
     param: the parameter this is the gradient of (lets a trainer's gradient sink receive it directly)."""
     L = lib()
     dev = xv.t.device
-    if dtype == "f32" and wino_eligible(cin, cout, ksize) and cin == xv.C:
-        ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout)
+    if tile is None:
+        tile = wino_tile(cin, cout, ksize, xv.H, xv.W) if dtype == "f32" else 0
+    if dtype == "f32" and tile and cin == xv.C:
+        ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, tile)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         dw = grad_dst(param, (cout, cin, 3, 3), dev)
         check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, _ptr(wino_v), dw.data_ptr(), ws.data_ptr(),
-                                       ws_bytes, xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_wino_conv3x3_wgrad")
+                                       ws_bytes, xv.B, xv.H, xv.W, cin, cout, tile, _stream()), "fsd_wino_conv3x3_wgrad")
         return dw
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)

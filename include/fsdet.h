@@ -105,20 +105,23 @@ int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const 
                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
                    int cout, int ksize, int out_nchw, hipStream_t stream);
 
-/* Winograd F(2x2,3x3) form of the fp32 3x3 convolution (2.25x fewer multiplications): input transform ->
- * 16 batched GEMMs on the fp32 MFMA kernel -> output transform (+bias, + BatchNorm partial sums
- * [fsd_wino_partial_rows][cout][2]).  u_packed = G g G^T from fsd_wino_pack_weight (mode 0 forward,
- * mode 1 data gradient), cin % 32 == 0, cout % 4 == 0.  Result equals fsd_conv2d_fwd up to fp32 round-off. */
-size_t fsd_wino_packed_weight_elems(int rows, int red);
-int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode, hipStream_t stream);
-size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout);
-int fsd_wino_partial_rows(int batch, int height, int width);
+/* Winograd form of the fp32 3x3 convolution: input transform -> (tile+2)^2 batched GEMMs on the fp32 MFMA kernel ->
+ * output transform (+bias, + BatchNorm partial sums [fsd_wino_partial_rows][cout][2]).
+ *   tile = 2: F(2x2,3x3), 16 positions, 2.25x fewer multiplications, round-off ~1e-6 of the output magnitude
+ *   tile = 4: F(4x4,3x3), 36 positions, 4x fewer multiplications (points 0,+-1,+-2,inf), round-off ~1.5e-5
+ * u_packed = G g G^T from fsd_wino_pack_weight (mode 0 forward, mode 1 data gradient; same tile), cin % 32 == 0,
+ * cout % 4 == 0.  Result equals fsd_conv2d_fwd up to that fp32 round-off. */
+size_t fsd_wino_packed_weight_elems(int rows, int red, int tile);
+int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int cout, int cin, int mode, int tile,
+                         hipStream_t stream);
+size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile);
+int fsd_wino_partial_rows(int batch, int height, int width, int tile);
 /* v_keep (nullable): if given, the transformed input B^T d B (fsd_wino_v_elems floats) is written there instead of
  * into the workspace, so that the weight gradient can reuse it (v_kept of fsd_wino_conv3x3_wgrad). */
-size_t fsd_wino_v_elems(int batch, int height, int width, int cin);
+size_t fsd_wino_v_elems(int batch, int height, int width, int cin, int tile);
 int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
                          long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
-                         int batch, int height, int width, int cin, int cout, hipStream_t stream);
+                         int batch, int height, int width, int cin, int cout, int tile, hipStream_t stream);
 
 /* First-layer 3x3 weight gradient (input with <= 4 channels stored as NHWC4, cout % 32 == 0) with the BatchNorm
  * backward fused into the operand load: dy = c1*(dt - c2 - xhat*c3) is formed in registers from dt (gradient w.r.t.
@@ -130,13 +133,14 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
                                  void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                  int cout, hipStream_t stream);
 
-/* Winograd F(3x3,2x2) form of the fp32 weight gradient of a 3x3 convolution: dW = sum over 2x2 tiles,
- * 16 batched reduction GEMMs over tiles instead of 9 taps x pixels (2.25x fewer multiplications).  v_kept (nullable):
- * the forward pass's transformed input; when given, x is not read. */
-size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout);
+/* Winograd form of the fp32 weight gradient of a 3x3 convolution, F(3x3, tile x tile): dW = sum over tiles,
+ * (tile+2)^2 batched reduction GEMMs over tiles instead of 9 taps x pixels (tile 2: 2.25x, tile 4: 4x fewer
+ * multiplications).  v_kept (nullable): the forward pass's transformed input of the same tile size; when given, x is
+ * not read. */
+size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile);
 int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, const float* v_kept,
                            float* dw_oihw, void* workspace, size_t workspace_bytes, int batch, int height, int width,
-                           int cin, int cout, hipStream_t stream);
+                           int cin, int cout, int tile, hipStream_t stream);
 
 /* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
  * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;

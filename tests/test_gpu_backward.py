@@ -61,13 +61,35 @@ def test_first_layer_fused_wgrad_matches_unfused_path(dev, B, H, W, cin, cout):
     assert torch.allclose(dw.cpu(), w.grad.float(), rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 13, 13, 1280, 1024), (3, 13, 11, 128, 256), (2, 52, 52, 128, 256),
+                                             (1, 7, 9, 256, 128), (5, 1, 1, 128, 128), (2, 26, 26, 64, 128)])
+def test_wgrad_winograd_4x4_matches_fp64_autograd(dev, B, H, W, cin, cout):
+    """F(3x3, 4x4) weight gradient (36 batched reduction GEMMs over 4x4 tiles) against fp64 autograd; also with the
+    transformed input kept by a tile-4 forward pass."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, 1, 1).backward(gy)
+    xv = ops.nchw_to_nhwc(x.float().to(dev))
+    gv = ops.nchw_to_nhwc(gy.float().to(dev))
+    dw = ops.conv2d_wgrad(gv, cout, xv, cin, 3, tile=4)
+    ref = w.grad.float()
+    err = float((dw.cpu() - ref).abs().max())
+    assert err < 1e-4 * float(ref.abs().max()), err
+    kept = []
+    ops.conv3x3_wino(xv, ops.pack_weight_wino(w.detach().float().to(dev), 0, 4), cout, keep_v=kept, tile=4)
+    assert torch.equal(ops.conv2d_wgrad(gv, cout, xv, cin, 3, wino_v=kept[0], tile=4), dw)
+
+
 def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(5)
     xv = ops.nchw_to_nhwc(torch.randn(4, 256, 26, 26, generator=g).to(dev))
     gv = ops.nchw_to_nhwc(torch.randn(4, 512, 26, 26, generator=g).to(dev))
     assert ops.wino_eligible(256, 512, 3)
-    a = ops.conv2d_wgrad(gv, 512, xv, 256, 3)
+    a = ops.conv2d_wgrad(gv, 512, xv, 256, 3, tile=2)
     monkeypatch.setattr(ops, "WINOGRAD", False)
     b = ops.conv2d_wgrad(gv, 512, xv, 256, 3)
     assert not torch.equal(a, b)                      # really two different code paths
@@ -76,7 +98,7 @@ def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
     monkeypatch.setattr(ops, "WINOGRAD", True)
     kept = []
     ops.conv3x3_wino(xv, ops.pack_weight_wino(torch.randn(512, 256, 3, 3, generator=g).to(dev)), 512, keep_v=kept)
-    c = ops.conv2d_wgrad(gv, 512, xv, 256, 3, wino_v=kept[0])
+    c = ops.conv2d_wgrad(gv, 512, xv, 256, 3, wino_v=kept[0], tile=2)
     assert torch.equal(a, c)
 
 
@@ -116,7 +138,9 @@ def test_conv_bn_leaky_pool_block_backward(dev, pool, B, H, W, cin, cout):
     tol = dict(rtol=1e-3, atol=1e-4)
     assert torch.allclose(dbeta.cpu(), bn.bias.grad.float(), **tol)
     assert torch.allclose(dgamma.cpu(), bn.weight.grad.float(), **tol)
-    assert torch.allclose(dw.cpu(), conv.weight.grad.float(), **tol)
+    # dW of the wide layers comes from the Winograd F(3x3,4x4) reduction: round-off ~1.5e-5 of the tensor's magnitude
+    wref = conv.weight.grad.float()
+    assert float((dw.cpu() - wref).abs().max()) < 1e-4 * float(wref.abs().max())
     assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), x.grad.float(), **tol)
 
 

@@ -256,14 +256,17 @@ def test_conv_bf16_matches_bf16_rounded_reference(dev, B, H, W, cin, cout, k, bi
         assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("B,H,W,cin,cout,bias", [
-    (2, 13, 13, 64, 128, False),     # odd size: 7x7 tiles, last row/column half empty
+    (2, 13, 13, 64, 128, False),     # odd size: last tile row/column partly outside the image
     (1, 26, 26, 128, 64, True),
     (2, 6, 6, 1280, 1024, False),    # L29 channel widths
     (3, 8, 10, 96, 36, False),       # Cout not a multiple of 64
     (1, 2, 2, 64, 32, True),         # a single tile per image
+    (2, 5, 3, 32, 32, False),        # smaller than one 4x4 tile in one direction
 ])
-def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias):
+def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias, tile):
+    """F(2x2,3x3) to ~1e-6, F(4x4,3x3) to ~1.5e-5 of the output magnitude (fp32 round-off of the transforms)."""
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(cin + H)
     x = torch.randn(B, cin, H, W, generator=g)
@@ -271,10 +274,11 @@ def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias):
     b = torch.randn(cout, generator=g) if bias else None
     ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 1).float()
     xv = ops.nchw_to_nhwc(x.to(dev))
-    yv, part = ops.conv3x3_wino(xv, ops.pack_weight_wino(w.to(dev)), cout, bias=None if b is None else b.to(dev),
-                                bn_partial=not bias)
+    yv, part = ops.conv3x3_wino(xv, ops.pack_weight_wino(w.to(dev), 0, tile), cout,
+                                bias=None if b is None else b.to(dev), bn_partial=not bias, tile=tile)
     y = ops.nhwc_to_nchw(yv).cpu()
-    assert torch.allclose(y, ref, rtol=1e-4, atol=5e-5), float((y - ref).abs().max())
+    tol = 1e-5 if tile == 2 else 6e-5                      # relative to the output magnitude
+    assert float((y - ref).abs().max()) < tol * float(ref.abs().max()), float((y - ref).abs().max())
     if part is not None:
         p = part.double().sum(0).cpu()
         flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
@@ -286,6 +290,7 @@ def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias):
     xg = x.double().requires_grad_(True)
     gy = torch.randn(B, cout, H, W, generator=g)
     F.conv2d(xg, w.double(), None, 1, 1).backward(gy.double())
-    dx, _ = ops.conv3x3_wino(ops.nchw_to_nhwc(gy.to(dev)), ops.pack_weight_wino(w.to(dev), mode=1), cin)
+    dx, _ = ops.conv3x3_wino(ops.nchw_to_nhwc(gy.to(dev)), ops.pack_weight_wino(w.to(dev), 1, tile), cin, tile=tile)
     gref = xg.grad.float()
-    assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), gref, rtol=1e-4, atol=1e-4 * float(gref.abs().max()))
+    err = float((ops.nhwc_to_nchw(dx).cpu() - gref).abs().max())
+    assert err < tol * float(gref.abs().max()), err

@@ -4,6 +4,7 @@
 
 Prints ms and direct-convolution-equivalent TFLOP/s per shape; used for kernel tuning (env knobs
 FSD_CONV_TILE / FSD_WGRAD_TILE select kernel variants)."""
+import os
 import sys
 import time
 
@@ -31,6 +32,10 @@ def timed(fn, iters=5):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     dev = torch.device("cuda:0")
+    if os.environ.get("FSD_WINO4") == "0":
+        ops.WINOGRAD4 = False
+    if os.environ.get("FSD_WINO4_MIN_CH"):
+        ops.WINO4_MIN_CH = int(os.environ["FSD_WINO4_MIN_CH"])
     for B, H, W, cin, cout, k in SHAPES:
         x = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, device=dev))
         dy = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, device=dev))
@@ -38,13 +43,14 @@ def main():
         flops = 2.0 * k * k * cin * cout * B * H * W
         line = "%3dx%3d %4d->%4d k%d:" % (H, W, cin, cout, k)
         if what in ("fwd", "all"):
-            if ops.wino_eligible(cin, cout, k):
-                wp = ops.pack_weight_wino(w)
-                ms = timed(lambda: ops.conv3x3_wino(x, wp, cout))
+            tile = ops.wino_tile(cin, cout, k, H, W)
+            if tile:
+                wp = ops.pack_weight_wino(w, 0, tile)
+                ms = timed(lambda: ops.conv3x3_wino(x, wp, cout, tile=tile))
             else:
                 wp = ops.pack_weight(w)
                 ms = timed(lambda: ops.conv2d(x, wp, cout, k))
-            line += "  fwd %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
+            line += "  fwd[%s] %7.3f ms %6.1f TF" % (tile or "d", ms, flops / ms / 1e9)
         if what in ("wgrad", "all"):
             ms = timed(lambda: ops.conv2d_wgrad(dy, cout, x, cin, k))
             line += "  wgrad %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
