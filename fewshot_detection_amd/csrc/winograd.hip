@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
-// One block: 64 channel groups x 4 tile lanes over kTilesPerBlock tiles; writes y and the BN partial sums.
+// One block: 64 channel groups x 4 tile lanes over `tpb` tiles; writes y and the BN partial sums.
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                          float* __restrict__ y, long long y_ld, float* __restrict__ partial,
-                                                         int H, int W, int TH, int TW, int C, long long T) {
+                                                         int H, int W, int TH, int TW, int C, long long T, int tpb) {
   __shared__ float s_red[4][64][8];
   const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int g = blockIdx.y * 64 + gl;
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
   f32x4 s1 = zero, s2 = zero;
-  const long long t0 = (long long)blockIdx.x * kTilesPerBlock;
+  const long long t0 = (long long)blockIdx.x * tpb;
   const long long ps = T * C;
   if (g_ok) {
-    for (int it = pl; it < kTilesPerBlock; it += 4) {
+    for (int it = pl; it < tpb; it += 4) {
       const long long tile = t0 + it;
       if (tile >= T) break;
       const int tx = (int)(tile % TW);
@@ -313,11 +313,17 @@ __device__ __forceinline__ void a3(const T& m0, const T& m1, const T& m2, const 
   o[2] = a + 4.f * c + m5;
 }
 
-// One thread: one 4x4-output tile (6x6 patch) x 4 channels.
+// One thread: one 4x4-output tile (6x6 patch) x 2 channels (36 live values: two channels keep the kernel at
+// ~90 VGPRs; with four it needs 166 and runs at less than half the HBM rate).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
                                                          int H, int W, int TH, int TW, int C, long long T) {
-  const int cg = C >> 2;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = C >> 1;
+  // neighbouring tiles re-read 2 of their 6 patch rows/columns: keep runs of consecutive tiles on one XCD (own L2)
+  const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
   const int g = (int)(idx % cg);
   const long long tile = idx / cg;
@@ -325,8 +331,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   const long long t2 = tile / TW;
   const int ty = (int)(t2 % TH);
   const long long b = t2 / TH;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 d[6][6];
+  const f32x2 zero = {0.f, 0.f};
+  f32x2 d[6][6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int iy = 4 * ty - 1 + i;
@@ -334,24 +340,24 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     for (int j = 0; j < 6; ++j) {
       const int ix = 4 * tx - 1 + j;
       const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      d[i][j] = ok ? ld4(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4) : zero;
+      d[i][j] = ok ? ld2(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 2) : zero;
     }
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {            // columns: t = B^T d (in place)
-    f32x4 r[6];
+    f32x2 r[6];
     bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[i][j] = r[i];
   }
-  float* dst = V + tile * C + g * 4;
+  float* dst = V + tile * C + g * 2;
   const long long ps = T * C;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {            // rows: V = t B
-    f32x4 r[6];
+    f32x2 r[6];
     bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) st4(dst + (i * 6 + j) * ps, r[j]);
+    for (int j = 0; j < 6; ++j) st2(dst + (i * 6 + j) * ps, r[j]);
   }
 }
 
@@ -395,74 +401,75 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
 }
 
-// One block: GL channel groups x 256/GL tile lanes over kTilesPerBlock tiles; writes y (+bias) and the BN partial sums.
+// One block: GL channel pairs x 256/GL tile lanes over `tpb` tiles; writes y (+bias) and the BN partial sums.
+// The 6 rows of m are streamed: row r is transformed along its columns (u = A^T-row-pass) and accumulated into the
+// 4x4 output with the column weights A^T[:, r] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1),
+// so only 16 outputs + one row are live (the all-at-once form needs 256 VGPRs and runs at occupancy 1).
 template <int GL>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                           float* __restrict__ y, long long y_ld, float* __restrict__ partial,
-                                                          int H, int W, int TH, int TW, int C, long long T) {
+                                                          int H, int W, int TH, int TW, int C, long long T, int tpb) {
   constexpr int NPL = 256 / GL;
-  __shared__ float s_red[NPL][GL][8];
+  __shared__ float s_red[NPL][GL][4];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
   const int g = blockIdx.y * GL + gl;
-  const int cg = C >> 2;
+  const int cg = C >> 1;
   const bool g_ok = g < cg;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
-  f32x4 s1 = zero, s2 = zero;
-  const long long t0 = (long long)blockIdx.x * kTilesPerBlock;
+  const f32x2 zero = {0.f, 0.f};
+  const f32x2 bv = (g_ok && bias) ? ld2(bias + g * 2) : zero;
+  f32x2 s1 = zero, s2 = zero;
+  const long long t0 = (long long)blockIdx.x * tpb;
   const long long ps = T * C;
   if (g_ok) {
-    for (int it = pl; it < kTilesPerBlock; it += NPL) {
+    for (int it = pl; it < tpb; it += NPL) {
       const long long tile = t0 + it;
       if (tile >= T) break;
       const int tx = (int)(tile % TW);
       const long long t2 = tile / TW;
       const int ty = (int)(t2 % TH);
       const long long b = t2 / TH;
-      const float* src = Mb + tile * C + g * 4;
-      f32x4 s[4][6];
+      const float* src = Mb + tile * C + g * 2;
+      f32x2 o[4][4];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {          // columns: s = A^T m
-        f32x4 r[4];
-        at4(ld4(src + (0 * 6 + j) * ps), ld4(src + (1 * 6 + j) * ps), ld4(src + (2 * 6 + j) * ps),
-            ld4(src + (3 * 6 + j) * ps), ld4(src + (4 * 6 + j) * ps), ld4(src + (5 * 6 + j) * ps), r);
+      for (int r = 0; r < 6; ++r) {
+        f32x2 u[4];
+        at4(ld2(src + (r * 6 + 0) * ps), ld2(src + (r * 6 + 1) * ps), ld2(src + (r * 6 + 2) * ps),
+            ld2(src + (r * 6 + 3) * ps), ld2(src + (r * 6 + 4) * ps), ld2(src + (r * 6 + 5) * ps), u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i][j] = r[i];
+        for (int j = 0; j < 4; ++j) {
+          if (r == 0) { o[0][j] = u[j]; }
+          else if (r == 1) { o[0][j] += u[j]; o[1][j] = u[j]; o[2][j] = u[j]; o[3][j] = u[j]; }
+          else if (r == 2) { o[0][j] += u[j]; o[1][j] -= u[j]; o[2][j] += u[j]; o[3][j] -= u[j]; }
+          else if (r == 3) { o[0][j] += u[j]; o[1][j] += 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] += 8.f * u[j]; }
+          else if (r == 4) { o[0][j] += u[j]; o[1][j] -= 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] -= 8.f * u[j]; }
+          else { o[3][j] += u[j]; }
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int oy = 4 * ty + i;
         if (oy >= H) continue;
-        f32x4 o[4];
-        at4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o);
-        float* dst = y + ((b * H + oy) * (long long)W + 4 * tx) * y_ld + g * 4;
+        float* dst = y + ((b * H + oy) * (long long)W + 4 * tx) * y_ld + g * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (4 * tx + j >= W) continue;
-          st4(dst + j * y_ld, o[j] + bv);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { s1[k] += o[j][k]; s2[k] += o[j][k] * o[j][k]; }
+          st2(dst + j * y_ld, o[i][j] + bv);
+          s1 += o[i][j];
+          s2 += o[i][j] * o[i][j];
         }
       }
     }
   }
   if (partial == nullptr) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    s_red[pl][gl][k] = s1[k];
-    s_red[pl][gl][4 + k] = s2[k];
-  }
+  s_red[pl][gl][0] = s1[0]; s_red[pl][gl][1] = s1[1];
+  s_red[pl][gl][2] = s2[0]; s_red[pl][gl][3] = s2[1];
   __syncthreads();
   if (pl == 0 && g_ok) {
-    float* dst = partial + ((long long)blockIdx.x * C + g * 4) * 2;
+    float* dst = partial + ((long long)blockIdx.x * C + g * 2) * 2;
+    float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = 0.f, b2 = 0.f;
-#pragma unroll
-      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b2 += s_red[l][gl][4 + k]; }
-      dst[2 * k] = a;
-      dst[2 * k + 1] = b2;
-    }
+    for (int l = 0; l < NPL; ++l) { a0 += s_red[l][gl][0]; a1 += s_red[l][gl][1]; q0 += s_red[l][gl][2]; q1 += s_red[l][gl][3]; }
+    dst[0] = a0; dst[1] = q0; dst[2] = a1; dst[3] = q1;
   }
 }
 
@@ -502,26 +509,31 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// ws[p][split][co][ci] (36 positions) -> dw[co][ci][3][3] = A3^T m A3.  Block = 16 outputs x 36 positions.
-__global__ __launch_bounds__(576) void wino4_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+// ws[p][split][co][ci] (36 positions) -> dw[co][ci][3][3] = A3^T m A3.  Block = 64 outputs (256-B rows of the
+// workspace) x 4 position lanes, 9 positions each; the first 64 threads apply the transform.
+__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                                       int cout, int cin) {
-  __shared__ float s_m[36][17];
-  const int il = threadIdx.x & 15, pp = threadIdx.x >> 4;
+  __shared__ float s_m[36][65];
+  const int il = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const long long n = (long long)cout * cin;
-  const long long idx = (long long)blockIdx.x * 16 + il;
-  float v = 0.f;
-  if (idx < n) {
-    const float* src = ws + (long long)pp * splits * n + idx;
-    int k = 0;
-    for (; k + 3 < splits; k += 4) {
-      const float v0 = src[k * n], v1 = src[(k + 1) * n], v2 = src[(k + 2) * n], v3 = src[(k + 3) * n];
-      v += v0; v += v1; v += v2; v += v3;
+  const long long idx = (long long)blockIdx.x * 64 + il;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int pp = pg * 9 + q;
+    float v = 0.f;
+    if (idx < n) {
+      const float* src = ws + (long long)pp * splits * n + idx;
+      int k = 0;
+      for (; k + 3 < splits; k += 4) {
+        const float v0 = src[k * n], v1 = src[(k + 1) * n], v2 = src[(k + 2) * n], v3 = src[(k + 3) * n];
+        v += v0; v += v1; v += v2; v += v3;
+      }
+      for (; k < splits; ++k) v += src[k * n];
     }
-    for (; k < splits; ++k) v += src[k * n];
+    s_m[pp][il] = v;
   }
-  s_m[pp][il] = v;
   __syncthreads();
-  if (threadIdx.x >= 16 || idx >= n) return;
+  if (threadIdx.x >= 64 || idx >= n) return;
   float s[3][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -541,6 +553,10 @@ __global__ __launch_bounds__(576) void wino4_dw_kernel(const float* __restrict__
     dst[i * 3 + 2] = r[2];
   }
 }
+
+// tiles reduced by one block of an output transform = one BatchNorm partial row; small maps get short blocks so
+// that the launch still covers the chip
+inline int tiles_per_block(long long T) { return T <= 2048 ? 8 : T <= 16384 ? 16 : kTilesPerBlock; }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline long long tiles_of(int batch, int h, int w, int m) { return (long long)batch * ((h + m - 1) / m) * ((w + m - 1) / m); }
@@ -575,7 +591,9 @@ extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int
 }
 
 extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
-  return (int)((tiles_of(batch, height, width, tile) + kTilesPerBlock - 1) / kTilesPerBlock);
+  const long long T = tiles_of(batch, height, width, tile);
+  const int tpb = tiles_per_block(T);
+  return (int)((T + tpb - 1) / tpb);
 }
 
 extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin, int tile) {
@@ -600,26 +618,25 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
                        width, TH, TW, cin, T);
   else
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
-                       width, TH, TW, cin, T);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V,
+                       height, width, TH, TW, cin, T);
   const int rows_pad = round_up(cout, 128);
   int rc = fsd_conv::conv_gemm_batched(V, cin, T * cin, u_packed, (long long)rows_pad * cin, Mb, cout, T * cout, T, cin, cout,
                                        P, stream);
   if (rc != 0) return rc;
-  const unsigned bx = (unsigned)((T + kTilesPerBlock - 1) / kTilesPerBlock);
-  const int cg = cout / 4;
+  const int tpb = tiles_per_block(T);
+  const unsigned bx = (unsigned)((T + tpb - 1) / tpb);
   if (tile == 2) {
-    hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial,
-                       height, width, TH, TW, cout, T);
-  } else if (cg <= 16) {
-    hipLaunchKernelGGL(wino4_output_kernel<16>, dim3(bx, (cg + 15) / 16), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                       bn_partial, height, width, TH, TW, cout, T);
-  } else if (cg <= 32) {
-    hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, 1), dim3(256), 0, stream, Mb, bias, y, y_ld, bn_partial, height,
-                       width, TH, TW, cout, T);
+    hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cout / 4 + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                       bn_partial, height, width, TH, TW, cout, T, tpb);
   } else {
-    hipLaunchKernelGGL(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                       bn_partial, height, width, TH, TW, cout, T);
+    const int cg = cout / 2;                                 // channel pairs
+    if (cg <= 32)
+      hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                         bn_partial, height, width, TH, TW, cout, T, tpb);
+    else
+      hipLaunchKernelGGL(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                         bn_partial, height, width, TH, TW, cout, T, tpb);
   }
   return (int)hipGetLastError();
 }
@@ -654,7 +671,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
       hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
     else
-      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
     V = Vw;
   }
@@ -671,6 +688,6 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (tile == 2)
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   else
-    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(576), 0, stream, ws, dw_oihw, splits, cout, cin);
+    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }
