@@ -127,6 +127,8 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0, g1 = L.fsd_event_create(), L.fsd_event_create()     # around the MFMA kernel alone
+        L.fsd_profile_next_gemm(g0, g1)
         e0.record()
     v = None
     if keep_v is not None:
@@ -138,7 +140,7 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
-        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles))
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles, g0, g1))
     return y, partial
 
 
@@ -165,7 +167,8 @@ def wino_tile(cin, cout, ksize, H, W):
 WINOGRAD = True     # Winograd for eligible fp32 3x3 layers (forward, data gradient, weight gradient)
 WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
 WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
-PROFILE = None      # bench.py sets this to a list: (start_event, end_event, algorithmic_flops, executed_mfma_flops) per conv launch
+PROFILE = None      # bench.py sets this to a list, one entry per conv launch: (start_event, end_event, algorithmic_flops,
+                    # executed_mfma_flops, gemm_start, gemm_stop) -- the last two are fsd_event handles around the MFMA kernel alone
 
 
 def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None):
@@ -183,8 +186,12 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
         tiles = (lib().fsd_conv_row_tiles_bf16(xv.pixels) if bf16
                  else lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize))
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
+    g0 = g1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if not bf16:
+            g0, g1 = lib().fsd_event_create(), lib().fsd_event_create()
+            lib().fsd_profile_next_gemm(g0, g1)
         e0.record()
     fn = lib().fsd_conv2d_fwd_bf16 if bf16 else lib().fsd_conv2d_fwd
     check(fn(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
@@ -193,7 +200,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
-                        2.0 * ksize * ksize * xv.C * cout * xv.pixels))
+                        2.0 * ksize * ksize * xv.C * cout * xv.pixels, g0, g1))
     return y, partial
 
 

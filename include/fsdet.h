@@ -250,6 +250,14 @@ int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dy
 int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
                  float weight_decay, int first_step, long long count, hipStream_t stream);
 
+/* Measurement aids (bench.py): HIP events owned by the library's runtime, and a one-shot hook that records a pair of
+ * them immediately before / after the NEXT fp32 MFMA convolution kernel (conv_gemm_kernel) this thread launches --
+ * inside fsd_conv2d_fwd or inside the Winograd pipeline -- on the stream that launch uses. */
+void* fsd_event_create(void);
+void fsd_event_destroy(void* event);
+float fsd_event_elapsed_ms(void* start, void* stop);   /* waits for `stop`; < 0 on error */
+void fsd_profile_next_gemm(void* start, void* stop);
+
 const char* fsd_version(void);
 
 #ifdef __cplusplus

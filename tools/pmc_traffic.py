@@ -1,13 +1,14 @@
 """Summarise rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) into HBM bytes per conv launch of
 bench.py.  A "conv launch" is what bench.py brackets with HIP events: one direct implicit-GEMM kernel, or the three
-kernels of the Winograd pipeline (input transform, 16 batched GEMMs, output transform).  FETCH_SIZE is doubled
+kernels of the Winograd pipeline (input transform, 36 or 16 batched GEMMs, output transform).  FETCH_SIZE is doubled
 (gfx950 correction, MI355X_MICROARCH.md section HBM); both counters are in KiB.
 Usage: python tools/pmc_traffic.py <fetch_prefix> <write_prefix> <steps_profiled> <conv_launches_per_step> <out.json>"""
 import csv
 import json
 import sys
 
-NEEDLES = ("conv_gemm_kernel", "conv_gemm_bf16_kernel", "wino_input_kernel", "wino_output_kernel")
+NEEDLES = ("conv_gemm_kernel", "conv_gemm_bf16_kernel", "wino_input_kernel", "wino_output_kernel", "wino4_input_kernel",
+           "wino4_output_kernel")
 
 
 def total(prefix, counter):
