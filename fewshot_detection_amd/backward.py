@@ -52,7 +52,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
             pgrads[id(bn.weight)] = s2
             if not rec["training"]:          # frozen statistics: dy = scale * dt
                 coef[1:].zero_()
-            if xv is first_input and net.compute_dtype == "f32" and ops.c4_bnfused_eligible(xv, cout, k):
+            if xv is first_input and ops.c4_bnfused_eligible(xv, cout, k):
                 # first layer: no data gradient is needed, so dy is formed inside the weight-gradient kernel
                 pgrads[id(conv.weight)] = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv,
                                                                        cin, cout, param=conv.weight)
@@ -62,12 +62,12 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
             pgrads[id(conv.bias)] = s1
         dy = dt
     kept = rec.get("wino_v")
-    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, net.compute_dtype,
-                                               wino_v=kept[0] if kept else None, param=conv.weight,
-                                               tile=rec.get("wino_tile") if kept else None)
+    wtile = rec.get("wino_tile") or 0
+    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32" if wtile else net.compute_dtype,
+                                               wino_v=kept[0] if kept else None, param=conv.weight, tile=wtile)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
-        tile = ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W) if net.compute_dtype == "f32" else 0
+        tile = ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)
         if tile:
             dx, _ = ops.conv3x3_wino(dyv, net.cache.get(conv.weight, 1, "wino%d" % tile), xv.C, tile=tile)
         else:
