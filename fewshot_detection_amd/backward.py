@@ -5,7 +5,8 @@ Per fused conv block (reverse of engine.Network._conv):
     dz (+ dz_full) --fsd_bn_act_pool_bwd--> dt, partial sums     (maxpool argmax recomputed from y)
     partial sums   --fsd_bn_bwd_finalize--> dgamma, dbeta, coefficients
     dt             --fsd_bn_bwd_apply-----> dy                  (in place; first layer: fused into its weight gradient,
-                                                                 fsd_conv3x3_wgrad_c4_bnfused)
+                                                                 fsd_conv3x3_wgrad_c4_bnfused; Winograd(4) layers: fused
+                                                                 with both gradient transforms, fsd_wino_grad_transforms)
     dy, x          --fsd_conv2d_wgrad-----> dW                  (split-K MFMA GEMM over pixels)
     dy, W flipped  --fsd_conv2d_fwd-------> dx                  (same implicit-GEMM kernel as the forward)
 """
@@ -56,6 +57,16 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
                 # first layer: no data gradient is needed, so dy is formed inside the weight-gradient kernel
                 pgrads[id(conv.weight)] = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv,
                                                                        cin, cout, param=conv.weight)
+                return
+            kept = rec.get("wino_v")
+            if (ops.FUSE_WINO_GRAD and kept and rec.get("wino_tile") == 4 and xv is not first_input and dt.C % 4 == 0
+                    and ops.wino_tile(dt.C, xv.C, k, xv.H, xv.W) == 4):
+                # Winograd(4) layer: BN backward + both gradient transforms in one pass over dt / y, dy never stored
+                vd, wt = ops.wino_grad_transforms(dt, yv, coef, rec["mean"], rec["invstd"])
+                pgrads[id(conv.weight)] = ops.conv2d_wgrad(dt, cout, xv, cin, k, "f32", wino_v=kept[0],
+                                                           param=conv.weight, tile=4, wt_in=wt)
+                dx, _ = ops.conv3x3_wino(dt, net.cache.get(conv.weight, 1, "wino4"), xv.C, tile=4, v_in=vd)
+                _accumulate(grads, xv, dx)
                 return
             ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
         elif conv.bias is not None:

@@ -401,6 +401,82 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
 }
 
+// Backward of a Winograd layer in ONE pass over the gradient: the BatchNorm backward dy = c1*(dt - c2 - xhat*c3)
+// (bn_bwd_apply) is formed in registers for the 6x6 patch, then BOTH transforms the layer's gradients need are written:
+//   Vd = B^T dy B            (input of the data-gradient GEMMs; patch = the 4x4 tile + 1 pixel of padding all round)
+//   Wt = G4 dy4 G4^T         (dy4 = the inner 4x4 of the same patch; operand of the weight-gradient GEMMs)
+// dt and y are read once (+ the patch overlap from L2) instead of three elementwise passes and two transform reads.
+__global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict__ dt, long long dt_ld,
+                                                        const float* __restrict__ y, long long y_ld,
+                                                        const float* __restrict__ coef, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ Vd,
+                                                        float* __restrict__ Wt, int H, int W, int TH, int TW, int C,
+                                                        long long T) {
+  const int cg = C >> 1;
+  const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
+  if (idx >= T * cg) return;
+  const int g = (int)(idx % cg);
+  const long long tile = idx / cg;
+  const int tx = (int)(tile % TW);
+  const long long t2 = tile / TW;
+  const int ty = (int)(t2 % TH);
+  const long long b = t2 / TH;
+  const f32x2 zero = {0.f, 0.f};
+  const f32x2 c1 = ld2(coef + g * 2), c2 = ld2(coef + C + g * 2), c3 = ld2(coef + 2 * C + g * 2);
+  const f32x2 mu = ld2(mean + g * 2), is = ld2(invstd + g * 2);
+  f32x2 d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int iy = 4 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = 4 * tx - 1 + j;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      if (ok) {
+        const long long pix = (b * H + iy) * (long long)W + ix;
+        const f32x2 tv = ld2(dt + pix * dt_ld + g * 2), yv = ld2(y + pix * y_ld + g * 2);
+        d[i][j] = c1 * (tv - c2 - (yv - mu) * is * c3);
+      } else {
+        d[i][j] = zero;
+      }
+    }
+  }
+  const long long ps = T * C;
+  {   // weight-gradient operand from the inner 4x4
+    f32x2 t[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 r[6];
+      g6x4(d[1][j + 1], d[2][j + 1], d[3][j + 1], d[4][j + 1], r);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) t[i][j] = r[i];
+    }
+    float* dst = Wt + tile * C + g * 2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      f32x2 r[6];
+      g6x4(t[i][0], t[i][1], t[i][2], t[i][3], r);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) st2(dst + (i * 6 + j) * ps, r[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {            // data-gradient operand: columns, then rows
+    f32x2 r[6];
+    bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], r);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i][j] = r[i];
+  }
+  float* dst = Vd + tile * C + g * 2;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x2 r[6];
+    bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], r);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) st2(dst + (i * 6 + j) * ps, r[j]);
+  }
+}
+
 // One block: GL channel pairs x 256/GL tile lanes over `tpb` tiles; writes y (+bias) and the BN partial sums.
 // The 6 rows of m are streamed: row r is transformed along its columns (u = A^T-row-pass) and accumulated into the
 // 4x4 output with the column weights A^T[:, r] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1),
@@ -602,24 +678,30 @@ extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin, in
 
 extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
                                     long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
-                                    float* v_keep, int batch, int height, int width, int cin, int cout, int tile,
-                                    hipStream_t stream) {
+                                    float* v_keep, const float* v_in, int batch, int height, int width, int cin,
+                                    int cout, int tile, hipStream_t stream) {
   (void)hipGetLastError();
-  if (!x || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile)) return FSD_ERR_ARG;
-  if (cin % 32 || (cout & 3) || (x_ld & 3) || (y_ld & 3) || x_ld < cin || y_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if ((!x && !v_in) || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile))
+    return FSD_ERR_ARG;
+  if (cin % 32 || (cout & 3) || (y_ld & 3) || y_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if (!v_in && ((x_ld & 3) || x_ld < cin)) return FSD_ERR_UNSUPPORTED;
   if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
   const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
   const long long T = tiles_of(batch, height, width, tile);
   const int P = npos(tile);
-  float* V = v_keep ? v_keep : reinterpret_cast<float*>(workspace);     // kept for the weight gradient if asked
+  float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * T * cin;
   const long long n_in = T * (cin / 4);
-  if (tile == 2)
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V, height,
-                       width, TH, TW, cin, T);
-  else
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, V,
-                       height, width, TH, TW, cin, T);
+  const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
+  if (!V) {
+    if (tile == 2)
+      hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T);
+    else
+      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T);
+    V = Vw;
+  }
   const int rows_pad = round_up(cout, 128);
   int rc = fsd_conv::conv_gemm_batched(V, cin, T * cin, u_packed, (long long)rows_pad * cin, Mb, cout, T * cout, T, cin, cout,
                                        P, stream);
@@ -649,13 +731,15 @@ extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int widt
 }
 
 extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld,
-                                      const float* v_kept, float* dw_oihw, void* workspace, size_t workspace_bytes,
-                                      int batch, int height, int width, int cin, int cout, int tile,
-                                      hipStream_t stream) {
+                                      const float* v_kept, const float* wt_in, float* dw_oihw, void* workspace,
+                                      size_t workspace_bytes, int batch, int height, int width, int cin, int cout,
+                                      int tile, hipStream_t stream) {
   (void)hipGetLastError();
-  if (!dy || (!x && !v_kept) || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile))
+  if ((!dy && !wt_in) || (!x && !v_kept) || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 ||
+      !tile_ok(tile))
     return FSD_ERR_ARG;
-  if ((cin & 3) || (cout & 3) || (dy_ld & 3) || dy_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if ((cin & 3) || (cout & 3)) return FSD_ERR_UNSUPPORTED;
+  if (!wt_in && ((dy_ld & 3) || dy_ld < cout)) return FSD_ERR_UNSUPPORTED;
   if (!v_kept && ((x_ld & 3) || x_ld < cin)) return FSD_ERR_UNSUPPORTED;
   if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
   const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
@@ -675,19 +759,37 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
                          height, width, TH, TW, cin, T);
     V = Vw;
   }
-  if (tile == 2)
-    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
-                       width, TH, TW, cout, T);
-  else
-    hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt, height,
-                       width, TH, TW, cout, T);
+  const float* Wg = wt_in;                                   // already transformed (fsd_wino_grad_transforms)
+  if (!Wg) {
+    if (tile == 2)
+      hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
+                         height, width, TH, TW, cout, T);
+    else
+      hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
+                         height, width, TH, TW, cout, T);
+    Wg = Wt;
+  }
   int splits = 0;
-  int rc = fsd_conv::wgrad_gemm_batched(Wt, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, P, &splits, stream);
+  int rc = fsd_conv::wgrad_gemm_batched(Wg, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, P, &splits, stream);
   if (rc != 0) return rc;
   const long long n = (long long)cout * cin;
   if (tile == 2)
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   else
     hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
+                                        const float* mean, const float* invstd, float* v_out, float* wt_out, int batch,
+                                        int height, int width, int channels, int tile, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dt || !y || !coef || !mean || !invstd || !v_out || !wt_out || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (tile != 4 || (channels & 3) || (dt_ld & 1) || (y_ld & 1) || dt_ld < channels || y_ld < channels) return FSD_ERR_UNSUPPORTED;
+  const int TH = (height + 3) / 4, TW = (width + 3) / 4;
+  const long long T = tiles_of(batch, height, width, 4);
+  const long long n = T * (channels / 2);
+  hipLaunchKernelGGL(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
+                     mean, invstd, v_out, wt_out, height, width, TH, TW, channels, T);
   return (int)hipGetLastError();
 }

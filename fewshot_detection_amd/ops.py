@@ -113,9 +113,10 @@ def pack_weight_wino(w, mode=0, tile=2):
     return out
 
 
-def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None, tile=2):
+def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None, tile=2, v_in=None):
     """Winograd F(tile x tile, 3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3).
-    keep_v: a list; the transformed input is appended to it (kept for the weight gradient)."""
+    keep_v: a list; the transformed input is appended to it (kept for the weight gradient).
+    v_in: an already transformed input (wino_grad_transforms); xv then only supplies the geometry."""
     L = lib()
     dev = xv.t.device
     y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
@@ -135,8 +136,8 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
         v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C, tile), dtype=torch.float32, device=dev)
         keep_v.append(v)
     check(L.fsd_wino_conv3x3_fwd(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                                 ws.data_ptr(), ws_bytes, _ptr(v), xv.B, xv.H, xv.W, xv.C, cout, tile, _stream()),
-          "fsd_wino_conv3x3_fwd")
+                                 ws.data_ptr(), ws_bytes, _ptr(v), _ptr(v_in), xv.B, xv.H, xv.W, xv.C, cout, tile,
+                                 _stream()), "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
@@ -166,6 +167,10 @@ def wino_tile(cin, cout, ksize, H, W):
 
 WINOGRAD = True     # Winograd for eligible fp32 3x3 layers (forward, data gradient, weight gradient)
 WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
+# One-pass BN backward + both gradient transforms (fsd_wino_grad_transforms).  Bit-identical to the separate kernels but
+# MEASURED SLOWER on MI355X (3.59 vs 3.04 ms per step: 72 loads + 72 stores per thread over two overlapping 6x6 patches
+# run at 4.5 TB/s at L2 level against 7.8 TB/s for the single-tensor transforms), so it is off by default.
+FUSE_WINO_GRAD = os.environ.get("FSD_FUSE_WINO_GRAD", "0") == "1"
 WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
 PROFILE = None      # bench.py sets this to a list, one entry per conv launch: (start_event, end_event, algorithmic_flops,
                     # executed_mfma_flops, gemm_start, gemm_stop) -- the last two are fsd_event handles around the MFMA kernel alone
@@ -294,10 +299,24 @@ def grad_dst(param, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None, tile=None):
+def wino_grad_transforms(dt, yv, coef, mean, invstd):
+    """BatchNorm backward + both Winograd(tile 4) gradient transforms in one pass: -> (Vd, Wt) for
+    conv3x3_wino(v_in=Vd, mode-1 weights) = data gradient and conv2d_wgrad(wt_in=Wt) = weight gradient."""
+    L = lib()
+    n = L.fsd_wino_v_elems(yv.B, yv.H, yv.W, yv.C, 4)
+    vd = torch.empty(n, dtype=torch.float32, device=yv.t.device)
+    wt = torch.empty(n, dtype=torch.float32, device=yv.t.device)
+    check(L.fsd_wino_grad_transforms(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                     vd.data_ptr(), wt.data_ptr(), yv.B, yv.H, yv.W, yv.C, 4, _stream()),
+          "fsd_wino_grad_transforms")
+    return vd, wt
+
+
+def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None, tile=None, wt_in=None):
     """dW (cout, cin, k, k) from dy (View, columns [0,cout)) and the conv's NHWC input xv.
     wino_v: the forward pass's transformed input (conv3x3_wino keep_v, same tile), saves its recomputation.
     tile: 0 direct / 2 / 4 Winograd form (default: wino_tile's choice for this shape).
+    wt_in: the already transformed gradient (wino_grad_transforms); dyv then only supplies the geometry.
     param: the parameter this is the gradient of (lets a trainer's gradient sink receive it directly)."""
     L = lib()
     dev = xv.t.device
@@ -307,8 +326,9 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
         ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, tile)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         dw = grad_dst(param, (cout, cin, 3, 3), dev)
-        check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, _ptr(wino_v), dw.data_ptr(), ws.data_ptr(),
-                                       ws_bytes, xv.B, xv.H, xv.W, cin, cout, tile, _stream()), "fsd_wino_conv3x3_wgrad")
+        check(L.fsd_wino_conv3x3_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, _ptr(wino_v), _ptr(wt_in), dw.data_ptr(),
+                                       ws.data_ptr(), ws_bytes, xv.B, xv.H, xv.W, cin, cout, tile, _stream()),
+              "fsd_wino_conv3x3_wgrad")
         return dw
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)

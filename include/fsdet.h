@@ -119,9 +119,11 @@ int fsd_wino_partial_rows(int batch, int height, int width, int tile);
 /* v_keep (nullable): if given, the transformed input B^T d B (fsd_wino_v_elems floats) is written there instead of
  * into the workspace, so that the weight gradient can reuse it (v_kept of fsd_wino_conv3x3_wgrad). */
 size_t fsd_wino_v_elems(int batch, int height, int width, int cin, int tile);
+/* v_in (nullable): an already transformed input (fsd_wino_grad_transforms); when given, x is not read. */
 int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
                          long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
-                         int batch, int height, int width, int cin, int cout, int tile, hipStream_t stream);
+                         const float* v_in, int batch, int height, int width, int cin, int cout, int tile,
+                         hipStream_t stream);
 
 /* First-layer 3x3 weight gradient (input with <= 4 channels stored as NHWC4, cout % 32 == 0) with the BatchNorm
  * backward fused into the operand load: dy = c1*(dt - c2 - xhat*c3) is formed in registers from dt (gradient w.r.t.
@@ -138,9 +140,18 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
  * multiplications).  v_kept (nullable): the forward pass's transformed input of the same tile size; when given, x is
  * not read. */
 size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile);
+/* wt_in (nullable): the already transformed gradient (fsd_wino_grad_transforms); when given, dy is not read. */
 int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, const float* v_kept,
-                           float* dw_oihw, void* workspace, size_t workspace_bytes, int batch, int height, int width,
-                           int cin, int cout, int tile, hipStream_t stream);
+                           const float* wt_in, float* dw_oihw, void* workspace, size_t workspace_bytes, int batch,
+                           int height, int width, int cin, int cout, int tile, hipStream_t stream);
+
+/* Backward of a BatchNorm + Winograd(tile 4) layer in one pass over the gradient: forms dy = c1*(dt - c2 - xhat*c3)
+ * (what fsd_bn_bwd_apply computes; coef from fsd_bn_bwd_finalize) in registers and writes both transformed operands the
+ * layer's gradients need: v_out = B^T dy B (v_in of fsd_wino_conv3x3_fwd with the mode-1 weights = data gradient) and
+ * wt_out = G4 dy G4^T (wt_in of fsd_wino_conv3x3_wgrad); fsd_wino_v_elems(batch, h, w, channels, 4) floats each. */
+int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
+                             const float* mean, const float* invstd, float* v_out, float* wt_out, int batch, int height,
+                             int width, int channels, int tile, hipStream_t stream);
 
 /* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
  * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;

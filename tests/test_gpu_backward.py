@@ -83,6 +83,31 @@ def test_wgrad_winograd_4x4_matches_fp64_autograd(dev, B, H, W, cin, cout):
     assert torch.equal(ops.conv2d_wgrad(gv, cout, xv, cin, 3, wino_v=kept[0], tile=4), dw)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 13, 13, 128, 256), (1, 26, 22, 64, 128), (3, 5, 7, 128, 128)])
+def test_fused_winograd_gradient_transforms_match_separate_path(dev, B, H, W, cin, cout):
+    """fsd_wino_grad_transforms + (v_in, wt_in) == fsd_bn_bwd_apply + the separate dy transforms, bit for bit."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(H * W + cin)
+    xv = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, generator=g).to(dev))
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dev)
+    yv = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev))
+    dt = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, generator=g).to(dev))
+    coef = (torch.rand(3, cout, generator=g) + 0.5).to(dev)
+    mean, invstd = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev)
+    kept = []
+    ops.conv3x3_wino(xv, ops.pack_weight_wino(w, 0, 4), cout, keep_v=kept, tile=4)
+    u1 = ops.pack_weight_wino(w, 1, 4)
+    vd, wt = ops.wino_grad_transforms(dt, yv, coef, mean, invstd)
+    dw_f = ops.conv2d_wgrad(dt, cout, xv, cin, 3, wino_v=kept[0], tile=4, wt_in=wt)
+    dx_f, _ = ops.conv3x3_wino(dt, u1, cin, tile=4, v_in=vd)
+    dy = ops.View(dt.t.clone(), B, H, W, cout)
+    ops.bn_bwd_apply(dy, yv, coef, mean, invstd)
+    dw_s = ops.conv2d_wgrad(dy, cout, xv, cin, 3, wino_v=kept[0], tile=4)
+    dx_s, _ = ops.conv3x3_wino(dy, u1, cin, tile=4)
+    assert torch.equal(dw_f, dw_s)
+    assert torch.equal(dx_f.t, dx_s.t)
+
+
 def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
     from fewshot_detection_amd import ops
     g = torch.Generator().manual_seed(5)
