@@ -27,6 +27,8 @@ PROTOTYPES = {
     "fsd_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fsd_conv_row_tiles": (_i, [_ll, _i, _i, _i]),
     "fsd_conv2d_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_conv3x3_c4_partial_rows": (_i, [_i, _i, _i]),
+    "fsd_conv3x3_c4_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_wino_packed_weight_elems": (_sz, [_i, _i, _i]),
     "fsd_wino_pack_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fsd_wino_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -1,0 +1,154 @@
+// First-layer 3x3 convolution (input with <= 4 channels stored as NHWC4): K = 9 taps x 4 channels = 36 is far too
+// short for the LDS-staged implicit-GEMM kernel (two k-chunks per tile: all prologue and epilogue, 2.4 TB/s).  This
+// layer is HBM-bound -- it writes 32 channels for every 16-byte input pixel -- so the kernel is organised around the
+// stores:  persistent waves, no LDS staging, MFMA operands loaded straight into registers.
+//   v_mfma_f32_32x32x2_f32, 18 k-steps; step s, lane half h  <->  tap = s >> 1, channel = 2h + (s & 1):
+//                            A[pixel][s,h] = x[pixel + tap][channel]   B[s,h][co] = w[co][channel][tap]
+//   so each lane half needs two ADJACENT channels of every tap: one 8-byte load per tap per lane (L1/L2-resident),
+//   issued one tile ahead of the MFMAs; 18 + 18 registers of prefetch, 18 of weights (loaded once per wave).
+//   D[pixel][co]: 32 lanes store 128 contiguous bytes per pixel.
+//   BatchNorm partial sums (sum y, sum y^2 per channel) accumulate in registers over the wave's whole pixel run and
+//   leave as ONE partial row per block.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fsdet.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FirstFwdArgs {
+  const float* x; const float* w; const float* bias; float* y; float* partial;
+  unsigned x_ld, y_ld;
+  int H, W, cin, Cout;
+  long long pixels;
+  int ppw;                          // pixels per wave (multiple of 32)
+};
+
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
+  __shared__ float s_red[4][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int co = blockIdx.y * 32 + c;
+  float bw[18];
+#pragma unroll
+  for (int s = 0; s < 18; ++s) {
+    const int tap = s >> 1, ci = 2 * h + (s & 1);
+    bw[s] = ci < p.cin ? p.w[((size_t)co * p.cin + ci) * 9 + tap] : 0.f;
+  }
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const long long p_begin = ((long long)blockIdx.x * 4 + wave) * p.ppw;
+  const long long p_end = p_begin + p.ppw < p.pixels ? p_begin + p.ppw : p.pixels;
+  const char* x_b = reinterpret_cast<const char*>(p.x);
+  const f32x2 zero2 = {0.f, 0.f};
+  const unsigned hw = (unsigned)(p.H * p.W);
+  float s1 = 0.f, s2 = 0.f;
+
+  auto load = [&](long long base, f32x2 (&pt)[9]) {       // this half's channel pair of the 9 tap pixels of pixel c
+    const long long pix = base + c;
+    const bool valid = pix < p_end;
+    const unsigned upix = (unsigned)(valid ? pix : p_begin);            // < 2^31 (launcher check): 32-bit divisions
+    const unsigned rem = upix % hw;
+    const int yy = (int)(rem / (unsigned)p.W), xx = (int)(rem - (unsigned)yy * (unsigned)p.W);
+    const unsigned off = upix * p.x_ld * 4u + 8u * h;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = valid && (unsigned)(yy + dy) < (unsigned)p.H && (unsigned)(xx + dx) < (unsigned)p.W;
+      const f32x2 v = *reinterpret_cast<const f32x2*>(x_b + (ok ? off + (unsigned)((dy * p.W + dx) * (int)p.x_ld * 4) : 0u));
+      pt[t] = ok ? v : zero2;
+    }
+  };
+  auto compute = [&](long long base, const f32x2 (&pt)[9]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[s >> 1][s & 1], bw[s], acc, 0, 0, 0);
+    }
+    // rows of this lane: (r & 3) + 8 * (r >> 2) + 4h; byte offsets advance by whole pixel rows of y
+    char* y_b = reinterpret_cast<char*>(p.y);
+    const unsigned ys = p.y_ld * 4u;
+    unsigned off = ((unsigned)base + 4u * h) * ys + (unsigned)co * 4u;
+    if (base + 32 <= p_end) {                        // whole tile inside this wave's run (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        *reinterpret_cast<float*>(y_b + off) = v + bv;
+        s1 += v;
+        s2 += v * v;
+        off += ((r & 3) == 3) ? 5u * ys : ys;
+      }
+    } else {
+      const int left = (int)(p_end - base);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((r & 3) + 8 * (r >> 2) + 4 * h < left) {
+          const float v = acc[r];
+          *reinterpret_cast<float*>(y_b + off) = v + bv;
+          s1 += v;
+          s2 += v * v;
+        }
+        off += ((r & 3) == 3) ? 5u * ys : ys;
+      }
+    }
+  };
+
+  if (p_begin < p_end) {
+    f32x2 p0[9], p1[9];
+    load(p_begin, p0);
+    for (long long base = p_begin; base < p_end; base += 64) {
+      load(base + 32, p1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(base, p0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(base + 64, p0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (base + 32 < p_end) compute(base + 32, p1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (p.partial == nullptr) return;
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (h == 0) { s_red[wave][c][0] = s1; s_red[wave][c][1] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float* dst = p.partial + ((size_t)blockIdx.x * p.Cout + co) * 2;
+    dst[0] = s_red[0][c][0] + s_red[1][c][0] + s_red[2][c][0] + s_red[3][c][0];
+    dst[1] = s_red[0][c][1] + s_red[1][c][1] + s_red[2][c][1] + s_red[3][c][1];
+  }
+}
+
+inline int first_fwd_blocks(long long pixels) {
+  long long b = (pixels + 4 * 256 - 1) / (4 * 256);        // at least 256 pixels per wave
+  return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+
+extern "C" int fsd_conv3x3_c4_partial_rows(int batch, int height, int width) {
+  return first_fwd_blocks((long long)batch * height * width);
+}
+
+extern "C" int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w_oihw, const float* bias, float* y,
+                                  long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                                  hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !w_oihw || !y || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (cin < 1 || cin > 4 || cout % 32 || x_ld < 4 || (x_ld & 3) || y_ld < cout) return FSD_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15)) return FSD_ERR_ARG;
+  const long long pixels = (long long)batch * height * width;
+  if ((pixels + width + 66) * (x_ld > y_ld ? x_ld : y_ld) * 4 >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit byte offsets
+  const int blocks = first_fwd_blocks(pixels);
+  FirstFwdArgs a;
+  a.x = x; a.w = w_oihw; a.bias = bias; a.y = y; a.partial = bn_partial;
+  a.x_ld = (unsigned)x_ld; a.y_ld = (unsigned)y_ld;
+  a.H = height; a.W = width; a.cin = cin; a.Cout = cout; a.pixels = pixels;
+  const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
+  a.ppw = (int)((per + 63) / 64 * 64);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  return (int)hipGetLastError();
+}

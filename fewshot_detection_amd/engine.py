@@ -128,7 +128,8 @@ class Network(object):
         # Winograd layers always run the fp32 Winograd pipeline: in bf16 mode it is both faster and more accurate than
         # the bf16 direct kernel (4x fewer multiplications beat the bf16 MFMA rate of a staging-bound kernel)
         wino = ops.wino_tile(xv.C, cout, k, xv.H, xv.W)
-        wp = self.cache.get(conv.weight, 0, "wino%d" % wino if wino else self.compute_dtype)
+        first = not wino and ops.c4_bnfused_eligible(xv, cout, k)        # NHWC4 input: direct-operand first-layer kernel
+        wp = None if first else self.cache.get(conv.weight, 0, "wino%d" % wino if wino else self.compute_dtype)
         dev = xv.t.device
         cin_true = conv.weight.shape[1]
         # Winograd layers keep their transformed input for the weight gradient when a backward pass will follow
@@ -139,6 +140,8 @@ class Network(object):
             z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
             if wino:
                 ops.conv3x3_wino(xv, wp, cout, bias=conv.bias, out=z, keep_v=keep, tile=wino)
+            elif first:
+                ops.conv3x3_c4(xv, conv.weight, cout, bias=conv.bias, out=z)
             else:
                 ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
             rec.update(y=z, z=z, z_full=None)
@@ -147,6 +150,9 @@ class Network(object):
         if wino:
             y, partial = ops.conv3x3_wino(xv, wp, cout, bias=None if bn is not None else conv.bias,
                                           bn_partial=bn is not None and training, keep_v=keep, tile=wino)
+        elif first:
+            y, partial = ops.conv3x3_c4(xv, conv.weight, cout, bias=None if bn is not None else conv.bias,
+                                        bn_partial=bn is not None and training)
         else:
             y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
                                     bn_partial=bn is not None and training, cin_true=cin_true)

@@ -209,6 +209,26 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     return y, partial
 
 
+def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False):
+    """First-layer 3x3 convolution of an NHWC4 view straight from the OIHW weights (HBM-bound direct-operand kernel)."""
+    L = lib()
+    dev = xv.t.device
+    y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
+    partial = None
+    if bn_partial:
+        partial = torch.empty((L.fsd_conv3x3_c4_partial_rows(xv.B, xv.H, xv.W), cout, 2), dtype=torch.float32, device=dev)
+    cin = w.shape[1]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(L.fsd_conv3x3_c4_fwd(xv.ptr, xv.ld, w.detach().contiguous().data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+                               xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_c4_fwd")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels, None, None))
+    return y, partial
+
+
 def bn_finalize(partial, count, bn, training):
     """-> (scale, shift, save_mean, save_invstd) for nn.BatchNorm2d-like `bn` (updates running stats)."""
     Cc = bn.num_features

@@ -105,6 +105,13 @@ int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const 
                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
                    int cout, int ksize, int out_nchw, hipStream_t stream);
 
+/* First-layer 3x3 convolution (input with <= 4 channels stored as NHWC4, x_ld >= 4; cout % 32 == 0): HBM-bound
+ * direct-operand MFMA kernel without LDS staging.  Takes the OIHW weights as they are (no packing).  Same results and
+ * contract as fsd_conv2d_fwd(ksize = 3, out_nchw = 0); bn_partial is [fsd_conv3x3_c4_partial_rows][cout][2]. */
+int fsd_conv3x3_c4_partial_rows(int batch, int height, int width);
+int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w_oihw, const float* bias, float* y, long long y_ld,
+                       float* bn_partial, int batch, int height, int width, int cin, int cout, hipStream_t stream);
+
 /* Winograd form of the fp32 3x3 convolution: input transform -> (tile+2)^2 batched GEMMs on the fp32 MFMA kernel ->
  * output transform (+bias, + BatchNorm partial sums [fsd_wino_partial_rows][cout][2]).
  *   tile = 2: F(2x2,3x3), 16 positions, 2.25x fewer multiplications, round-off ~1e-6 of the output magnitude

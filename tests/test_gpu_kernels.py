@@ -54,6 +54,30 @@ def test_conv_forward_matches_fp64_reference(dev, B, H, W, cin, cout, k, bias):
         assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,bias", [(2, 20, 24, 3, 32, False), (1, 13, 13, 4, 64, True), (3, 416, 64, 3, 32, False),
+                                                  (2, 1, 2, 3, 32, False), (5, 7, 5, 4, 32, False)])
+def test_first_layer_conv_matches_fp64_reference(dev, B, H, W, cin, cout, bias):
+    """fsd_conv3x3_c4_fwd (direct-operand MFMA, OIHW weights) incl. its BatchNorm partial sums."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.zeros(B, 4, H, W)
+    x[:, :cin] = torch.randn(B, cin, H, W, generator=g)
+    if cin == 3:
+        x[:, 3] = 7.0                                      # the padding channel must not leak into the result
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = F.conv2d(x[:, :cin].double(), w.double(), None if b is None else b.double(), 1, 1).float()
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    yv, part = ops.conv3x3_c4(xv, w.to(dev), cout, bias=None if b is None else b.to(dev), bn_partial=not bias)
+    y = ops.nhwc_to_nchw(yv).cpu()
+    assert torch.allclose(y, ref, rtol=1e-4, atol=2e-5), float((y - ref).abs().max())
+    if part is not None:
+        p = part.double().sum(0).cpu()
+        flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
+        assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
+
+
 def test_conv_nchw_store_and_asymmetric_weights(dev):
     """Transposed-accumulator epilogue: identity-like input with an ASYMMETRIC weight catches row/col swaps."""
     from fewshot_detection_amd import ops
