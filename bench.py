@@ -198,13 +198,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (Functional check of the N>1 path on a single-GPU box: FSD_BENCH_BACKEND=gloo lets several ranks
+    # share device 0 -- RCCL refuses two ranks on one device; tests/test_gpu_dp.py uses this.)
+    backend = os.environ.get("FSD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fewshot_detection_amd import backward as bw
     from fewshot_detection_amd import cfgs, ops

@@ -1,0 +1,99 @@
+"""The N>1 path on the real kernels.  The driver's GPU box has ONE MI355X and RCCL refuses two ranks on one device, so
+these tests run two ranks on device 0 with the gloo backend (it reduces device tensors through the host): everything of
+the data-parallel path except the RCCL transport itself -- flat buffers, gradient sink, bucketed async all-reduce, the
+fused HIP SGD kernel, bench.py's rank handling and its single JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _episode(B, N, S=96):
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, S, S, generator=g)
+    metax = torch.rand(N, 3, S, S, generator=g)
+    mask = torch.zeros(N, 1, S, S)
+    mask[:, :, 10:60, 20:70] = 1
+    tgt = torch.zeros(B, N, 250, dtype=torch.float64)
+    for b in range(B):
+        n = b % N
+        tgt[b, n, :5] = torch.tensor([n, 0.3 + 0.05 * b, 0.5, 0.3, 0.4], dtype=torch.float64)
+    return x, metax, mask, tgt
+
+
+def _train(rank, world, steps, dist_mod):
+    """`steps` SGD steps of the mini meta-detector on this rank's shard of a B=4 episode (frozen BN statistics, so that
+    the loss -- hence the gradient -- is a plain sum over images and R ranks must reproduce one full-batch process)."""
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    dev = torch.device("cuda:0")
+    cfg.neg_ratio = "full"
+    torch.manual_seed(3)
+    net = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg")).to(dev).eval()
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    region.seen = 20000
+    x, metax, mask, tgt = _episode(4, 3)
+    per = 4 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    x, tgt = x[sl].to(dev), tgt[sl]
+    tr = EpisodeTrainer(net, lr=1e-4, momentum=0.9, weight_decay=0.01, process_group=dist_mod, n_buckets=3)
+    for _ in range(steps):
+        tr.backward_and_step(region(net(x, metax.to(dev), mask.to(dev)), tgt))
+    return tr.flat.detach().cpu()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = _train(rank, world, 3, dist)
+    torch.save(flat, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_one_full_batch_process(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    assert torch.equal(r0, r1)                                   # replicas stay bit-identical
+    ref = _train(0, 1, 3, None)
+    assert float((r0 - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    moved = _train(0, 1, 0, None)
+    assert float((ref - moved).abs().max()) > 1e-6                # the steps really changed the parameters
+
+
+def test_bench_two_ranks_one_json_line():
+    env = dict(os.environ, FSD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+           "2", "--warmup", "1", "--batch", "4", "--classes", "3", "--size", "160", "--support", "160"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    # (the gloo transport itself announces its ranks on stdout; RCCL does not)
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    assert len(lines) == 1, out.stdout                            # rank 0 prints exactly one line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 8
+    assert res["value"] > 0 and "roofline" in res and "cpu_baseline" not in res
