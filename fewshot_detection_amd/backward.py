@@ -111,7 +111,9 @@ def run(net, tape, grad_out, params):
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn
             if head.bias is not None:
-                pgrads[id(head.bias)] = ops.colsum(g, rows).view(n_cls, o_ch).sum(0)
+                dst = ops.grad_dst(head.bias, (o_ch,), g.t.device)
+                torch.sum(ops.colsum(g, rows).view(n_cls, o_ch), dim=0, out=dst)
+                pgrads[id(head.bias)] = dst
         elif kind == "globalmax":
             x = rec["x"]
             _accumulate(grads, x, ops.global_maxpool_bwd(grad_out.reshape(x.B, x.C), rec["arg"], x))

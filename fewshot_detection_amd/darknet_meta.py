@@ -202,6 +202,8 @@ class _NetFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         from . import backward as bw
         grads = bw.run(ctx.net, ctx.tape, grad_out.contiguous(), ctx.params)
+        if ops.GRAD_HOOK is not None:
+            ops.GRAD_HOOK()
         head = [None] * ctx.n_inputs + ([grads["dyn"]] if ctx.has_dyn else [])
         return (None, None, None, None) + tuple(head) + tuple(grads["params"])
 

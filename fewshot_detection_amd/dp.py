@@ -49,9 +49,14 @@ class EpisodeTrainer(object):
         self.mom = torch.zeros_like(self.flat)
         self.buckets = bucket_bounds(self.flat.numel(), n_buckets)
         self.sink, off = {}, 0               # parameter -> its slice of the flat gradient buffer
+        self._bucket_params = [[] for _ in self.buckets]         # ids of the parameters overlapping each bucket
         for p in self.params:
             self.sink[id(p)] = self.grad[off:off + p.numel()]
+            for i, (lo, hi) in enumerate(self.buckets):
+                if off < hi and off + p.numel() > lo:
+                    self._bucket_params[i].append(id(p))
             off += p.numel()
+        self._works = [None] * len(self.buckets)
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
 
@@ -74,16 +79,25 @@ class EpisodeTrainer(object):
                 p.grad = None
             off += n
 
+    def _launch_ready(self, sunk, final=False):
+        """Start the all-reduce of every bucket whose gradients are complete (all of its parameters were written by
+        the backward kernels, or -- `final` -- everything has been gathered).  Called once per network as its backward
+        finishes (ops.GRAD_HOOK), so the reduction of the detector's buckets runs under the reweighting net's backward;
+        every rank launches the same buckets in the same order."""
+        if self.dist is None or self.dist.get_world_size() <= 1:
+            return
+        for i, (lo, hi) in enumerate(self.buckets):
+            if self._works[i] is None and (final or all(pid in sunk for pid in self._bucket_params[i])):
+                self._works[i] = self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True)
+
     def reduce_and_step(self):
         """Bucketed SUM all-reduce overlapped with the per-bucket optimizer kernel."""
-        works = []
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            for lo, hi in self.buckets:
-                works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+        self._launch_ready((), final=True)
         for i, (lo, hi) in enumerate(self.buckets):
-            if works:
-                works[i].wait()
+            if self._works[i] is not None:
+                self._works[i].wait()
             self._step_fn(lo, hi)
+        self._works = [None] * len(self.buckets)
         self.steps += 1
         bump_weight_epoch()
 
@@ -91,10 +105,12 @@ class EpisodeTrainer(object):
         # While this backward runs, the HIP gradient kernels write dW / dgamma / dbeta straight into the flat
         # buffer (ops.GRAD_SINK); whatever still arrives through autograd is gathered afterwards.
         ops.GRAD_SINK, ops.GRAD_SUNK = self.sink, set()
+        ops.GRAD_HOOK = lambda: self._launch_ready(ops.GRAD_SUNK)
         try:
             loss.backward()
             sunk = ops.GRAD_SUNK
         finally:
-            ops.GRAD_SINK, ops.GRAD_SUNK = None, set()
+            ops.GRAD_SINK, ops.GRAD_SUNK, ops.GRAD_HOOK = None, set(), None
+        # a bucket that is already being reduced had all of its parameters sunk: nothing of it is left to gather
         self.gather_grads(sunk)
         self.reduce_and_step()

@@ -307,6 +307,7 @@ def _fold_reweight_head_f32(head_w, head_b, dyn):
 
 GRAD_SINK = None    # dp.EpisodeTrainer: {id(param): 1-D view into its flat gradient buffer} while a step's backward runs
 GRAD_SUNK = set()   # ids of the parameters whose gradient the kernels wrote straight into the sink
+GRAD_HOOK = None    # called after each network's backward sweep (the trainer starts the all-reduce of finished buckets)
 
 
 def grad_dst(param, shape, device):
