@@ -174,8 +174,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="query images per GPU")
     ap.add_argument("--classes", type=int, default=15, help="episode classes N")
     ap.add_argument("--size", type=int, default=416)
