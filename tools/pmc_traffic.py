@@ -8,7 +8,7 @@ import json
 import sys
 
 NEEDLES = ("conv_gemm_kernel", "conv_gemm_bf16_kernel", "wino_input_kernel", "wino_output_kernel", "wino4_input_kernel",
-           "wino4_output_kernel")
+           "wino4_output_kernel", "conv_first_kernel")
 
 
 def total(prefix, counter):
