@@ -402,13 +402,14 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   static const char* env = getenv("FSD_WINO_TILE");
   const char pick = env ? env[0] : (cin >= 1024 && cout % 128 == 0 ? 'd' : 'a');
   const int big = pick == 'c' || pick == 'd';
-  const int bm = big ? 128 : 64;
+  const int bm = (big || pick == 'e') ? 128 : 64, bn = big ? 128 : 64;
   a.m_tiles = (int)((rows + bm - 1) / bm);
-  a.n_tiles = (cout + bm - 1) / bm;
+  a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
   a.part_base = 0;
   a.batches = batches;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
+  if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (big) return pick == 'c' ? launch<128, 128, 2, 2, 2>(a, false, stream) : launch<128, 128, 2, 2, 2, true>(a, false, stream);
   return launch<64, 64, 2, 2, 1>(a, false, stream);
 }

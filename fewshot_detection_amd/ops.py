@@ -362,7 +362,9 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
 
 def c4_bnfused_eligible(xv, cout, ksize):
     """First-layer shape: NHWC4 input, 3x3, cout a multiple of 32 (darknet L0, reweighting-net L0)."""
-    return ksize == 3 and xv.C == 4 and xv.ld == 4 and cout % 32 == 0 and xv.W >= 2
+    # the first-layer kernels address with 32-bit byte offsets: the (pixels, cout) activation must stay below 4 GiB
+    fits = (xv.pixels + xv.W + 66) * max(4, cout) * 4 < 0xffffffff
+    return ksize == 3 and xv.C == 4 and xv.ld == 4 and cout % 32 == 0 and xv.W >= 2 and fits
 
 
 def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout, param=None):
