@@ -223,6 +223,39 @@ def gold_decode(u):
              nms_thresh=0.45, boxes=np.array(flat, np.float64), kept=np.array(kept, np.float64))
 
 
+def gold_episode(im):
+    """image.fill_truth_detection_meta / fill_truth_detection on random label files (out-of-range boxes, degenerate
+    boxes, classes outside the base set, more than 50 boxes)."""
+    import tempfile
+    rng = np.random.RandomState(7)
+    cases = {}
+    base_ids = [0, 2, 3, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 18, 19]
+    im.cfg.base_ids = base_ids
+    im.cfg.base_classes = ["c%d" % i for i in base_ids]
+    im.cfg.yolo_joint = False
+    im.cfg.metaids = []
+    tmp = tempfile.mkdtemp()
+    for k, nbox in enumerate([0, 1, 7, 30, 80]):
+        rows = np.zeros((nbox, 5))
+        rows[:, 0] = rng.randint(0, 20, nbox)
+        rows[:, 1:3] = rng.uniform(-0.1, 1.1, (nbox, 2))
+        rows[:, 3:5] = rng.uniform(0.0005, 0.6, (nbox, 2))
+        flip = int(rng.randint(0, 2))
+        sx, sy = rng.uniform(0.7, 1.3, 2)
+        dx, dy = rng.uniform(-0.2, 0.2, 2)
+        path = os.path.join(tmp, "%06d.txt" % k)
+        if nbox:
+            np.savetxt(path, rows, fmt="%.17g")
+        else:
+            open(path, "w").close()
+        cases["in%d" % k] = rows
+        cases["par%d" % k] = np.array([flip, dx, dy, sx, sy])
+        cases["meta%d" % k] = im.fill_truth_detection_meta(path, 416, 416, flip, dx, dy, sx, sy)
+        cases["det%d" % k] = im.fill_truth_detection(path, 416, 416, flip, dx, dy, sx, sy)
+    cases["base_ids"] = np.array(base_ids)
+    np.savez_compressed(os.path.join(HERE, "episode.npz"), **cases)
+
+
 def main():
     assert ref_shim.available(), "needs /root/reference"
     u = ref_shim.load("utils")
@@ -238,6 +271,7 @@ def main():
     gold_region_v2(rl, cfgmod)
     gold_region_v1(rl, cfgmod)
     gold_decode(u)
+    gold_episode(ref_shim.load("image"))
     print("golden vectors written to", HERE)
 
 

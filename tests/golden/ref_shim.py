@@ -129,7 +129,7 @@ def load(name):
     saved = {}
     deps = {"cfg": ["utils"], "region_loss": ["utils", "cfg"],
             "darknet_meta": ["utils", "cfg", "region_loss", "dynamic_conv", "pooling"],
-            "darknet": ["utils", "cfg", "region_loss"]}.get(name, [])
+            "darknet": ["utils", "cfg", "region_loss"], "image": ["cfg"]}.get(name, [])
     for d in deps:
         saved[d] = sys.modules.get(d)
         sys.modules[d] = load(d)
