@@ -306,6 +306,67 @@ def test_plain_yolo_backward_vs_oracle(dev):
         cfg.metayolo = True
 
 
+def _wide_yolo_cfg(path):
+    """A plain detector wide enough for every conv form: first-layer kernel (3->32), direct 3x3 (32->64), Winograd
+    F(4x4) (64->128, 128->128 @16x16; 128->256 @8x8), 1x1, a biased head, RegionLoss v1."""
+    def conv(f, k, bn=1, act="leaky"):
+        return "[convolutional]\n%sfilters=%d\nsize=%d\nstride=1\npad=1\nactivation=%s\n\n" % (
+            "batch_normalize=1\n" if bn else "", f, k, act)
+    pool = "[maxpool]\nsize=2\nstride=2\n\n"
+    txt = ("[net]\nbatch=2\nwidth=64\nheight=64\nchannels=3\n\n" + conv(32, 3) + pool + conv(64, 3) + pool + conv(128, 3)
+           + conv(128, 3) + pool + conv(256, 3) + conv(128, 1) + conv(256, 3) + conv(40, 1, bn=0, act="linear")
+           + "[region]\nanchors = 1.08,1.19,  3.42,4.41,  6.63,11.38,  9.42,5.11,  16.62,10.52\nbias_match=1\nclasses=3\n"
+             "coords=4\nnum=5\nsoftmax=1\njitter=.2\nrescore=1\nobject_scale=5\nnoobject_scale=1\nclass_scale=1\n"
+             "coord_scale=1\nabsolute=1\nthresh = .6\nrandom=1\n")
+    open(path, "w").write(txt)
+    return path
+
+
+def test_wide_detector_three_sgd_steps_follow_the_oracle(dev, tmp_path):
+    """Trajectory test over every conv form (incl. Winograd with kept V, the fused first-layer weight gradient and the
+    gradient sink): three SGD steps on the HIP path == oracle + torch.optim.SGD on the CPU."""
+    from fewshot_detection_amd import ops
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet import Darknet
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    from oracle.net import OracleYolo
+    from oracle.region import region_loss_v1
+    c = _wide_yolo_cfg(os.path.join(str(tmp_path), "wide.cfg"))
+    assert ops.wino_tile(64, 128, 3, 16, 16) == 4 and ops.wino_tile(128, 256, 3, 8, 8) == 4
+    torch.manual_seed(13)
+    ora = OracleYolo(c).train()
+    net = Darknet(c)
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train()
+    x = torch.rand(4, 3, 64, 64)
+    tgt = torch.zeros(4, 250, dtype=torch.float64)
+    for b in range(4):
+        tgt[b, :5] = torch.tensor([b % 3, 0.3 + 0.1 * b, 0.5, 0.3, 0.4])
+    cfg.neg_ratio, cfg.metayolo = "full", False
+    try:
+        region = net.models[len(net.models) - 1]
+        region.verbose = False
+        lr, mom, wd = 2e-5, 0.9, 5e-3
+        trainer = EpisodeTrainer(net, lr=lr, momentum=mom, weight_decay=wd)
+        opt = torch.optim.SGD(ora.parameters(), lr=lr, momentum=mom, weight_decay=wd)
+        for step in range(3):
+            loss = region(net(x.to(dev)), tgt)
+            trainer.backward_and_step(loss)
+            opt.zero_grad()
+            r = region_loss_v1(ora(x), tgt, ora.region.anchors, 5, 3)
+            r["loss"].backward()
+            opt.step()
+            assert abs(float(loss.detach()) - float(r["loss"])) < 2e-3 * max(1.0, abs(float(r["loss"]))), step
+        ref = dict(ora.named_parameters())
+        for name, p in net.named_parameters():
+            # BN biases start at 0 and have moved by ~1e-4 after three steps: scale the tolerance by at least 1e-3
+            r_ = ref[name].detach()
+            err = float((p.detach().cpu() - r_).abs().max())
+            assert err < 2e-3 * max(1e-3, float(r_.abs().max())), (name, err)
+    finally:
+        cfg.metayolo = True
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [(2, 13, 13, 64, 128, 3), (3, 9, 7, 3, 32, 3), (2, 13, 13, 256, 30, 1),
                                                (2, 13, 13, 1280, 1024, 3), (3, 52, 52, 64, 128, 3)])
 def test_wgrad_bf16_matches_bf16_rounded_reference(dev, B, H, W, cin, cout, k):
