@@ -73,7 +73,11 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_reproduce_one_full_batch_process(tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    except Exception as e:  # noqa: BLE001  (rendezvous port race: one retry on a fresh port)
+        sys.stderr.write("two-rank spawn failed once: %r\n" % (e,))
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
     assert torch.equal(r0, r1)                                   # replicas stay bit-identical
@@ -85,14 +89,20 @@ def test_two_ranks_reproduce_one_full_batch_process(tmp_path):
 
 def test_bench_two_ranks_one_json_line():
     env = dict(os.environ, FSD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
-           "2", "--warmup", "1", "--batch", "4", "--classes", "3", "--size", "160", "--support", "160"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    for attempt in range(2):            # the rendezvous port is picked, released and re-bound by torchrun: allow one retry
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+               "2", "--warmup", "1", "--batch", "4", "--classes", "3", "--size", "160", "--support", "160"]
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            break
+        sys.stderr.write("bench.py --gpus 2 attempt %d failed:\n%s\n" % (attempt, out.stderr[-3000:]))
     assert out.returncode == 0, out.stderr[-2000:]
-    # (the gloo transport itself announces its ranks on stdout; RCCL does not)
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
-    assert len(lines) == 1, out.stdout                            # rank 0 prints exactly one line
+    # The gloo transport announces its ranks on stdout (RCCL does not), unsynchronised with our line: take the JSON
+    # object itself and require that exactly one was printed.
+    assert out.stdout.count('{"metric"') == 1, out.stdout
+    start = out.stdout.index('{"metric"')
+    lines = [out.stdout[start:].splitlines()[0]]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
     assert res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 8
