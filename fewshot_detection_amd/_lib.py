@@ -48,6 +48,7 @@ PROTOTYPES = {
     "fsd_bn_finalize": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
     "fsd_bn_act_pool_fwd": (_i, [_p, _ll, _p, _p, _f, _i, _p, _ll, _i, _i, _i, _i, _p]),
     "fsd_transpose_batched": (_i, [_p, _ll, _ll, _p, _ll, _ll, _i, _i, _i, _p]),
+    "fsd_nchw_to_nhwc4": (_i, [_p, _p, _i, _i, _ll, _p]),
     "fsd_fill": (_i, [_p, _f, _ll, _p]),
     "fsd_reorg_fwd": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
     "fsd_global_maxpool_fwd": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),

@@ -157,6 +157,22 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// (B, C<=4, HW) planes -> (B*HW, 4) pixels, missing channels zero: one thread per pixel, coalesced plane reads and
+// one 16-byte store (the 32x32 LDS transpose wastes 29 of its 32 rows on a 3-channel image)
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                            long long hw, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / hw, pix = i - b * hw;
+  const float* s = src + b * C * hw + pix;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  v[0] = s[0];
+  if (C > 1) v[1] = s[hw];
+  if (C > 2) v[2] = s[2 * hw];
+  if (C > 3) v[3] = s[3 * hw];
+  *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+}
+
 __global__ void fill_kernel(float* dst, float v, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long step = (long long)gridDim.x * blockDim.x;
@@ -280,6 +296,15 @@ extern "C" int fsd_transpose_batched(const float* src, long long src_batch_strid
   if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
                      dst_batch_stride, dst_row_stride, rows, cols);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_nchw_to_nhwc4(const float* src, float* dst, int batch, int channels, long long hw, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!src || !dst || batch < 1 || channels < 1 || channels > 4 || hw < 1) return FSD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(dst) & 15)) return FSD_ERR_ARG;
+  const long long total = (long long)batch * hw;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, src, dst, channels, hw, total);
   return (int)hipGetLastError();
 }
 

@@ -197,6 +197,9 @@ int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, cons
 int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
                           float* dst, long long dst_batch_stride, long long dst_row_stride,
                           int batch, int rows, int cols, hipStream_t stream);
+/* Network input: (batch, channels <= 4, hw) NCHW planes -> (batch*hw, 4) NHWC4 pixels, missing channels zero
+ * (darknet_meta.py:117-118 concatenates image and mask along channels; the kernels read 16-byte pixels). */
+int fsd_nchw_to_nhwc4(const float* src, float* dst, int batch, int channels, long long hw, hipStream_t stream);
 int fsd_fill(float* dst, float value, long long count, hipStream_t stream);
 
 /* Reorg (darknet_meta.py:55-74): out[b,i,j,(di*s+dj)*C + c] = x[b, s*i+di, s*j+dj, c], NHWC. */
