@@ -17,6 +17,7 @@ all-reduced over RCCL.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import contextlib
+import gc
 import json
 import os
 import random
@@ -259,12 +260,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # the per-launch event records below create thousands of python objects: keep the cyclic collector from
+    # stopping the host for a full-heap pass in the middle of the timed region
+    gc.collect()
+    gc.disable()
     ops.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof, ops.PROFILE = ops.PROFILE, None
     if rank != 0:                        # only rank 0 evaluates the per-launch events
         for e in prof:

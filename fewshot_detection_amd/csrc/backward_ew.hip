@@ -253,17 +253,27 @@ inline void launch_reduce_partials(const float* partial, double* slots, int rows
 }
 
 // dgamma/dbeta (or dbias) and the per-channel coefficients of  dy = c1 * (dt - c2 - xhat * c3)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
                                        const float* __restrict__ scale, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= channels) return;
+  // block = 32 channels x 8 slot lanes (coalesced along channels); lanes folded through LDS in a fixed order
+  __shared__ double s_part[8][32][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < n_slots; ++k) {
-    s1 += slots[((long long)k * channels + c) * 2 + 0];
-    s2 += slots[((long long)k * channels + c) * 2 + 1];
+  if (c < channels) {
+#pragma unroll 4
+    for (int k = sl; k < n_slots; k += 8) {
+      s1 += slots[((long long)k * channels + c) * 2 + 0];
+      s2 += slots[((long long)k * channels + c) * 2 + 1];
+    }
   }
+  s_part[sl][cl][0] = s1;
+  s_part[sl][cl][1] = s2;
+  __syncthreads();
+  if (sl != 0 || c >= channels) return;
+#pragma unroll
+  for (int l = 1; l < 8; ++l) { s1 += s_part[l][cl][0]; s2 += s_part[l][cl][1]; }
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
   if (coef) {
@@ -438,7 +448,7 @@ extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long cou
   const int n_slots = rows < kSlots ? rows : kSlots;
   const int two_c = 2 * channels;
   launch_reduce_partials(partial, reinterpret_cast<double*>(workspace), rows, two_c, n_slots, stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, scale, dgamma, dbeta,
                      coef);
   return (int)hipGetLastError();

@@ -57,21 +57,33 @@ inline void launch_bn_reduce(const float* partial, double* slots, int tiles, int
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    int training, float* __restrict__ scale, float* __restrict__ shift,
                                    float* save_mean, float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= channels) return;
+  // block = 32 channels x 8 slot lanes (coalesced along channels); lanes folded through LDS in a fixed order
+  __shared__ double s_part[8][32][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (training) {
+    if (c < channels) {
+#pragma unroll 4
+      for (int k = sl; k < n_slots; k += 8) {
+        s += slots[((long long)k * channels + c) * 2 + 0];
+        q += slots[((long long)k * channels + c) * 2 + 1];
+      }
+    }
+    s_part[sl][cl][0] = s;
+    s_part[sl][cl][1] = q;
+    __syncthreads();
+  }
+  if (sl != 0 || c >= channels) return;
   double mean, var;
   if (training) {
-    double s = 0.0, q = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < n_slots; ++k) {
-      s += slots[((long long)k * channels + c) * 2 + 0];
-      q += slots[((long long)k * channels + c) * 2 + 1];
-    }
+#pragma unroll
+    for (int l = 1; l < 8; ++l) { s += s_part[l][cl][0]; q += s_part[l][cl][1]; }
     mean = s / count;
     var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -261,7 +273,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
     const int two_c = 2 * channels;
     launch_bn_reduce(bn_partial, reinterpret_cast<double*>(workspace), row_tiles, two_c, n_slots, stream);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 127) / 128), dim3(128), 0, stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, gamma, beta,
                      running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_invstd);
   return (int)hipGetLastError();
