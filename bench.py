@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="conv compute mode: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, fp32 "
                          "accumulate, fp32 BN/loss/master weights and fp32 weight gradients (BASELINE C3/C5)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps that carry the per-launch HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / metric-string-episode timings")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
@@ -264,14 +265,18 @@ def main():
     # stopping the host for a full-heap pass in the middle of the timed region
     gc.collect()
     gc.disable()
-    ops.PROFILE = []
+    # Per-launch HIP events (roofline) are recorded inside the timed region, on its first `prof_steps` steps only: each
+    # record is a barrier packet in the queue and 230 of them per step cost ~1 ms of the 39 ms step.
+    prof_steps = min(args.steps, args.profile_steps)
+    prof = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.PROFILE = prof if i < prof_steps else None
         loss = step()
+    ops.PROFILE = None
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    prof, ops.PROFILE = ops.PROFILE, None
     if rank != 0:                        # only rank 0 evaluates the per-launch events
         for e in prof:
             if e[4]:
@@ -299,9 +304,9 @@ def main():
         gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         if args.per_layer:
-            per = len(prof) // max(1, args.steps)
+            per = len(prof) // max(1, prof_steps)
             for i in range(per):
-                ms_i = sum(prof[s * per + i][0].elapsed_time(prof[s * per + i][1]) for s in range(args.steps)) / args.steps
+                ms_i = sum(prof[s * per + i][0].elapsed_time(prof[s * per + i][1]) for s in range(prof_steps)) / prof_steps
                 fl = prof[i][2]
                 sys.stderr.write("conv launch %2d: %8.3f ms  %8.2f GFLOP  %6.1f TFLOP/s\n" % (i, ms_i, fl / 1e9, fl / ms_i / 1e9))
         blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
@@ -341,13 +346,13 @@ def main():
                          "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
                          "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 and args.dtype == "f32" else None,
                          "mfma_kernel": {"issued_tflops": gemm_tflops, "frac": gemm_tflops / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                                         "kernel_ms_per_step": gemm_ms / max(1, args.steps),
+                                         "kernel_ms_per_step": gemm_ms / max(1, prof_steps),
                                          "avg_kernel_ms": gemm_ms / max(1, len(gemm)), "kernels_timed": len(gemm)},
                          "launch_issued_tflops": exec_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "flop_per_launch": conv_flops / max(1, len(prof)),
                          "avg_launch_ms": conv_ms / max(1, len(prof)),
-                         "launches_per_step": len(prof) // max(1, args.steps),
-                         "conv_ms_per_step": conv_ms / max(1, args.steps)},
+                         "launches_per_step": len(prof) // max(1, prof_steps), "profiled_steps": prof_steps,
+                         "conv_ms_per_step": conv_ms / max(1, prof_steps)},
         }
         if world == 1 and not args.no_extras:
             res["also_measured"] = extras(net, region, opt, args, dev, x, metax, mask, target, full_flops,
