@@ -318,3 +318,123 @@ def test_winograd_conv_matches_direct_reference(dev, B, H, W, cin, cout, bias, t
     gref = xg.grad.float()
     err = float((ops.nhwc_to_nchw(dx).cpu() - gref).abs().max())
     assert err < tol * float(gref.abs().max()), err
+
+
+def _nasty_targets(rng, bs, cs, grid):
+    """Targets that sit on the awkward spots of build_targets: boxes on cell borders and image edges, boxes sharing a
+    cell (later box wins), tiny and huge boxes, rows with up to 50 boxes, empty rows and empty images."""
+    tgt = np.zeros((bs, cs, 250), np.float64)
+    for b in range(bs):
+        if rng.rand() < 0.15:
+            continue                                             # an image without any box
+        for n in range(cs):
+            if rng.rand() < 0.5:
+                continue
+            k = int(rng.choice([1, 1, 2, 3, 7, 50]))
+            for t in range(k):
+                mode = rng.randint(0, 5)
+                if mode == 0:                                    # exactly on a cell border
+                    cx, cy = rng.randint(1, grid) / grid, rng.randint(1, grid) / grid
+                elif mode == 1:                                  # image edge
+                    cx, cy = rng.choice([0.001, 0.998]), rng.uniform(0.05, 0.95)
+                elif mode == 2 and t > 0:                        # same cell as the previous box
+                    cx, cy = tgt[b, n, 5 * (t - 1) + 1] + 1e-4, tgt[b, n, 5 * (t - 1) + 2] + 1e-4
+                else:
+                    cx, cy = rng.uniform(0.02, 0.97, 2)
+                w, h = rng.choice([0.002, 0.03, 0.2, 0.6, 0.98]), rng.choice([0.002, 0.05, 0.3, 0.7, 0.98])
+                tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+    return torch.from_numpy(tgt)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_region_loss_v2_random_sweep_vs_oracle(dev, seed):
+    """GPU RegionLossV2 against the oracle (itself pinned to the reference goldens) on randomised shapes and nasty
+    targets: row selection and every assignment mask bit-exact, loss / gradient / statistics within fp32 tolerance."""
+    import random
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.region_loss import RegionLossV2
+    from oracle.region import region_loss_v2
+    rng = np.random.RandomState(100 + seed)
+    bs, cs = int(rng.randint(1, 5)), int(rng.choice([1, 2, 5, 15, 20]))
+    grid = int(rng.choice([7, 13, 19]))
+    seen = int(rng.choice([0, 12799, 12800, 20000]))
+    neg = ["full", 0, 1, 5][seed % 4]
+    tgt = _nasty_targets(rng, bs, cs, grid)
+    out_cpu = torch.from_numpy(rng.randn(bs * cs, 30, grid, grid).astype(np.float32) * 1.5)
+    cfg.neg_ratio = neg
+    try:
+        random.seed(seed)
+        ref_in = out_cpu.clone().requires_grad_(True)
+        r = region_loss_v2(ref_in, tgt, ANCH, seen=seen, neg_ratio=neg)
+        r["loss"].backward()
+        random.seed(seed)
+        mod = RegionLossV2(1, ANCH, 5)
+        mod.verbose = False
+        mod.seen = seen
+        mod.debug_targets = True
+        out = out_cpu.to(dev).requires_grad_(True)
+        loss = mod(out, tgt)
+        loss.backward()
+        assert list(mod.last_keep) == list(r["keep"])                       # same rows survive neg_filter
+        s = mod.stats()
+        assert (s["nGT"], s["nCorrect"], s["nProposals"]) == (r["nGT"], r["nCorrect"], r["nProposals"])
+        got = mod.last_targets.cpu().numpy()
+        for i, k in enumerate(MASKS):
+            want = r["targets"][k]
+            if k in ("coord_mask", "conf_mask", "cls_mask", "tcls", "tx", "ty"):
+                assert np.array_equal(got[i], want), k
+            else:
+                assert np.allclose(got[i], want, rtol=1e-5, atol=1e-6), k
+        ref_loss = float(r["loss"].detach())
+        assert abs(float(loss.detach()) - ref_loss) <= 1e-3 * max(1.0, abs(ref_loss)) * 0.1
+        g_ref = ref_in.grad.numpy()
+        assert np.allclose(out.grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(g_ref).max())))
+    finally:
+        cfg.neg_ratio = "full"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_region_loss_v1_random_sweep_vs_oracle(dev, seed):
+    """Same sweep for the classic per-cell softmax loss (C1 path), incl. cfg.metayolo zeroing the class targets."""
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.region_loss import RegionLoss
+    from oracle.region import region_loss_v1
+    rng = np.random.RandomState(300 + seed)
+    bs, nc = int(rng.randint(1, 5)), int(rng.choice([1, 3, 20]))
+    grid = int(rng.choice([7, 13, 19]))
+    seen = int(rng.choice([0, 12800, 20000]))
+    meta = bool(seed % 2)
+    tgt3 = _nasty_targets(rng, bs, nc, grid)                     # (bs, nc, 250): reuse, then flatten per image
+    tgt = torch.zeros(bs, 250, dtype=torch.float64)
+    for b in range(bs):
+        rows = tgt3[b].reshape(-1, 5)
+        rows = rows[rows[:, 3] > 0][:50]
+        tgt[b, :rows.numel()] = rows.reshape(-1)
+    out_cpu = torch.from_numpy(rng.randn(bs, 5 * (5 + nc), grid, grid).astype(np.float32) * 1.5)
+    cfg.neg_ratio, cfg.metayolo = "full", meta
+    try:
+        ref_in = out_cpu.clone().requires_grad_(True)
+        r = region_loss_v1(ref_in, tgt, ANCH_V1, 5, nc, seen=seen, metayolo=meta)
+        r["loss"].backward()
+        mod = RegionLoss(nc, ANCH_V1, 5)
+        mod.verbose = False
+        mod.seen = seen
+        mod.debug_targets = True
+        out = out_cpu.to(dev).requires_grad_(True)
+        loss = mod(out, tgt)
+        loss.backward()
+        s = mod.stats()
+        assert (s["nGT"], s["nCorrect"], s["nProposals"]) == (r["nGT"], r["nCorrect"], r["nProposals"])
+        got = mod.last_targets.cpu().numpy()
+        for i, k in enumerate(MASKS):
+            want = r["targets"][k]
+            if k in ("coord_mask", "conf_mask", "cls_mask", "tcls", "tx", "ty"):
+                assert np.array_equal(got[i], want), k
+            else:
+                assert np.allclose(got[i], want, rtol=1e-5, atol=1e-6), k
+        ref_loss = float(r["loss"].detach())
+        assert abs(float(loss.detach()) - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+        g_ref = ref_in.grad.numpy()
+        assert np.allclose(out.grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(g_ref).max())))
+    finally:
+        cfg.metayolo = True
