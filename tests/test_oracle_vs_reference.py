@@ -159,3 +159,71 @@ def test_full_size_construction_matches_live_reference():
     assert list(rs.keys()) == list(os_.keys())
     assert all(rs[k].shape == os_[k].shape for k in rs)
     assert sum(p.numel() for p in o.parameters()) == 66287742
+
+
+def _nasty_targets(rng, bs, cs, grid):
+    """Boxes on cell borders / image edges, boxes sharing a cell, tiny and huge boxes, long rows, empty rows/images."""
+    tgt = np.zeros((bs, cs, 250), np.float64)
+    for b in range(bs):
+        if rng.rand() < 0.15:
+            continue
+        for n in range(cs):
+            if rng.rand() < 0.5:
+                continue
+            for t in range(int(rng.choice([1, 1, 2, 3, 7, 50]))):
+                mode = rng.randint(0, 5)
+                if mode == 0:
+                    cx, cy = rng.randint(1, grid) / grid, rng.randint(1, grid) / grid
+                elif mode == 1:
+                    cx, cy = rng.choice([0.001, 0.998]), rng.uniform(0.05, 0.95)
+                elif mode == 2 and t > 0:
+                    cx, cy = tgt[b, n, 5 * (t - 1) + 1] + 1e-4, tgt[b, n, 5 * (t - 1) + 2] + 1e-4
+                else:
+                    cx, cy = rng.uniform(0.02, 0.97, 2)
+                w, h = rng.choice([0.002, 0.03, 0.2, 0.6, 0.98]), rng.choice([0.002, 0.05, 0.3, 0.7, 0.98])
+                tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+    return tgt
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_region_loss_v2_live_sweep(seed):
+    """The oracle against the LIVE reference RegionLossV2 (py2->py3 shim) on randomised nasty targets: every mask of
+    build_targets bit-exact, loss and gradient equal.  Skipped where /root/reference is absent (GPU box)."""
+    import random
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not present")
+    import make_golden
+    from oracle.region import region_loss_v2
+    cfgmod, rl = ref_shim.load("cfg"), ref_shim.load("region_loss")
+    rng = np.random.RandomState(500 + seed)
+    bs, cs, grid = int(rng.randint(1, 4)), int(rng.choice([1, 3, 5])), int(rng.choice([5, 7, 13]))
+    seen = int(rng.choice([0, 12800, 20000]))
+    neg = ["full", 0, 1][seed % 3]
+    tgt = _nasty_targets(rng, bs, cs, grid)
+    out = torch.from_numpy(rng.randn(bs * cs, 30, grid, grid).astype(np.float32) * 1.5)
+    mod = rl.RegionLossV2()
+    mod.anchors, mod.num_anchors, mod.num_classes, mod.anchor_step = make_golden.ANCH, 5, 1, 2
+    mod.seen = seen
+    cfgmod.cfg.neg_ratio = neg
+    try:
+        if not (tgt.reshape(bs * cs, -1).sum(1) != 0).any() and neg != "full":
+            pytest.skip("no positive row: the reference divides by zero here")
+        n_pos = int((tgt.reshape(bs * cs, -1).sum(1) != 0).sum())
+        if neg == 0 and n_pos == 1:
+            # reference quirk (SURVEY 8a'): np.argwhere(flags).squeeze() is 0-d for a single surviving row, pred[inds]
+            # loses its batch dimension and the reference raises a shape error; the oracle / kernels keep the row
+            pytest.skip("single surviving row: the reference itself raises here")
+        random.seed(seed)
+        ref = make_golden._run_loss(rl, mod, out, torch.from_numpy(tgt))
+        random.seed(seed)
+        o = out.clone().requires_grad_(True)
+        r = region_loss_v2(o, torch.from_numpy(tgt), make_golden.ANCH, seen=seen, neg_ratio=neg)
+        r["loss"].backward()
+    finally:
+        cfgmod.cfg.neg_ratio = "full"
+    assert (r["nGT"], r["nCorrect"]) == (int(ref["nGT"]), int(ref["nCorrect"]))
+    for k in ("coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"):
+        assert np.array_equal(r["targets"][k], ref[k]), k
+    assert abs(float(r["loss"].detach()) - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
+    assert np.allclose(o.grad.numpy(), ref["grad"], rtol=1e-5, atol=1e-6)
