@@ -223,6 +223,30 @@ def gold_decode(u):
              nms_thresh=0.45, boxes=np.array(flat, np.float64), kept=np.array(kept, np.float64))
 
 
+def gold_decode_extra(u):
+    """More shapes for the two decoders: meta (softmax across class rows) and plain YOLOv2 (per-cell softmax)."""
+    out = {}
+    for k, (bs, cs, g, th) in enumerate([(1, 1, 7, 0.5), (2, 5, 19, 0.5), (1, 20, 13, 0.5)]):
+        torch.manual_seed(20 + k)
+        o = torch.randn(bs * cs, 30, g, g) * 1.3
+        o[:, 4::6] -= 3.0              # ~1 % of the cells survive: the reference NMS is O(n^2) python
+        boxes = u.get_region_boxes_v2(o, cs, th, 1, ANCH, 5)
+        flat = [[r] + [float(v) for v in bx] for r, bl in enumerate(boxes) for bx in bl]
+        kept = [[r] + [float(v) for v in bx] for r, bl in enumerate(boxes) for bx in u.nms(bl, 0.45)]
+        out.update({"m%d_output" % k: o.numpy(), "m%d_cfg" % k: np.array([bs, cs, g, th]),
+                    "m%d_boxes" % k: np.array(flat, np.float64).reshape(-1, 8),
+                    "m%d_kept" % k: np.array(kept, np.float64).reshape(-1, 8)})
+    for k, (bs, nc, g, th) in enumerate([(2, 3, 13, 0.5), (1, 20, 7, 0.3)]):
+        torch.manual_seed(40 + k)
+        o = torch.randn(bs, 5 * (5 + nc), g, g) * 1.3
+        o[:, 4::5 + nc] -= 3.0
+        boxes = u.get_region_boxes(o, th, nc, ANCH_V1, 5)
+        flat = [[r] + [float(v) for v in bx] for r, bl in enumerate(boxes) for bx in bl]
+        out.update({"y%d_output" % k: o.numpy(), "y%d_cfg" % k: np.array([bs, nc, g, th]),
+                    "y%d_boxes" % k: np.array(flat, np.float64).reshape(-1, 8)})
+    np.savez_compressed(os.path.join(HERE, "decode_extra.npz"), **out)
+
+
 def gold_episode(im):
     """image.fill_truth_detection_meta / fill_truth_detection on random label files (out-of-range boxes, degenerate
     boxes, classes outside the base set, more than 50 boxes)."""
@@ -271,6 +295,7 @@ def main():
     gold_region_v2(rl, cfgmod)
     gold_region_v1(rl, cfgmod)
     gold_decode(u)
+    gold_decode_extra(u)
     gold_episode(ref_shim.load("image"))
     print("golden vectors written to", HERE)
 

@@ -438,3 +438,33 @@ def test_region_loss_v1_random_sweep_vs_oracle(dev, seed):
         assert np.allclose(out.grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(g_ref).max())))
     finally:
         cfg.metayolo = True
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_meta_decode_more_shapes_vs_reference_golden(dev, k):
+    """get_region_boxes_v2 + nms at 1 / 5 / 20 class rows and 7 / 19 / 13 grids (tests/golden/decode_extra.npz)."""
+    from fewshot_detection_amd import utils
+    d = np.load(os.path.join(GOLD, "decode_extra.npz"))
+    bs, cs, g, th = d["m%d_cfg" % k]
+    got = utils.get_region_boxes_v2(torch.from_numpy(d["m%d_output" % k]).to(dev), int(cs), float(th), 1, ANCH, 5)
+    flat = np.array([[r] + b for r, bl in enumerate(got) for b in bl], np.float64).reshape(-1, 8)
+    ref = d["m%d_boxes" % k]
+    assert flat.shape == ref.shape
+    assert np.array_equal(flat[:, 0], ref[:, 0]) and np.array_equal(flat[:, 7], ref[:, 7])      # row and class id
+    assert np.allclose(flat[:, 1:7], ref[:, 1:7], rtol=1e-5, atol=1e-6)
+    kept = np.array([[r] + b for r, bl in enumerate(got) for b in utils.nms(bl, 0.45)], np.float64).reshape(-1, 8)
+    assert np.allclose(kept, d["m%d_kept" % k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_plain_decode_vs_reference_golden(dev, k):
+    """get_region_boxes (per-cell softmax over 3 / 20 classes, reference utils.py:112-193)."""
+    from fewshot_detection_amd import utils
+    d = np.load(os.path.join(GOLD, "decode_extra.npz"))
+    bs, nc, g, th = d["y%d_cfg" % k]
+    got = utils.get_region_boxes(torch.from_numpy(d["y%d_output" % k]).to(dev), float(th), int(nc), ANCH_V1, 5)
+    flat = np.array([[r] + b for r, bl in enumerate(got) for b in bl], np.float64).reshape(-1, 8)
+    ref = d["y%d_boxes" % k]
+    assert flat.shape == ref.shape
+    assert np.array_equal(flat[:, 0], ref[:, 0]) and np.array_equal(flat[:, 7], ref[:, 7])
+    assert np.allclose(flat[:, 1:7], ref[:, 1:7], rtol=1e-5, atol=1e-6)
