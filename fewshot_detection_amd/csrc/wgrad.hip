@@ -42,10 +42,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   BF16 = true : operands rounded to bf16 (RNE) on the LDS store, 32x32x16 MFMA with fp32 accumulation
 //                 (BASELINE C3/C5); fragments need 8 consecutive PIXELS per lane, which are LDS rows here, so
 //                 they are gathered with 16-bit LDS reads (pairs land in the two halves of one VGPR).
-template <int TILE, int STAGES, bool BF16, bool PLAIN = false>
+//   DMA = true  : (fp32, PLAIN, 2 stages) the [row][channel] tiles go global -> LDS with global_load_lds: no staging
+//                 registers, no ds_write, no address VALU in the loop; LDS rows are unpadded (the DMA writes 1 KB per
+//                 wave instruction linearly), which is conflict-free for the 32-lane b32 fragment reads.  Needs full
+//                 tiles and full 32-row chunks: the launcher sends column remainders / the last < 32 rows elsewhere.
+template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
+  static_assert(!DMA || (!BF16 && PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
   typedef typename std::conditional<BF16, unsigned short, float>::type lds_t;
-  constexpr int LDT = TILE + (BF16 ? 8 : 4);       // LDS row stride in elements (keeps 16-byte alignment)
+  constexpr int LDT = DMA ? TILE : TILE + (BF16 ? 8 : 4);   // LDS row stride in elements (keeps 16-byte alignment)
   constexpr int CQ = TILE / 4;                     // float4 column groups per tile row
   constexpr int RPP = kThreads / CQ;               // pixel rows staged per pass
   constexpr int PASSES = kBK / RPP;
@@ -215,7 +220,35 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
     }
   };
 
-  if (nk > 0) {
+  if constexpr (DMA) {
+    // one wave instruction moves 2 rows of TILE floats (64 lanes x 16 B); a wave owns kBK/4 rows of each operand
+    constexpr int ROWS_PER_INSTR = 256 / TILE;                 // 2 for TILE = 128
+    constexpr int PER_WAVE = kBK / 4 / ROWS_PER_INSTR;         // instructions per wave per operand per chunk
+    const int r2 = lane / (TILE / 4), c4 = (lane % (TILE / 4)) * 4;
+    auto dma = [&](int kc, float* st) {
+      const long long row0 = (long long)p_begin + (long long)kc * kBK + wave * (kBK / 4) + r2;
+#pragma unroll
+      for (int j = 0; j < PER_WAVE; ++j) {
+        const long long row = row0 + j * ROWS_PER_INSTR;
+        float* dstA = st + (wave * (kBK / 4) + j * ROWS_PER_INSTR) * LDT;
+        __builtin_amdgcn_global_load_lds(p.dy + row * p.dy_ld + m0 + c4, dstA, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(p.x + row * p.x_ld + n0 + c4, dstA + kBK * LDT, 16, 0, 0);
+      }
+    };
+    if (nk > 0) {
+      dma(0, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int cur = 0;
+      for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) dma(kc + 1, smem + (cur ^ 1) * STAGE);     // buffer last read before the previous barrier
+        compute(smem + cur * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // DMA of the next chunk has landed
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+  } else if (nk > 0) {
     gload(0);
     sstore(smem);
     __syncthreads();
@@ -505,31 +538,79 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
 
 // 16 (or any number of) independent reduction GEMMs  ws[b][split][m][n] = sum_rows dy[b][row][m] * x[b][row][n]
 // on the fp32 weight-gradient kernel (ks = 1).  Returns the number of splits through *splits_out.
+// Plan of a batched reduction GEMM: 128x128 DMA-staged tiles over the full 32-row chunks when both channel counts
+// are multiples of 128 (+ one extra workspace slot filled by the 64x64 kernel for the last < 32 rows), else 64x64.
+struct BatchedPlan { bool dma; int splits; int tail_rows; int slots; };
+inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) {
+  static const char* env = getenv("FSD_WGRAD_DMA");         // tuning aid: 0 disables the DMA variant
+  const bool allow = !(env && env[0] == '0') && f32_variant() == 0;
+  BatchedPlan pl;
+  const long long full = rows / kBK * kBK;
+  // measured (tools/layer_bench.py wgrad): +5-7 % on the 1024/1280-channel layers, +2 % at 512, -2 % at 128/256
+  pl.dma = allow && cout % 128 == 0 && cin % 128 == 0 && cin >= 512 && cout >= 512 && full >= 8 * kBK;
+  if (pl.dma) {
+    const int tiles = (cout / 128) * (cin / 128) * batches;
+    pl.splits = pick_splits(full, tiles);
+    pl.tail_rows = (int)(rows - full);
+    pl.slots = pl.splits + (pl.tail_rows ? 1 : 0);
+  } else {
+    const int tile = tile_of(0);
+    const int tiles = ((cout + tile - 1) / tile) * ((cin + tile - 1) / tile) * batches;
+    pl.splits = pick_splits(rows, tiles);
+    pl.tail_rows = 0;
+    pl.slots = pl.splits;
+  }
+  return pl;
+}
+
 int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_bs, const float* x, long long x_ld,
                                  long long x_bs, float* ws, long long rows, int cin, int cout, int batches,
                                  int* splits_out, hipStream_t stream) {
   if (rows < 1 || rows > 0x7fffffffLL - 4096 || (cin & 3) || (dy_ld & 3) || (x_ld & 3)) return FSD_ERR_UNSUPPORTED;
+  const BatchedPlan pl = batched_plan(rows, cin, cout, batches);
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = ws;
   a.dy_ld = dy_ld; a.x_ld = x_ld;
-  a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;
   a.Cout = cout; a.cin4 = cin; a.ks = 1; a.pad = 0;
   a.ncols = cin;
+  a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)pl.slots * cout * cin;
+  *splits_out = pl.slots;
+  if (pl.dma) {
+    const long long full = rows - pl.tail_rows;
+    a.H = 1; a.W = (int)full; a.HW = (int)full; a.M = (int)full;
+    a.m_tiles = cout / 128;
+    a.n_tiles = cin / 128;
+    a.pix_per_split = round_up((int)((full + pl.splits - 1) / pl.splits), kBK);
+    const size_t lds = 2 * (size_t)(2 * kBK * 128) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
+                       dim3(kThreads), lds, stream, a);
+    if (pl.tail_rows) {                                      // the last < 32 rows -> workspace slot `splits`
+      WgradArgs t = a;
+      t.dy = dy + full * dy_ld; t.x = x + full * x_ld; t.ws = ws + (long long)pl.splits * cout * cin;
+      t.H = 1; t.W = pl.tail_rows; t.HW = pl.tail_rows; t.M = pl.tail_rows;
+      t.m_tiles = (cout + 63) / 64;
+      t.n_tiles = (cin + 63) / 64;
+      t.pix_per_split = kBK;
+      const size_t lds1 = (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+      hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true>), dim3(t.m_tiles * t.n_tiles, 1, batches), dim3(kThreads), lds1,
+                         stream, t);
+    }
+    return (int)hipGetLastError();
+  }
+  a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;
   const int tile = tile_of(0);
   a.m_tiles = (cout + tile - 1) / tile;
   a.n_tiles = (cin + tile - 1) / tile;
-  const int splits = wgrad_batched_splits(rows, cin, cout, batches);
-  a.pix_per_split = round_up((int)((rows + splits - 1) / splits), kBK);
-  a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)splits * cout * cin;
-  if (int rc = launch_wgrad(a, 0, dim3(a.m_tiles * a.n_tiles, splits, batches), stream)) return rc;
-  *splits_out = splits;
+  a.pix_per_split = round_up((int)((rows + pl.splits - 1) / pl.splits), kBK);
+  if (int rc = launch_wgrad(a, 0, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), stream)) return rc;
   return (int)hipGetLastError();
 }
 
 int fsd_conv::wgrad_batched_splits(long long rows, int cin, int cout, int batches) {
-  const int tile = tile_of(0);
-  const int tiles = ((cout + tile - 1) / tile) * ((cin + tile - 1) / tile) * batches;
-  return pick_splits(rows, tiles);
+  return batched_plan(rows, cin, cout, batches).slots;
 }
 
 extern "C" size_t fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(int batch, int height, int width, int cout) {
