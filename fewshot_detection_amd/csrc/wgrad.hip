@@ -550,7 +550,12 @@ inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) 
   pl.dma = allow && cout % 128 == 0 && cin % 128 == 0 && cin >= 512 && cout >= 512 && full >= 8 * kBK;
   if (pl.dma) {
     const int tiles = (cout / 128) * (cin / 128) * batches;
-    pl.splits = pick_splits(full, tiles);
+    // 512 co-resident 128x128 workgroups: ~3 rounds of blocks are enough, every extra split is another workspace
+    // slice for the fold kernel to read
+    int sp = (1536 + tiles - 1) / tiles;
+    const long long max_s = full / (8 * kBK);
+    if (sp > max_s) sp = (int)max_s;
+    pl.splits = sp < 1 ? 1 : sp;
     pl.tail_rows = (int)(rows - full);
     pl.slots = pl.splits + (pl.tail_rows ? 1 : 0);
   } else {

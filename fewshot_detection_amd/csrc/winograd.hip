@@ -593,21 +593,24 @@ __global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__
   const int il = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const long long n = (long long)cout * cin;
   const long long idx = (long long)blockIdx.x * 64 + il;
+  // 9 positions per thread: the 9 loads of one split are independent and issued together (memory-level parallelism),
+  // each position still folds its splits in the fixed order 0, 1, 2, ...
+  float v[9];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
-    const int pp = pg * 9 + q;
-    float v = 0.f;
-    if (idx < n) {
-      const float* src = ws + (long long)pp * splits * n + idx;
-      int k = 0;
-      for (; k + 3 < splits; k += 4) {
-        const float v0 = src[k * n], v1 = src[(k + 1) * n], v2 = src[(k + 2) * n], v3 = src[(k + 3) * n];
-        v += v0; v += v1; v += v2; v += v3;
-      }
-      for (; k < splits; ++k) v += src[k * n];
+  for (int q = 0; q < 9; ++q) v[q] = 0.f;
+  if (idx < n) {
+    const float* src = ws + (long long)(pg * 9) * splits * n + idx;
+    const long long pstride = (long long)splits * n;
+    for (int k = 0; k < splits; ++k) {
+      float t[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) t[q] = src[q * pstride + k * n];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) v[q] += t[q];
     }
-    s_m[pp][il] = v;
   }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) s_m[pg * 9 + q][il] = v[q];
   __syncthreads();
   if (threadIdx.x >= 64 || idx >= n) return;
   float s[3][6];
