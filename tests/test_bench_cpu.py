@@ -1,0 +1,56 @@
+"""bench.py's host-side arithmetic: the algorithmic FLOP counts behind `roofline.achieved` are the SURVEY 8(d) /
+BASELINE.md figures, the synthetic episode has the contract's shapes, and without a GPU the bench fails loudly."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_flops_match_baseline_md(tmp_path):
+    import bench
+    from fewshot_detection_amd import cfgs
+    from fewshot_detection_amd.cfg import parse_cfg
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    det = bench.conv_flops_per_image(parse_cfg(dyn_cfg), 416)            # layers 0-29 + one head 1x1 (layer 31)
+    rw416 = bench.conv_flops_per_image(parse_cfg(rw_cfg), 416)
+    rw224 = bench.conv_flops_per_image(parse_cfg(rw_cfg), 224)
+    head = 2.0 * 1024 * 30 * 13 * 13                                      # 0.0104 GFLOP per (image, class)
+    assert abs((det - head) / 1e9 - 29.317) < 0.002                       # full detector, GFLOP / image
+    assert abs(rw416 / 1e9 - 9.053) < 0.002 and abs(rw224 / 1e9 - 2.598) < 0.002
+    c2 = 64 * det + 15 * rw416 + head * 15 * 64 - 64 * head               # the expression bench.py uses (B=64, N=15)
+    assert abs(c2 / 1e9 - 2022.0) < 0.5                                   # "episode forward, C2 (Sm=416)"
+    det608 = bench.conv_flops_per_image(parse_cfg(dyn_cfg), 608) - 2.0 * 1024 * 30 * 19 * 19
+    assert abs(det608 / 1e9 - 62.624) < 0.005                             # C5 detector GFLOP / image
+
+
+def test_synthetic_episode_contract():
+    import bench
+    x, metax, mask, tgt = bench.synth_episode(7, 4, 3, 64, 32)
+    assert x.shape == (4, 3, 64, 64) and metax.shape == (3, 3, 32, 32) and mask.shape == (3, 1, 32, 32)
+    assert tgt.shape == (4, 3, 250) and tgt.dtype == torch.float64
+    assert float(x.min()) >= 0 and float(x.max()) < 1                    # ToTensor range, no normalisation
+    assert set(np.unique(mask.numpy())) <= {0.0, 1.0} and all(mask[n].sum() > 0 for n in range(3))
+    rows = tgt.numpy().reshape(12, 50, 5)
+    used = rows[:, :, 3] > 0
+    assert used.any()
+    for r in range(12):                                                   # zero-terminated, class field = row's class
+        k = int(used[r].sum())
+        assert not used[r, k:].any() and np.all(rows[r, :k, 0] == r % 3)
+    boxes = rows[used]
+    assert np.all(boxes[:, 1] - boxes[:, 3] / 2 >= -1e-9) and np.all(boxes[:, 1] + boxes[:, 3] / 2 <= 0.999 + 1e-9)
+    x2 = bench.synth_episode(7, 4, 3, 64, 32)[0]
+    assert torch.equal(x, x2)                                             # seeded
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "no CPU fallback" in out.stderr
+    assert out.stdout.strip() == ""                                       # and prints no JSON line
