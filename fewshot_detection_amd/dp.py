@@ -87,8 +87,11 @@ class EpisodeTrainer(object):
         if self.dist is None or self.dist.get_world_size() <= 1:
             return
         for i, (lo, hi) in enumerate(self.buckets):
-            if self._works[i] is None and (final or all(pid in sunk for pid in self._bucket_params[i])):
-                self._works[i] = self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True)
+            if self._works[i] is not None:
+                continue
+            if not (final or all(pid in sunk for pid in self._bucket_params[i])):
+                break          # strictly ascending bucket order on every rank, whatever order the networks finish in
+            self._works[i] = self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True)
 
     def reduce_and_step(self):
         """Bucketed SUM all-reduce overlapped with the per-bucket optimizer kernel."""
