@@ -33,6 +33,7 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         return
     conv, bn, xv, k, cout = rec["conv"], rec["bn"], rec["x"], rec["k"], rec["cout"]
     cin = conv.weight.shape[1]
+    wt_in = None
     direct = bn is None and rec["slope"] == 1.0 and rec["pool"] == 0
     if direct:
         dy = gz
@@ -68,14 +69,19 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
                 dx, _ = ops.conv3x3_wino(dt, net.cache.get(conv.weight, 1, "wino4"), xv.C, tile=4, v_in=vd)
                 _accumulate(grads, xv, dx)
                 return
-            ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
+            if kept and rec.get("wino_tile") == 4 and dt.C % 4 == 0:
+                # Winograd(4) layer: the BN backward rides on the weight-gradient transform (dt -> dy in place)
+                wt_in = ops.wino_dy_bn_transform(dt, yv, coef, rec["mean"], rec["invstd"])
+            else:
+                ops.bn_bwd_apply(dt, yv, coef, rec["mean"], rec["invstd"])
         elif conv.bias is not None:
             pgrads[id(conv.bias)] = s1
         dy = dt
     kept = rec.get("wino_v")
     wtile = rec.get("wino_tile") or 0
     pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32" if wtile else net.compute_dtype,
-                                               wino_v=kept[0] if kept else None, param=conv.weight, tile=wtile)
+                                               wino_v=kept[0] if kept else None, param=conv.weight, tile=wtile,
+                                               wt_in=wt_in)
     if xv is not first_input:
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         tile = ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)

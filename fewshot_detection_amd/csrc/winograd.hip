@@ -362,8 +362,15 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 }
 
 // dy (4x4 tile) -> G4 dy G4^T  (36 positions)
-__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
-                                                      int H, int W, int TH, int TW, int C, long long T) {
+// BN = true: `dy` holds dt (gradient w.r.t. the BatchNorm output); the BatchNorm backward c1*(dt - c2 - xhat*c3) is
+// applied on the way in and written back IN PLACE (tiles do not overlap), so fsd_bn_bwd_apply's separate pass -- and
+// one read of its result -- disappear; the data-gradient transform then reads the finished dy as usual.
+template <bool BN>
+__global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
+                                                      int H, int W, int TH, int TW, int C, long long T,
+                                                      const float* __restrict__ y, long long y_ld,
+                                                      const float* __restrict__ coef, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd) {
   const int cg = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
@@ -374,13 +381,30 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   const int ty = (int)(t2 % TH);
   const long long b = t2 / TH;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 c1 = zero, c2 = zero, c3 = zero, mu = zero, is = zero;
+  if constexpr (BN) {
+    c1 = ld4(coef + g * 4); c2 = ld4(coef + C + g * 4); c3 = ld4(coef + 2 * C + g * 4);
+    mu = ld4(mean + g * 4); is = ld4(invstd + g * 4);
+  }
   f32x4 q[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int oy = 4 * ty + i, ox = 4 * tx + j;
-      q[i][j] = (oy < H && ox < W) ? ld4(dy + ((b * H + oy) * (long long)W + ox) * dy_ld + g * 4) : zero;
+      if (oy < H && ox < W) {
+        const long long pix = (b * H + oy) * (long long)W + ox;
+        f32x4 v = ld4(dy + pix * dy_ld + g * 4);
+        if constexpr (BN) {
+          const f32x4 yv = ld4(y + pix * y_ld + g * 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = c1[k] * (v[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);   // == bn_bwd_apply
+          st4(dy + pix * dy_ld + g * 4, v);
+        }
+        q[i][j] = v;
+      } else {
+        q[i][j] = zero;
+      }
     }
   f32x4 t[6][4];
 #pragma unroll
@@ -768,8 +792,9 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
       hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
                          height, width, TH, TW, cout, T);
     else
-      hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
-                         height, width, TH, TW, cout, T);
+      hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
+                         const_cast<float*>(dy), dy_ld, Wt, height, width, TH, TW, cout, T, (const float*)nullptr, 0LL,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     Wg = Wt;
   }
   int splits = 0;
@@ -794,5 +819,19 @@ extern "C" int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const 
   const long long n = T * (channels / 2);
   hipLaunchKernelGGL(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
                      mean, invstd, v_out, wt_out, height, width, TH, TW, channels, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
+                                        const float* mean, const float* invstd, float* wt_out, int batch, int height,
+                                        int width, int channels, int tile, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dt || !y || !coef || !mean || !invstd || !wt_out || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (tile != 4 || (channels & 3) || (dt_ld & 3) || (y_ld & 3) || dt_ld < channels || y_ld < channels) return FSD_ERR_UNSUPPORTED;
+  const int TH = (height + 3) / 4, TW = (width + 3) / 4;
+  const long long T = tiles_of(batch, height, width, 4);
+  const long long n = T * (channels / 4);
+  hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
+                     height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd);
   return (int)hipGetLastError();
 }

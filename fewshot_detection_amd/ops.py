@@ -324,6 +324,16 @@ def grad_dst(param, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+def wino_dy_bn_transform(dt, yv, coef, mean, invstd):
+    """BatchNorm backward (dt -> dy, in place) fused with the Winograd(tile 4) weight-gradient transform: -> Wt for
+    conv2d_wgrad(wt_in=Wt); afterwards `dt` holds dy exactly as bn_bwd_apply would have left it."""
+    L = lib()
+    wt = torch.empty(L.fsd_wino_v_elems(yv.B, yv.H, yv.W, yv.C, 4), dtype=torch.float32, device=yv.t.device)
+    check(L.fsd_wino_dy_bn_transform(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                     wt.data_ptr(), yv.B, yv.H, yv.W, yv.C, 4, _stream()), "fsd_wino_dy_bn_transform")
+    return wt
+
+
 def wino_grad_transforms(dt, yv, coef, mean, invstd):
     """BatchNorm backward + both Winograd(tile 4) gradient transforms in one pass: -> (Vd, Wt) for
     conv3x3_wino(v_in=Vd, mode-1 weights) = data gradient and conv2d_wgrad(wt_in=Wt) = weight gradient."""

@@ -152,6 +152,13 @@ int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, lon
                            const float* wt_in, float* dw_oihw, void* workspace, size_t workspace_bytes, int batch,
                            int height, int width, int cin, int cout, int tile, hipStream_t stream);
 
+/* BatchNorm backward fused into the weight-gradient transform of a Winograd(tile 4) layer: dt (gradient w.r.t. the BN
+ * output) becomes dy = c1*(dt - c2 - xhat*c3) IN PLACE (what fsd_bn_bwd_apply would write) and wt_out = G4 dy G4^T
+ * (wt_in of fsd_wino_conv3x3_wgrad) in the same pass; the data gradient then reads dy from dt as usual. */
+int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
+                             const float* mean, const float* invstd, float* wt_out, int batch, int height, int width,
+                             int channels, int tile, hipStream_t stream);
+
 /* Backward of a BatchNorm + Winograd(tile 4) layer in one pass over the gradient: forms dy = c1*(dt - c2 - xhat*c3)
  * (what fsd_bn_bwd_apply computes; coef from fsd_bn_bwd_finalize) in registers and writes both transformed operands the
  * layer's gradients need: v_out = B^T dy B (v_in of fsd_wino_conv3x3_fwd with the mode-1 weights = data gradient) and

@@ -106,6 +106,11 @@ def test_fused_winograd_gradient_transforms_match_separate_path(dev, B, H, W, ci
     dx_s, _ = ops.conv3x3_wino(dy, u1, cin, tile=4)
     assert torch.equal(dw_f, dw_s)
     assert torch.equal(dx_f.t, dx_s.t)
+    # the default path: BN backward fused into the weight-gradient transform only, dt -> dy in place
+    dt2 = ops.View(dt.t.clone(), B, H, W, cout)
+    wt2 = ops.wino_dy_bn_transform(dt2, yv, coef, mean, invstd)
+    assert torch.equal(dt2.t, dy.t)                                   # exactly what bn_bwd_apply leaves behind
+    assert torch.equal(ops.conv2d_wgrad(dt2, cout, xv, cin, 3, wino_v=kept[0], tile=4, wt_in=wt2), dw_s)
 
 
 def test_wgrad_winograd_agrees_with_direct(dev, monkeypatch):
