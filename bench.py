@@ -5,7 +5,11 @@ One "step" = one episode: B query images (SxS) + N support images with masks (Sm
 reweighting net, the Darknet-19 meta feature extractor, the fused reweighting (x) 1x1 head and
 RegionLossV2 (+ backward + SGD in --mode train).  Inputs are synthetic and resident in HBM before the
 timed region.  Default workload = BASELINE.json configs[1]: darknet_dynamic.cfg + reweighting_net.cfg,
-B=64, 15 base classes, 416x416, fp32, 1 MI355X.
+B=64, 15 base classes, 416x416, fp32, 1 MI355X.  (BASELINE.json's metric STRING quotes "64x416x416 query + 20x224x224
+support": 20 supports of 224x224, which neither configs[1] (15 base classes) nor the cfg (support 416x416,
+cfg/reweighting_net.cfg:4-5) has.  The default is the heavier, cfg-true episode -- 2022 vs 1941.5 GFLOP forward -- and
+the metric-string episode is timed as well and reported under `also_measured`; `--classes 20 --support 224` makes it
+the headline line.)
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
