@@ -115,16 +115,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
     s_red[pl][gl][4 + k] = s2[k];
   }
   __syncthreads();
-  if (pl == 0 && g_ok) {
-    float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b += s_red[l][gl][4 + k]; }
-      dst[2 * k] = a;
-      dst[2 * k + 1] = b;
-    }
+  // fold the NPL pixel lanes: one thread per (channel group, value) pair, fixed order.  (Unrolling this over all
+  // lanes of the 32-channel layer -- 32 lanes x 8 values per thread -- cost 254 VGPRs and occupancy 1.)
+  for (int t = threadIdx.x; t < GL * 8; t += 256) {
+    const int tg = t >> 3, k8 = t & 7;
+    const int gg = blockIdx.y * GL + tg;
+    if (gg >= cg) continue;
+    float a = 0.f;
+#pragma unroll 4
+    for (int l = 0; l < NPL; ++l) a += s_red[l][tg][k8];
+    // k8 < 4: sum of dt for channel gg*4 + k8;  k8 >= 4: sum of dt * xhat for channel gg*4 + k8 - 4
+    p.partial[((long long)blockIdx.x * p.C + gg * 4 + (k8 & 3)) * 2 + (k8 >> 2)] = a;
   }
 }
 
@@ -199,16 +200,17 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
     s_red[pl][gl][4 + k] = s2[k];
   }
   __syncthreads();
-  if (pl == 0 && g_ok) {
-    float* dst = p.partial + ((long long)blockIdx.x * p.C + g * 4) * 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; b += s_red[l][gl][4 + k]; }
-      dst[2 * k] = a;
-      dst[2 * k + 1] = b;
-    }
+  // fold the NPL pixel lanes: one thread per (channel group, value) pair, fixed order.  (Unrolling this over all
+  // lanes of the 32-channel layer -- 32 lanes x 8 values per thread -- cost 254 VGPRs and occupancy 1.)
+  for (int t = threadIdx.x; t < GL * 8; t += 256) {
+    const int tg = t >> 3, k8 = t & 7;
+    const int gg = blockIdx.y * GL + tg;
+    if (gg >= cg) continue;
+    float a = 0.f;
+#pragma unroll 4
+    for (int l = 0; l < NPL; ++l) a += s_red[l][tg][k8];
+    // k8 < 4: sum of dt for channel gg*4 + k8;  k8 >= 4: sum of dt * xhat for channel gg*4 + k8 - 4
+    p.partial[((long long)blockIdx.x * p.C + gg * 4 + (k8 & 3)) * 2 + (k8 >> 2)] = a;
   }
 }
 
