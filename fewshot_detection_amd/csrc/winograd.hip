@@ -609,40 +609,41 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// ws[p][split][co][ci] (36 positions) -> dw[co][ci][3][3] = A3^T m A3.  Block = 64 outputs (256-B rows of the
-// workspace) x 4 position lanes, 9 positions each; the first 64 threads apply the transform.
-__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+// ws[p][split][co][ci] (36 positions) -> dw[co][ci][3][3] = A3^T m A3.  Block = 192 threads = 16 output quads
+// (64 outputs, 16-byte loads) x 12 position lanes of 3 positions each; the first 64 threads apply the transform.
+__global__ __launch_bounds__(192) void wino4_dw_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                                       int cout, int cin) {
-  __shared__ float s_m[36][65];
-  const int il = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const long long n = (long long)cout * cin;
-  const long long idx = (long long)blockIdx.x * 64 + il;
-  // 9 positions per thread: the 9 loads of one split are independent and issued together (memory-level parallelism),
-  // each position still folds its splits in the fixed order 0, 1, 2, ...
-  float v[9];
+  __shared__ float s_m[36][68];
+  const int il = threadIdx.x & 15, pg = threadIdx.x >> 4;          // 16 x 12
+  const long long n = (long long)cout * cin;                         // multiple of 4 (cin % 4 == 0)
+  const long long idx4 = (long long)blockIdx.x * 64 + il * 4;
+  f32x4 v[3];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) v[q] = 0.f;
-  if (idx < n) {
-    const float* src = ws + (long long)(pg * 9) * splits * n + idx;
+  for (int q = 0; q < 3; ++q) v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (idx4 < n) {
+    const float* src = ws + (long long)(pg * 3) * splits * n + idx4;
     const long long pstride = (long long)splits * n;
-    for (int k = 0; k < splits; ++k) {
-      float t[9];
+    for (int k = 0; k < splits; ++k) {                                // fixed order 0, 1, 2, ... per position
+      f32x4 t[3];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) t[q] = src[q * pstride + k * n];
+      for (int q = 0; q < 3; ++q) t[q] = ld4(src + q * pstride + k * n);
 #pragma unroll
-      for (int q = 0; q < 9; ++q) v[q] += t[q];
+      for (int q = 0; q < 3; ++q) v[q] += t[q];
     }
   }
 #pragma unroll
-  for (int q = 0; q < 9; ++q) s_m[pg * 9 + q][il] = v[q];
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_m[pg * 3 + q][il * 4 + e] = v[q][e];
   __syncthreads();
+  const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || idx >= n) return;
+  const int o = threadIdx.x;
   float s[3][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float r[3];
-    a3(s_m[0 * 6 + j][il], s_m[1 * 6 + j][il], s_m[2 * 6 + j][il], s_m[3 * 6 + j][il], s_m[4 * 6 + j][il],
-       s_m[5 * 6 + j][il], r);
+    a3(s_m[0 * 6 + j][o], s_m[1 * 6 + j][o], s_m[2 * 6 + j][o], s_m[3 * 6 + j][o], s_m[4 * 6 + j][o], s_m[5 * 6 + j][o], r);
 #pragma unroll
     for (int i = 0; i < 3; ++i) s[i][j] = r[i];
   }
@@ -804,7 +805,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (tile == 2)
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   else
-    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(192), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }
 
