@@ -29,12 +29,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   const int cg = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
-  const int g = (int)(idx % cg);
-  const long long tile = idx / cg;
-  const int tx = (int)(tile % TW);
-  const long long t2 = tile / TW;
-  const int ty = (int)(t2 % TH);
-  const long long b = t2 / TH;
+  const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
+  const int g = (int)(uidx % (unsigned)cg);
+  const unsigned utile = uidx / (unsigned)cg;
+  const long long tile = utile;
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 d[4][4];
 #pragma unroll
@@ -85,10 +87,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     for (int it = pl; it < tpb; it += 4) {
       const long long tile = t0 + it;
       if (tile >= T) break;
-      const int tx = (int)(tile % TW);
-      const long long t2 = tile / TW;
-      const int ty = (int)(t2 % TH);
-      const long long b = t2 / TH;
+      const unsigned utile = (unsigned)tile;             // < 2^31: 32-bit divisions
+      const int tx = (int)(utile % (unsigned)TW);
+      const unsigned ut2 = utile / (unsigned)TW;
+      const int ty = (int)(ut2 % (unsigned)TH);
+      const long long b = ut2 / (unsigned)TH;
       const float* src = Mb + tile * C + g * 4;
       f32x4 m[4][4];
 #pragma unroll
@@ -184,12 +187,14 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   const int cg = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
-  const int g = (int)(idx % cg);
-  const long long tile = idx / cg;
-  const int tx = (int)(tile % TW);
-  const long long t2 = tile / TW;
-  const int ty = (int)(t2 % TH);
-  const long long b = t2 / TH;
+  const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
+  const int g = (int)(uidx % (unsigned)cg);
+  const unsigned utile = uidx / (unsigned)cg;
+  const long long tile = utile;
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 q[2][2];
 #pragma unroll
@@ -325,12 +330,14 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   // neighbouring tiles re-read 2 of their 6 patch rows/columns: keep runs of consecutive tiles on one XCD (own L2)
   const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
-  const int g = (int)(idx % cg);
-  const long long tile = idx / cg;
-  const int tx = (int)(tile % TW);
-  const long long t2 = tile / TW;
-  const int ty = (int)(t2 % TH);
-  const long long b = t2 / TH;
+  const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
+  const int g = (int)(uidx % (unsigned)cg);
+  const unsigned utile = uidx / (unsigned)cg;
+  const long long tile = utile;
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
   const f32x2 zero = {0.f, 0.f};
   f32x2 d[6][6];
 #pragma unroll
@@ -374,12 +381,14 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
   const int cg = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
-  const int g = (int)(idx % cg);
-  const long long tile = idx / cg;
-  const int tx = (int)(tile % TW);
-  const long long t2 = tile / TW;
-  const int ty = (int)(t2 % TH);
-  const long long b = t2 / TH;
+  const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
+  const int g = (int)(uidx % (unsigned)cg);
+  const unsigned utile = uidx / (unsigned)cg;
+  const long long tile = utile;
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 c1 = zero, c2 = zero, c3 = zero, mu = zero, is = zero;
   if constexpr (BN) {
@@ -439,12 +448,14 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
   const int cg = C >> 1;
   const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
-  const int g = (int)(idx % cg);
-  const long long tile = idx / cg;
-  const int tx = (int)(tile % TW);
-  const long long t2 = tile / TW;
-  const int ty = (int)(t2 % TH);
-  const long long b = t2 / TH;
+  const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
+  const int g = (int)(uidx % (unsigned)cg);
+  const unsigned utile = uidx / (unsigned)cg;
+  const long long tile = utile;
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
   const f32x2 zero = {0.f, 0.f};
   const f32x2 c1 = ld2(coef + g * 2), c2 = ld2(coef + C + g * 2), c3 = ld2(coef + 2 * C + g * 2);
   const f32x2 mu = ld2(mean + g * 2), is = ld2(invstd + g * 2);
@@ -524,10 +535,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     for (int it = pl; it < tpb; it += NPL) {
       const long long tile = t0 + it;
       if (tile >= T) break;
-      const int tx = (int)(tile % TW);
-      const long long t2 = tile / TW;
-      const int ty = (int)(t2 % TH);
-      const long long b = t2 / TH;
+      const unsigned utile = (unsigned)tile;             // < 2^31: 32-bit divisions
+      const int tx = (int)(utile % (unsigned)TW);
+      const unsigned ut2 = utile / (unsigned)TW;
+      const int ty = (int)(ut2 % (unsigned)TH);
+      const long long b = ut2 / (unsigned)TH;
       const float* src = Mb + tile * C + g * 2;
       f32x2 o[4][4];
 #pragma unroll
@@ -716,6 +728,7 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   if (workspace_bytes < fsd_wino_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
   const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
   const long long T = tiles_of(batch, height, width, tile);
+  if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * T * cin;
@@ -772,6 +785,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (workspace_bytes < fsd_wino_wgrad_workspace_bytes(batch, height, width, cin, cout, tile)) return FSD_ERR_WORKSPACE;
   const int TH = (height + tile - 1) / tile, TW = (width + tile - 1) / tile;
   const long long T = tiles_of(batch, height, width, tile);
+  if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   float* Vw = reinterpret_cast<float*>(workspace);
   float* Wt = Vw + (size_t)P * T * cin;
@@ -817,6 +831,7 @@ extern "C" int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const 
   if (tile != 4 || (channels & 3) || (dt_ld & 1) || (y_ld & 1) || dt_ld < channels || y_ld < channels) return FSD_ERR_UNSUPPORTED;
   const int TH = (height + 3) / 4, TW = (width + 3) / 4;
   const long long T = tiles_of(batch, height, width, 4);
+  if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   const long long n = T * (channels / 2);
   hipLaunchKernelGGL(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
                      mean, invstd, v_out, wt_out, height, width, TH, TW, channels, T);
@@ -831,6 +846,7 @@ extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float*
   if (tile != 4 || (channels & 3) || (dt_ld & 3) || (y_ld & 3) || dt_ld < channels || y_ld < channels) return FSD_ERR_UNSUPPORTED;
   const int TH = (height + 3) / 4, TW = (width + 3) / 4;
   const long long T = tiles_of(batch, height, width, 4);
+  if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   const long long n = T * (channels / 4);
   hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
                      height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd);
