@@ -307,13 +307,15 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Measured on MI355X (profiles/r01_summary.txt, section D):
 //  * kTile64     64x64, one LDS stage (18 KB -> 8 workgroups = 32 waves per CU): 104-116 TFLOP/s on every
 //                layer of the path and insensitive to code placement.                      [DEFAULT]
-//  * kTile128x32 128x32, one stage: the short-K layers (first convs, K <= 320) are store/latency bound.
+//  * kTile128x32 128x32, one stage: layers with <= 32 output channels (a 64-wide tile idles half its MFMAs).
 //  * kTile128    128x128, two stages, + 64x64 tiles for the rows of the last partial round of
 //                co-resident workgroups ("tail split"): up to 120 TFLOP/s on the 13x13 layers but swings
 //                between 87 and 120 with unrelated code changes.
 //  * kDma*       direct global->LDS DMA staging (XOR-swizzled linear LDS image; 2 stages or a 3-deep
-//                ring with counted vmcnt): same throughput as register staging today; kept because it
-//                frees 32 VGPRs per lane for the planned bf16 path.
+//                ring with counted vmcnt): same throughput as register staging on the direct layers; the
+//                128x128 DMA variant is the default of the K >= 1024 Winograd batches (conv_gemm_batched:
+//                MFMA pipe 83 % busy against 69 % for 64x64).
+//  * kTile128x64 128x64, one stage: measured equal to 64x64 (kept as a tuning aid).
 // FSD_CONV_TILE=<letter> forces one configuration (tuning aid, read once per process).
 enum TileId { kTile64 = 0, kTile128x32, kTile128, kDma128, kDma128Ring, kDma64, kTile128x64, kNumTiles };
 struct TileCfg { int bm, bn; };
