@@ -35,6 +35,8 @@ PROTOTYPES = {
     "fsd_wino_partial_rows": (_i, [_i, _i, _i, _i]),
     "fsd_wino_v_elems": (_sz, [_i, _i, _i, _i, _i]),
     "fsd_wino_conv3x3_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _p, _sz, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_wino_fwd_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),
+    "fsd_wino_wgrad_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fsd_conv3x3_wgrad_c4_bnfused": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
     "fsd_wino_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -241,6 +241,10 @@ def print_cfg(blocks):
 def _pull(buf, start, dst):
     n = dst.numel()
     dst.data.copy_(torch.from_numpy(buf[start:start + n]).view_as(dst))
+    # `.data.copy_` does not move the parameter's autograd version counter, which is what the engine's packed-weight
+    # cache keys on: invalidate the cache explicitly so a model that already ran a forward pass sees the new weights
+    from .engine import bump_weight_epoch
+    bump_weight_epoch()
     return start + n
 
 

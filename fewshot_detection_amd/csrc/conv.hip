@@ -386,7 +386,26 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
   return r;
 }
 
+// Tile choice of the batched plain GEMMs (Winograd positions).  64x64 single-stage tiles win up to K = 512; for the
+// K >= 1024 GEMMs the 128x128 tile with DMA staging (global_load_lds, two stages) is ~3 % faster (measured,
+// tools/layer_bench.py).  FSD_WINO_TILE = a|c|d|e overrides.  'a' 64x64, 'c' 128x128 register-staged, 'd' 128x128 DMA,
+// 'e' 128x64.
+inline char batched_pick(int cin, int cout) {
+  static const char* env = getenv("FSD_WINO_TILE");
+  return env ? env[0] : (cin >= 1024 && cout % 128 == 0 ? 'd' : 'a');
+}
+
 }  // namespace
+
+int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
+  const char pick = batched_pick(cin, cout);
+  const int big = pick == 'c' || pick == 'd';
+  const int bm = (big || pick == 'e') ? 128 : 64, bn = big ? 128 : 64;
+  if (bm_out) *bm_out = bm;
+  if (bn_out) *bn_out = bn;
+  if (dma_out) *dma_out = pick == 'd';
+  return (int)((rows + bm - 1) / bm);
+}
 
 int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs,
                                 float* y, long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches,
@@ -402,10 +421,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.Kpad = cin;
   a.nk = cin / kBK;
   a.cpt = cin / kBK;
-  // 64x64 single-stage tiles win up to K = 512; for the K >= 1024 GEMMs the 128x128 tile with DMA staging
-  // (global_load_lds, two stages) is ~3 % faster (measured, tools/layer_bench.py).  FSD_WINO_TILE = a|c|d overrides.
-  static const char* env = getenv("FSD_WINO_TILE");
-  const char pick = env ? env[0] : (cin >= 1024 && cout % 128 == 0 ? 'd' : 'a');
+  const char pick = batched_pick(cin, cout);
   const int big = pick == 'c' || pick == 'd';
   const int bm = (big || pick == 'e') ? 128 : 64, bn = big ? 128 : 64;
   a.m_tiles = (int)((rows + bm - 1) / bm);

@@ -126,8 +126,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   }
 }
 
+// which tile the batched forward / data-gradient GEMM of conv_gemm_batched will use; returns the number of M tiles
+int conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out);
+
 // batched reduction GEMMs on the fp32 weight-gradient kernel (defined in wgrad.hip)
 int wgrad_batched_splits(long long rows, int cin, int cout, int batches);
+// plan of wgrad_gemm_batched: *dma = 128x128 DMA-staged variant, *splits = row splits of the main launch, *tail_rows =
+// rows (< 32) handled by the 64x64 side launch; returns the number of workspace slots
+int wgrad_batched_plan(long long rows, int cin, int cout, int batches, int* dma, int* splits, int* tail_rows);
 int wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_bs, const float* x, long long x_ld, long long x_bs,
                        float* ws, long long rows, int cin, int cout, int batches, int* splits_out, hipStream_t stream);
 

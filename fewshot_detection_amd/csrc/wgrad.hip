@@ -618,6 +618,14 @@ int fsd_conv::wgrad_batched_splits(long long rows, int cin, int cout, int batche
   return batched_plan(rows, cin, cout, batches).slots;
 }
 
+int fsd_conv::wgrad_batched_plan(long long rows, int cin, int cout, int batches, int* dma, int* splits, int* tail_rows) {
+  const BatchedPlan pl = batched_plan(rows, cin, cout, batches);
+  if (dma) *dma = pl.dma ? 1 : 0;
+  if (splits) *splits = pl.splits;
+  if (tail_rows) *tail_rows = pl.tail_rows;
+  return pl.slots;
+}
+
 extern "C" size_t fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(int batch, int height, int width, int cout) {
   return (size_t)first_blocks((long long)batch * height * width) * cout * 36 * sizeof(float);
 }

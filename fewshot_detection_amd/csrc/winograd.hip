@@ -764,6 +764,24 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   return (int)hipGetLastError();
 }
 
+extern "C" int fsd_wino_fwd_plan(int batch, int height, int width, int cin, int cout, int tile, int* plan4) {
+  if (!plan4 || batch < 1 || height < 1 || width < 1 || !tile_ok(tile)) return FSD_ERR_ARG;
+  const long long T = tiles_of(batch, height, width, tile);
+  int bm = 0, bn = 0, dma = 0;
+  const int m_tiles = fsd_conv::conv_gemm_batched_plan(T, cin, cout, &bm, &bn, &dma);
+  plan4[0] = bm; plan4[1] = bn; plan4[2] = dma; plan4[3] = m_tiles;
+  return 0;
+}
+
+extern "C" int fsd_wino_wgrad_plan(int batch, int height, int width, int cin, int cout, int tile, int* plan4) {
+  if (!plan4 || batch < 1 || height < 1 || width < 1 || !tile_ok(tile)) return FSD_ERR_ARG;
+  const long long T = tiles_of(batch, height, width, tile);
+  int dma = 0, splits = 0, tail = 0;
+  const int slots = fsd_conv::wgrad_batched_plan(T, cin, cout, npos(tile), &dma, &splits, &tail);
+  plan4[0] = dma; plan4[1] = splits; plan4[2] = tail; plan4[3] = slots;
+  return 0;
+}
+
 extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
   const int P = npos(tile);

@@ -32,6 +32,14 @@ class ConvBlock(nn.Sequential):
         act = self[len(self) - 1]
         slope = 0.1 if isinstance(act, nn.LeakyReLU) else 0.0 if isinstance(act, nn.ReLU) else 1.0
         k = conv.kernel_size[0]
+        # the same limits engine.Network._conv enforces: stride 1, 1x1 or "same"-padded 3x3, no groups / dilation
+        if (tuple(conv.stride) != (1, 1) or conv.kernel_size[0] != conv.kernel_size[1] or k not in (1, 3)
+                or tuple(conv.padding) != ((k - 1) // 2,) * 2 or tuple(conv.dilation) != (1, 1) or conv.groups != 1):
+            raise NotImplementedError("standalone ConvBlock: only stride-1 1x1 / same-padded 3x3 convolutions run on the "
+                                      "HIP path (got kernel %s stride %s padding %s)"
+                                      % (conv.kernel_size, conv.stride, conv.padding))
+        if x.shape[1] != conv.in_channels:
+            raise ValueError("ConvBlock expects %d input channels, got %d" % (conv.in_channels, x.shape[1]))
         with torch.no_grad():
             xv = ops.nchw_to_nhwc(x)
             wp = ops.pack_weight(conv.weight)
@@ -51,8 +59,9 @@ class _Pool2x2(nn.Module):
         self.mode = mode
 
     def forward(self, x):
-        with torch.no_grad():
-            return ops.nhwc_to_nchw(ops.bn_act_pool(ops.nchw_to_nhwc(x), None, None, 1.0, self.mode))
+        with torch.no_grad():       # the kernels work on channel quads: zero-padded channels pool to zero, slice them off
+            out = ops.nhwc_to_nchw(ops.bn_act_pool(ops.nchw_to_nhwc(x), None, None, 1.0, self.mode))
+            return out if out.shape[1] == x.shape[1] else out[:, :x.shape[1]].contiguous()
 
 
 class MaxPoolStride1(_Pool2x2):
@@ -79,7 +88,12 @@ class Reorg(nn.Module):
     def forward(self, x):
         assert x.dim() == 4 and x.shape[2] % self.stride == 0 and x.shape[3] % self.stride == 0
         with torch.no_grad():
-            return ops.nhwc_to_nchw(ops.reorg(ops.nchw_to_nhwc(x), self.stride))
+            out = ops.nhwc_to_nchw(ops.reorg(ops.nchw_to_nhwc(x), self.stride))
+            c, s2 = x.shape[1], self.stride * self.stride
+            if out.shape[1] != c * s2:      # C was padded to a channel quad: drop the padding inside every (di, dj) group
+                b, cp, h, w = out.shape[0], out.shape[1] // s2, out.shape[2], out.shape[3]
+                out = out.view(b, s2, cp, h, w)[:, :, :c].reshape(b, s2 * c, h, w)
+            return out
 
 
 class EmptyModule(nn.Module):

@@ -57,8 +57,30 @@ class EpisodeTrainer(object):
                     self._bucket_params[i].append(id(p))
             off += p.numel()
         self._works = [None] * len(self.buckets)
+        self._launch_order = []              # bucket indices in the order their all-reduce was started this step
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
+        self.world_size = 1 if self.dist is None else int(self.dist.get_world_size())
+        # per-bucket time the optimizer loop spent blocked in work.wait() (exposed all-reduce), accumulated over steps
+        self.allreduce_wait_ms = [0.0] * len(self.buckets)
+        self.time_allreduce = False
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Every replica starts from rank 0's parameters, momentum and BatchNorm running statistics (the reference's
+        nn.DataParallel re-broadcasts module 0's state every step, train_meta.py:137-141; DDP does this once at
+        construction).  Without it, ranks that seeded or loaded differently would apply the SUM of their gradients to
+        different weights and silently diverge."""
+        if self.world_size <= 1:
+            return
+        self.dist.broadcast(self.flat, 0)
+        self.dist.broadcast(self.mom, 0)
+        for b in self.net.buffers():
+            if b.is_floating_point():
+                self.dist.broadcast(b, 0)
+            else:                            # num_batches_tracked (int64): gloo/RCCL both take integer tensors
+                self.dist.broadcast(b, 0)
+        bump_weight_epoch()
 
     def _hip_step(self, lo, hi):
         ops.sgd_step(self.flat[lo:hi], self.grad[lo:hi], self.mom[lo:hi], self.lr, self.momentum,
@@ -91,16 +113,29 @@ class EpisodeTrainer(object):
                 continue
             if not (final or all(pid in sunk for pid in self._bucket_params[i])):
                 break          # strictly ascending bucket order on every rank, whatever order the networks finish in
+            if self._launch_order and self._launch_order[-1] >= i:
+                raise RuntimeError("gradient buckets must be reduced in ascending order on every rank (bucket %d after "
+                                   "%d): ranks would pair different buckets in one collective" % (i, self._launch_order[-1]))
+            self._launch_order.append(i)
             self._works[i] = self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True)
 
     def reduce_and_step(self):
         """Bucketed SUM all-reduce overlapped with the per-bucket optimizer kernel."""
         self._launch_ready((), final=True)
+        if self.world_size > 1 and self._launch_order != list(range(len(self.buckets))):
+            raise RuntimeError("all-reduce launch order %r is not 0..%d ascending" % (self._launch_order, len(self.buckets) - 1))
         for i, (lo, hi) in enumerate(self.buckets):
             if self._works[i] is not None:
-                self._works[i].wait()
+                if self.time_allreduce:
+                    import time
+                    t0 = time.perf_counter()
+                    self._works[i].wait()
+                    self.allreduce_wait_ms[i] += (time.perf_counter() - t0) * 1e3
+                else:
+                    self._works[i].wait()
             self._step_fn(lo, hi)
         self._works = [None] * len(self.buckets)
+        self._launch_order = []
         self.steps += 1
         bump_weight_epoch()
 

@@ -179,6 +179,19 @@ class Network(object):
         if tape is None:
             tape = []
         ops.require_device(*inputs)
+        for t in inputs:
+            if t.dim() != 4:
+                raise ValueError("network inputs must be (B, C, H, W) tensors, got shape %s" % (tuple(t.shape),))
+            if t.dtype != torch.float32:
+                raise ValueError("network inputs must be float32 (got %s): the kernels read raw fp32 storage" % t.dtype)
+            if (t.shape[0],) + tuple(t.shape[2:]) != (inputs[0].shape[0],) + tuple(inputs[0].shape[2:]):
+                raise ValueError("inputs concatenated along channels must share batch and spatial size: %s vs %s"
+                                 % (tuple(t.shape), tuple(inputs[0].shape)))
+        if dyn is not None:
+            for v in dyn:
+                ops.require_device(v)
+                if v.dtype != torch.float32:
+                    raise ValueError("reweighting vectors must be float32 (got %s)" % v.dtype)
         B, _, H, W = inputs[0].shape
         ctot = sum(t.shape[1] for t in inputs)
         if len(inputs) == 1:

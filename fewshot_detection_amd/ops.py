@@ -57,6 +57,8 @@ def fill(t, value):
 def nchw_to_nhwc(x, pad_to=4, out=None):
     """(B,C,H,W) contiguous -> View with channels padded (zeros) to a multiple of `pad_to`."""
     require_device(x)
+    if x.dtype != torch.float32:
+        raise ValueError("nchw_to_nhwc needs a float32 tensor (got %s)" % x.dtype)
     x = x.contiguous()
     B, Cc, H, W = x.shape
     Cp = (Cc + pad_to - 1) // pad_to * pad_to
@@ -76,6 +78,11 @@ def nchw_to_nhwc(x, pad_to=4, out=None):
 def write_channels(x, view, c_off):
     """Scatter an NCHW tensor into channels [c_off, c_off+C) of an existing NHWC view."""
     B, Cc, H, W = x.shape
+    if x.dtype != torch.float32:
+        raise ValueError("write_channels needs a float32 tensor (got %s)" % x.dtype)
+    if (B, H, W) != (view.B, view.H, view.W) or c_off < 0 or c_off + Cc > view.ld - view.c0:
+        raise ValueError("write_channels: a %s tensor at channel %d does not fit the (%d, %d, %d, %d) view"
+                         % (tuple(x.shape), c_off, view.B, view.H, view.W, view.C))
     x = x.contiguous()
     check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, view.ptr + 4 * c_off, H * W * view.ld,
                                       view.ld, B, Cc, H * W, _stream()), "fsd_transpose_batched")

@@ -36,8 +36,11 @@ def neg_filter_indices(target_rows):
     return [i for i, p in enumerate(pos) if p or not (random() > ratio)]
 
 
-def _validate_targets(rows):
-    """The reference raises (math.log domain error / bad index) on these; say why instead."""
+def _validate_targets(rows, n_labels=None):
+    """The reference raises (math.log domain error / bad index) on these; say why instead.
+    n_labels: number of valid class ids (rows per image for the meta loss, num_classes for v1); a label outside
+    [0, n_labels) makes the reference's CrossEntropyLoss raise, so it is refused here on the host rather than being
+    counted by a device-side statistic nobody reads when verbose=False."""
     cx = rows[:, 1::5]
     w, h = rows[:, 3::5], rows[:, 4::5]
     n = min(cx.shape[1], w.shape[1], h.shape[1])
@@ -47,6 +50,10 @@ def _validate_targets(rows):
     cy = rows[:, 2::5][:, :n]
     if np.any(live & ((cx[:, :n] < 0) | (cx[:, :n] >= 1) | (cy < 0) | (cy >= 1))):
         raise ValueError("region loss target has a box centre outside [0, 1)")
+    if n_labels is not None:
+        cls = rows[:, 0::5][:, :n]
+        if np.any(live & ((cls < 0) | (np.floor(cls) >= n_labels))):
+            raise ValueError("region loss target carries a class id outside [0, %d)" % n_labels)
 
 
 class _RegionLossFn(torch.autograd.Function):
@@ -118,7 +125,7 @@ class _RegionBase(nn.Module):
         tr = np.ascontiguousarray(target_rows_host, dtype=np.float64)
         if tr.shape[0] != rows:
             raise ValueError("target has %d rows, output has %d" % (tr.shape[0], rows))
-        _validate_targets(tr)
+        _validate_targets(tr, None if zero_tcls else (rows_per_image if softmax_over_rows else self.num_classes))
         keep = neg_filter_indices(tr)
         keep_map = np.full(rows, -1, np.int32)
         keep_map[keep] = np.arange(len(keep), dtype=np.int32)

@@ -142,6 +142,15 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
                                  void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                  int cout, hipStream_t stream);
 
+/* Which kernel variants the Winograd entry points will launch for a shape (pure host queries; the parity tests use them
+ * to prove that a test shape really exercises a given variant).
+ *   fsd_wino_fwd_plan:   plan4 = {BM, BN, dma_staged(0/1), m_tiles} of the batched position GEMM of
+ *                        fsd_wino_conv3x3_fwd (forward and, with mode-1 weights, data gradient).
+ *   fsd_wino_wgrad_plan: plan4 = {dma_128x128(0/1), row_splits, tail_rows (< 32, side launch on the 64x64 kernel),
+ *                        workspace_slots} of the batched reduction GEMM of fsd_wino_conv3x3_wgrad. */
+int fsd_wino_fwd_plan(int batch, int height, int width, int cin, int cout, int tile, int* plan4);
+int fsd_wino_wgrad_plan(int batch, int height, int width, int cin, int cout, int tile, int* plan4);
+
 /* Winograd form of the fp32 weight gradient of a 3x3 convolution, F(3x3, tile x tile): dW = sum over tiles,
  * (tile+2)^2 batched reduction GEMMs over tiles instead of 9 taps x pixels (tile 2: 2.25x, tile 4: 4x fewer
  * multiplications).  v_kept (nullable): the forward pass's transformed input of the same tile size; when given, x is

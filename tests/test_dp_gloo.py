@@ -81,3 +81,52 @@ def test_bucket_bounds_cover_buffer():
         b = bucket_bounds(total, 4)
         assert b[0][0] == 0 and b[-1][1] == total
         assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+
+
+class _TinyBN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Conv2d(3, 5, 3, 1, 1, bias=False)
+        self.bn = nn.BatchNorm2d(5)
+
+    def forward(self, x):
+        return self.bn(self.a(x))
+
+
+def _worker_sync(rank, world, port, out_dir):
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                                 # every rank initialises DIFFERENTLY
+    net = _TinyBN()
+    net.bn.running_mean.fill_(float(rank + 1))
+    net.bn.running_var.fill_(float(rank + 2))
+    tr = EpisodeTrainer(net, 0.01, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
+    torch.save(dict(flat=tr.flat.clone(), mean=net.bn.running_mean.clone(), var=net.bn.running_var.clone(),
+                    world=tr.world_size), os.path.join(out_dir, "sync%d.pt" % rank))
+    # buckets must be reduced in ascending order on every rank: a descending launch is refused loudly
+    tr._launch_order = [1]
+    try:
+        tr._launch_ready((), final=True)
+        ok = False
+    except RuntimeError:
+        ok = True
+    torch.save(ok, os.path.join(out_dir, "order%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0_state_and_bucket_order_is_enforced(tmp_path):
+    """EpisodeTrainer broadcasts parameters, momentum and BN running statistics from rank 0 at
+    construction (the reference's DataParallel re-broadcasts module 0 every step, train_meta.py:137-141)."""
+    port = _free_port()
+    mp.spawn(_worker_sync, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "sync0.pt"))
+    b = torch.load(os.path.join(str(tmp_path), "sync1.pt"))
+    assert a["world"] == b["world"] == 2
+    assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["mean"], b["mean"]) and torch.equal(a["var"], b["var"])
+    torch.manual_seed(100)
+    ref = _TinyBN()
+    assert torch.equal(a["flat"], torch.cat([p.detach().reshape(-1) for p in ref.parameters()]))
+    assert float(a["mean"][0]) == 1.0 and float(b["var"][0]) == 2.0      # rank 0's statistics everywhere
+    assert torch.load(os.path.join(str(tmp_path), "order0.pt")) and torch.load(os.path.join(str(tmp_path), "order1.pt"))

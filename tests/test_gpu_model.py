@@ -178,3 +178,81 @@ def test_bf16_mode_trains(dev):
     assert abs(losses[0] - losses[1]) < 0.05 * abs(losses[0])
     cos = float(torch.dot(grads[0], grads[1]) / (grads[0].norm() * grads[1].norm()))
     assert cos > 0.9, cos          # bf16 operand noise on a tiny random net; fp32 weight gradients keep it aligned
+
+
+def test_load_weights_after_a_forward_invalidates_packed_weights(dev, tmp_path):
+    """eval.py:118-122 pushes several checkpoints through ONE model.  The packed / Winograd weight
+    copies the engine caches must not survive load_weights (its `.data.copy_` leaves torch's version counter alone)."""
+    from fewshot_detection_amd.darknet_meta import Darknet
+    d = np.load(os.path.join(GOLD, "mini_forward.npz"))
+    x, metax, mask = (torch.from_numpy(d[k]).to(dev) for k in ("x", "metax", "mask"))
+    other = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.uniform_(-0.3, 0.3)
+    p_other = str(tmp_path / "other.weights")
+    other.save_weights(p_other)
+    net = _mini(dev).eval()
+    with torch.no_grad():
+        first = net(x, metax, mask).clone()                     # fills the packed-weight cache
+        net.load_weights(p_other)                               # second checkpoint through the same model
+        second = net(x, metax, mask)
+        fresh_net = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+        fresh_net.load_weights(p_other)
+        fresh = fresh_net.to(dev).eval()(x, metax, mask)
+    assert float((first - second).abs().max()) > 1e-3          # the checkpoints really differ
+    assert torch.equal(second, fresh)
+    # a user's raw in-place edit through .data followed by the documented invalidation call
+    from fewshot_detection_amd.engine import bump_weight_epoch
+    with torch.no_grad():
+        net.models[0][0].weight.data.mul_(0.5)
+        bump_weight_epoch()
+        third = net(x, metax, mask)
+    assert float((third - second).abs().max()) > 1e-6
+
+
+def test_network_inputs_are_validated(dev):
+    """wrong dtypes / mismatched mask sizes raise instead of being reinterpreted or scattered."""
+    d = np.load(os.path.join(GOLD, "mini_forward.npz"))
+    net = _mini(dev).eval()
+    x, metax, mask = (torch.from_numpy(d[k]).to(dev) for k in ("x", "metax", "mask"))
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            net(x.double(), metax, mask)
+        with pytest.raises(ValueError):
+            net(x, metax, (mask * 255).to(torch.uint8))
+        with pytest.raises(ValueError):
+            net(x, metax, torch.cat([mask, mask], 0))                      # more masks than supports
+        with pytest.raises(ValueError):
+            net(x, metax, mask[:, :, :mask.shape[2] // 2])                  # stale smaller mask
+        dyn = net.meta_forward(metax, mask)
+        with pytest.raises(ValueError):
+            net.detect_forward(x, [dyn[0].half()])
+        net.detect_forward(x, dyn)
+
+
+def test_standalone_modules_are_shape_faithful(dev):
+    """Reorg / MaxPool modules with C % 4 != 0 return the true channel count and ordering; a
+    ConvBlock the HIP path cannot run says so."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from fewshot_detection_amd.darknet_meta import ConvBlock, MaxPool2x2, MaxPoolStride1, Reorg
+    from oracle.net import reorg as oracle_reorg
+    g = torch.Generator().manual_seed(3)
+    for c in (3, 6, 8):
+        x = torch.randn(2, c, 8, 6, generator=g)
+        r = Reorg(2)(x.to(dev)).cpu()
+        assert r.shape == (2, 4 * c, 4, 3) and torch.equal(r, oracle_reorg(x, 2))
+        p = MaxPool2x2()(x.to(dev)).cpu()
+        assert torch.equal(p, F.max_pool2d(x, 2, 2))
+        p1 = MaxPoolStride1()(x.to(dev)).cpu()
+        assert torch.equal(p1, F.max_pool2d(F.pad(x, (0, 1, 0, 1), mode="replicate"), 2, 1))
+    blk = ConvBlock()
+    blk.add_module("conv1", nn.Conv2d(4, 8, 3, 2, 1))
+    with pytest.raises(NotImplementedError):
+        blk.to(dev)(torch.randn(1, 4, 8, 8).to(dev))
+    blk = ConvBlock()
+    blk.add_module("conv1", nn.Conv2d(4, 8, 3, 1, 0))
+    with pytest.raises(NotImplementedError):
+        blk.to(dev)(torch.randn(1, 4, 8, 8).to(dev))

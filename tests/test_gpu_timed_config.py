@@ -1,0 +1,200 @@
+"""Parity of exactly what `bench.py` times (BASELINE configs[1], B=64): the kernel variants that only large batches
+select -- the DMA-staged 128x128 weight-gradient GEMM with its < 32-row side launch (csrc/wgrad.hip, batched_plan)
+and the DMA-staged 128x128 forward / data-gradient GEMM with several M tiles (csrc/conv.hip, batched_pick) -- each
+against fp64, with the plan queries of include/fsdet.h proving that the shape really takes that variant; and one
+full-size episode (B=64, N=15, 416x416, 66.3 M parameters) against the CPU oracle: forward, loss, row selection,
+statistics, all nine build_targets tensors and per-parameter gradients (reference: region_loss.py:252-366,
+darknet_meta.py:130-201)."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+MASKS = ["coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _plan(fn, B, H, W, cin, cout, tile=4):
+    a = (C.c_int * 4)()
+    assert fn(B, H, W, cin, cout, tile, a) == 0
+    return list(a)
+
+
+# (B, H, W, cin, cout, expected tail rows).  Tiles T = B * ceil(H/4) * ceil(W/4); the DMA kernel takes the full 32-row
+# chunks, the 64x64 kernel the remaining T % 32 rows.
+@pytest.mark.parametrize("B,H,W,cin,cout,tail", [
+    (16, 13, 13, 512, 512, 0),        # T = 256: the smallest batch that selects the variant, no tail
+    (17, 13, 13, 1024, 512, 16),      # T = 272: 8 full chunks + a 16-row side launch
+    (19, 13, 13, 512, 1280, 16),      # T = 304: 9 chunks + 16 rows, 1280 output channels (10 column tiles)
+    (5, 26, 26, 512, 1024, -1),       # control: T = 5*7*7 = 245 < 256 rows must NOT select the variant
+    (64, 13, 13, 1280, 1024, 0),      # the bench shape of L29 (T = 1024, 36 positions)
+    (64, 13, 13, 1024, 1024, 0),      # L23/L24 of the bench
+])
+def test_wgrad_dma128_variant_matches_fp64(dev, B, H, W, cin, cout, tail):
+    from fewshot_detection_amd import ops
+    L = ops.lib()
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    dma, splits, tail_rows, slots = _plan(L.fsd_wino_wgrad_plan, B, H, W, cin, cout)
+    if T >= 256:
+        assert dma == 1 and tail_rows == tail == T % 32 and slots == splits + (1 if tail else 0), (dma, splits, tail_rows)
+    else:
+        assert dma == 0                                   # control case: the 64x64 kernel
+    g = torch.Generator().manual_seed(cin + cout + B)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(gy.double())
+    ref = w.grad
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    gv = ops.nchw_to_nhwc(gy.to(dev))
+    dw = ops.conv2d_wgrad(gv, cout, xv, cin, 3, tile=4).cpu().double()
+    err = float((dw - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-4, err
+    # the same with the transformed input kept by a forward pass (what the training step does)
+    keep = []
+    ops.conv3x3_wino(xv, ops.pack_weight_wino(torch.randn(cout, cin, 3, 3, generator=g).to(dev), 0, 4), cout,
+                     keep_v=keep, tile=4)
+    dw2 = ops.conv2d_wgrad(gv, cout, xv, cin, 3, tile=4, wino_v=keep[0]).cpu().double()
+    assert float((dw2 - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,m_tiles", [
+    (24, 13, 13, 1024, 1024, 3),      # T = 384: three full 128-row tiles
+    (17, 13, 13, 1280, 1024, 3),      # T = 272: two full tiles + 16 rows of a third
+    (64, 13, 13, 1280, 1024, 8),      # L29 at the bench batch
+    (64, 13, 13, 1024, 1024, 8),      # L23/L24 at the bench batch
+])
+def test_wino_gemm_dma128_multi_tile_matches_fp64(dev, B, H, W, cin, cout, m_tiles):
+    """Forward and data gradient (mode-1 weights) of the K >= 1024 Winograd layers with several M tiles."""
+    from fewshot_detection_amd import ops
+    L = ops.lib()
+    bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cin, cout)
+    assert (bm, bn, dma, mt) == (128, 128, 1, m_tiles)
+    bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cout, cin)      # the data gradient swaps the roles
+    assert (bm, bn, dma, mt) == (128, 128, 1, m_tiles)
+    g = torch.Generator().manual_seed(cin + B)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    gy = torch.randn(B, cout, H, W, generator=g)
+    xg = x.double().requires_grad_(True)
+    ref = F.conv2d(xg, w.double(), None, 1, 1)
+    ref.backward(gy.double())
+    yv, part = ops.conv3x3_wino(ops.nchw_to_nhwc(x.to(dev)), ops.pack_weight_wino(w.to(dev), 0, 4), cout,
+                                bn_partial=True, tile=4)
+    y = ops.nhwc_to_nchw(yv).cpu().double()
+    refd = ref.detach()
+    assert float((y - refd).abs().max()) < 6e-5 * float(refd.abs().max())
+    p = part.double().sum(0).cpu()                         # BatchNorm partial sums of the epilogue
+    flat = refd.permute(1, 0, 2, 3).reshape(cout, -1)
+    assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=2e-3)
+    dx, _ = ops.conv3x3_wino(ops.nchw_to_nhwc(gy.to(dev)), ops.pack_weight_wino(w.to(dev), 1, 4), cin, tile=4)
+    gref = xg.grad
+    assert float((ops.nhwc_to_nchw(dx).cpu().double() - gref).abs().max()) < 6e-5 * float(gref.abs().max())
+
+
+def _targets(rng, bs, cs):
+    """bench.py's synth_targets: 1-5 boxes per image."""
+    tgt = np.zeros((bs, cs, 250), np.float64)
+    fill = np.zeros((bs, cs), np.int64)
+    for b in range(bs):
+        for _ in range(rng.randint(1, 6)):
+            n = rng.randint(0, cs)
+            w, h = rng.uniform(0.05, 0.5, 2)
+            cx = float(np.clip(rng.uniform(0.1, 0.9), w / 2, 0.999 - w / 2))
+            cy = float(np.clip(rng.uniform(0.1, 0.9), h / 2, 0.999 - h / 2))
+            t = fill[b, n]
+            tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+            fill[b, n] += 1
+    return torch.from_numpy(tgt)
+
+
+@pytest.mark.parametrize("seen", [0, 20000])
+def test_c2_full_batch_episode_vs_oracle(dev, tmp_path, seen):
+    """BASELINE configs[1] at its full size -- B=64 queries 416x416, N=15 supports 416x416, neg_ratio 'full' -- i.e. the
+    launch configuration bench.py times (every B>=16-only kernel variant included), against the CPU oracle."""
+    from fewshot_detection_amd import cfgs
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from oracle.net import OracleDarknet
+    from oracle.region import region_loss_v2
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    torch.manual_seed(7)
+    random.seed(7)
+    ora = OracleDarknet(dyn_cfg, rw_cfg).train()
+    net = Darknet(dyn_cfg, rw_cfg)
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train()
+    B, N, S = 64, 15, 416
+    g = torch.Generator().manual_seed(11)
+    x, metax = torch.rand(B, 3, S, S, generator=g), torch.rand(N, 3, S, S, generator=g)
+    mask = torch.zeros(N, 1, S, S)
+    for n in range(N):
+        mask[n, 0, 40 + 5 * n:200 + 9 * n, 30 + 7 * n:150 + 11 * n] = 1
+    tgt = _targets(np.random.RandomState(11), B, N)
+    cfg.neg_ratio = "full"
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    region.debug_targets = True
+    region.seen = seen
+    out = net(x.to(dev), metax.to(dev), mask.to(dev))
+    loss = region(out, tgt)
+    loss.backward()
+    out_cpu = out.detach().cpu()
+    got_t = region.last_targets.cpu().numpy()
+    stats = region.stats()
+
+    # (1) forward of the whole network against the oracle's
+    ref = ora(x, metax, mask)
+    r = region_loss_v2(ref, tgt, ora.region.anchors, seen=seen)
+    r["loss"].backward()
+    fwd_err = float((out_cpu - ref.detach()).abs().max())
+    ref_loss = float(r["loss"].detach())
+    print("B=64 C2 seen=%d: forward max|diff| %.3e (max|out| %.2f), loss %.4f vs oracle %.4f"
+          % (seen, fwd_err, float(ref.detach().abs().max()), float(loss.detach()), ref_loss))
+    assert out.shape == (B * N, 30, 13, 13)
+    assert fwd_err < 1e-3
+    assert abs(float(loss.detach()) - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
+
+    # (2) the loss kernel on IDENTICAL inputs (the HIP network's own output): selection, statistics and every
+    # build_targets tensor bit-exact, loss and gradient within fp32 tolerance
+    same_in = out_cpu.clone().requires_grad_(True)
+    r2 = region_loss_v2(same_in, tgt, ora.region.anchors, seen=seen)
+    r2["loss"].backward()
+    assert list(region.last_keep) == list(r2["keep"])
+    assert (stats["nGT"], stats["nCorrect"], stats["nProposals"]) == (r2["nGT"], r2["nCorrect"], r2["nProposals"])
+    for i, k in enumerate(MASKS):
+        want = r2["targets"][k]
+        if k in ("coord_mask", "conf_mask", "cls_mask", "tcls", "tx", "ty"):
+            assert np.array_equal(got_t[i], want), k
+        else:
+            assert np.allclose(got_t[i], want, rtol=1e-5, atol=1e-6), k
+    l2 = float(r2["loss"].detach())
+    assert abs(float(loss.detach()) - l2) <= 1e-4 * max(1.0, abs(l2)), (float(loss.detach()), l2)
+
+    # (3) per-parameter gradients of the 66.3 M parameters
+    named, mine = dict(ora.named_parameters()), dict(net.named_parameters())
+    worst_l2, worst_cos, worst_name = 0.0, 1.0, ""
+    for name, p in mine.items():
+        gm, gr = p.grad.cpu().double().flatten(), named[name].grad.double().flatten()
+        rel = float((gm - gr).norm() / gr.norm())
+        cos = float(torch.dot(gm, gr) / (gm.norm() * gr.norm()))
+        if rel > worst_l2:
+            worst_l2, worst_name = rel, name
+        worst_cos = min(worst_cos, cos)
+    print("B=64 C2 seen=%d: worst relative-L2 gradient error %.3e (%s), worst cosine %.6f" % (seen, worst_l2, worst_name, worst_cos))
+    assert worst_l2 < 2e-2 and worst_cos > 0.9995, (worst_name, worst_l2, worst_cos)
+    for name in ("models.31.conv24.weight", "models.31.conv24.bias", "models.29.bn22.weight", "learnet_models.12.conv7.weight"):
+        gm, gr = mine[name].grad.cpu(), named[name].grad
+        assert float((gm - gr).abs().max()) / float(gr.abs().max()) < 1e-3, name

@@ -180,3 +180,26 @@ def test_compat_aliases_expose_reference_names():
         sys.path.pop(0)
         for m in ("cfg", "darknet_meta", "region_loss", "dynamic_conv", "pooling", "utils", "darknet"):
             sys.modules.pop(m, None)
+
+
+def test_region_targets_with_bad_class_ids_are_refused_on_the_host():
+    """a class id outside the episode makes the reference's CrossEntropyLoss raise
+    (region_loss.py:349-352); with verbose=False nobody reads the device-side bad-target counter, so the host refuses."""
+    import pytest
+    from fewshot_detection_amd.region_loss import _validate_targets
+    rows = np.zeros((6, 250))
+    rows[1, :5] = [2, 0.5, 0.5, 0.2, 0.2]
+    rows[4, :10] = [0, 0.3, 0.3, 0.1, 0.1, 1, 0.6, 0.6, 0.2, 0.3]
+    _validate_targets(rows, 3)
+    _validate_targets(rows, None)
+    bad = rows.copy()
+    bad[1, 0] = 3                                          # == number of labels
+    with pytest.raises(ValueError):
+        _validate_targets(bad, 3)
+    bad = rows.copy()
+    bad[4, 5] = -1
+    with pytest.raises(ValueError):
+        _validate_targets(bad, 3)
+    dead = rows.copy()
+    dead[0, 5:10] = [99, 0.0, 0.5, 0.1, 0.1]               # behind the zero terminator: never read, never refused
+    _validate_targets(dead, 3)
