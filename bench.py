@@ -4,20 +4,21 @@
 One "step" = one episode: B query images (SxS) + N support images with masks (SmxSm) through the
 reweighting net, the Darknet-19 meta feature extractor, the fused reweighting (x) 1x1 head and
 RegionLossV2 (+ backward + SGD in --mode train).  Inputs are synthetic and resident in HBM before the
-timed region.  Default workload = BASELINE.json configs[1]: darknet_dynamic.cfg + reweighting_net.cfg,
-B=64, 15 base classes, 416x416, fp32, 1 MI355X.  (BASELINE.json's metric STRING quotes "64x416x416 query + 20x224x224
-support": 20 supports of 224x224, which neither configs[1] (15 base classes) nor the cfg (support 416x416,
-cfg/reweighting_net.cfg:4-5) has.  The default is the heavier, cfg-true episode -- 2022 vs 1941.5 GFLOP forward -- and
-the metric-string episode is timed as well and reported under `also_measured`; `--classes 20 --support 224` makes it
-the headline line.)
+timed region.
+
+Headline workload = the episode BASELINE.json's `metric` string quotes: 64 queries 416x416 + 20 supports 224x224 on
+darknet_dynamic.cfg + reweighting_net.cfg, fp32, train step, 1 MI355X.  BASELINE configs[1] as the cfg files spell it
+(15 base classes, supports at the cfg's 416x416) is timed in the same run and reported under `also_measured`
+(`--classes 15 --support 416` makes it the headline line instead).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-           --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+           --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3 [--scaling strong]
 
-Multi-GPU: one process per GPU, each rank runs its own episode shard (B queries + its own N supports,
-like the reference's per-GPU MetaDataset draw) -> weak scaling; in train mode gradients are SUM
-all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+Multi-GPU: one process per GPU over RCCL.  --scaling weak (default): every rank runs its own episode (B queries + its
+own N supports, like the reference's per-GPU MetaDataset draw).  --scaling strong: ONE global episode per step, its B
+queries split over the ranks, the N supports replicated on every rank.  In train mode gradients are SUM
+all-reduced.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import contextlib
@@ -38,6 +39,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured with a float4 copy)
 
 
 def synth_targets(rng, bs, cs):
@@ -89,91 +91,167 @@ def conv_flops_per_image(blocks, S):
     return total
 
 
-def cpu_baseline(dyn_cfg, rw_cfg, args, full_flops):
-    """The oracle (PyTorch-CPU fp32 restatement of the reference) timed on this host on a bounded sample
-    of the same workload: a smaller episode, scaled to the full episode by conv FLOPs."""
+def episode_flops(blocks, lblocks, B, N, S, Sm):
+    """Algorithmic forward FLOPs of one episode: detector on B queries + reweighting net on N supports + the
+    1x1 head on B*N (image, class) rows."""
+    g = S // 32
+    head = 2.0 * 1024 * 30 * g * g
+    return B * conv_flops_per_image(blocks, S) + N * conv_flops_per_image(lblocks, Sm) + head * N * B - B * head
+
+
+def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev):
+    """The oracle (PyTorch-CPU fp32 restatement of the reference) timed on this host on a bounded sample of the same
+    workload -- a smaller query batch, scaled to the full episode by conv FLOPs; median of 3 repetitions after one
+    warm-up.  The oracle's outputs on that sample are then the checker for the HIP path on the same
+    weights and inputs: BASELINE.json's metric names "RegionLoss max|delta| vs ref"."""
     from oracle.net import OracleDarknet
     from oracle.region import region_loss_v2
-    from fewshot_detection_amd.cfg import parse_cfg
+    from fewshot_detection_amd.cfg import cfg, parse_cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    Bs, Ns = min(args.batch, 32), args.classes          # about 10-20 s of CPU work on a 64-core host
+    Bs, Ns = min(args.batch, 32), args.classes          # about 7 s of CPU work per repetition on a 64-core host
+    torch.manual_seed(4242)
     ora = OracleDarknet(dyn_cfg, rw_cfg).train()
     x, metax, mask, tgt = synth_episode(123, Bs, Ns, args.size, args.support)
     blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
-    sample_flops = Bs * conv_flops_per_image(blocks, args.size) + Ns * conv_flops_per_image(lblocks, args.support)
-    mult = 3.0 if args.mode == "train" else 1.0
+    sample_flops = episode_flops(blocks, lblocks, Bs, Ns, args.size, args.support)
+    state = {k: v.clone() for k, v in ora.state_dict().items()}        # before train-mode forwards move the BN statistics
 
     def once():
+        ora.zero_grad()
         t0 = time.time()
         out = ora(x, metax, mask)
         r = region_loss_v2(out, tgt, ora.region.anchors, seen=0)
         if args.mode == "train":
             r["loss"].backward()
-        return time.time() - t0
+        return time.time() - t0, out, r
 
     once()
-    t = once()
-    eps = 1.0 / (t * (full_flops * mult) / (sample_flops * mult))
-    return {"value": eps, "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": "oracle (PyTorch-CPU fp32) %s of B=%d queries %dx%d + N=%d supports %dx%d in %.2f s, "
-                      "scaled by conv FLOPs (%.1f -> %.1f GFLOP) to the full episode"
+    reps = []
+    for _ in range(3):
+        ora.load_state_dict(state)
+        t, out, r = once()
+        reps.append(t)
+    t = sorted(reps)[1]
+    eps = 1.0 / (t * full_flops / sample_flops)
+    base = {"value": eps, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32) %s of B=%d queries %dx%d + N=%d supports %dx%d: median of 3 repetitions "
+                      "after 1 warm-up = %.2f s (%s), scaled by conv FLOPs (%.1f -> %.1f GFLOP forward) to the full episode"
                       % (args.mode, Bs, args.size, args.size, Ns, args.support, args.support, t,
-                         sample_flops / 1e9, full_flops / 1e9)}
+                         ", ".join("%.2f" % v for v in reps), sample_flops / 1e9, full_flops / 1e9)}
+    if args.no_parity:
+        return base, None
+
+    # ---- parity of the HIP path on the very same sample, weights and (for the loss) inputs --------------------------
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        net2 = Darknet(dyn_cfg, rw_cfg)
+    net2.load_state_dict(state)
+    net2 = net2.to(dev).train().set_compute_dtype(args.dtype)
+    region2 = net2.models[len(net2.models) - 1]
+    region2.verbose = False
+    region2.seen = 0
+    keep_neg = cfg.neg_ratio
+    cfg.neg_ratio = "full"
+    try:
+        hip_out = net2(x.to(dev), metax.to(dev), mask.to(dev))
+        hip_loss = region2(hip_out, tgt)
+        hip_out_cpu = hip_out.detach().cpu()
+        # the loss on IDENTICAL inputs: feed the HIP network's own output to both implementations
+        leaf = hip_out.detach().clone().requires_grad_(True)
+        loss_same = region2(leaf, tgt)
+        loss_same.backward()
+        ref_in = hip_out_cpu.clone().requires_grad_(True)
+        r_same = region_loss_v2(ref_in, tgt, ora.region.anchors, seen=0)
+        r_same["loss"].backward()
+        st = region2.stats()
+    finally:
+        cfg.neg_ratio = keep_neg
+    ref_out = out.detach()
+    ref_loss = float(r["loss"].detach())
+    parity = {
+        "config": "B=%d queries %dx%d + N=%d supports %dx%d, train-mode BatchNorm, neg_ratio=full, seen=0, fp32 oracle "
+                  "weights loaded into the HIP model (%s compute)" % (Bs, args.size, args.size, Ns, args.support,
+                                                                      args.support, args.dtype),
+        "forward_max_abs_delta": float((hip_out_cpu - ref_out).abs().max()),
+        "forward_max_abs": float(ref_out.abs().max()),
+        "region_loss_end_to_end": {"hip": float(hip_loss.detach()), "oracle": ref_loss,
+                                   "abs_delta": abs(float(hip_loss.detach()) - ref_loss),
+                                   "rel_delta": abs(float(hip_loss.detach()) - ref_loss) / max(1.0, abs(ref_loss))},
+        # RegionLoss on identical inputs (the head output the HIP network produced)
+        "region_loss_abs_delta": abs(float(loss_same.detach()) - float(r_same["loss"].detach())),
+        "region_loss_max_abs_delta": float((leaf.grad.cpu() - ref_in.grad).abs().max()),
+        "region_loss_grad_max_abs": float(ref_in.grad.abs().max()),
+        "anchor_assignment_equal": bool((st["nGT"], st["nCorrect"], st["nProposals"]) ==
+                                        (r_same["nGT"], r_same["nCorrect"], r_same["nProposals"])),
+        "tolerance": 1e-3,
+    }
+    parity["ok"] = bool(parity["forward_max_abs_delta"] < (1e-3 if args.dtype == "f32" else 5e-2 * parity["forward_max_abs"])
+                        and parity["region_loss_max_abs_delta"] < 1e-3 and parity["anchor_assignment_equal"]
+                        and parity["region_loss_abs_delta"] < 1e-3 * max(1.0, abs(ref_loss)))
+    del net2
+    torch.cuda.empty_cache()
+    return base, parity
 
 
-def extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, det_flops_img, rw224_flops_img):
-    """Two more timings of the same model on the same device (N=1 only, ~1 s): the forward pass alone (the
-    north_star's ">= 0.6x MFMA roofline on the forward" target) and the episode shape quoted in BASELINE.json's
-    metric string (20 supports of 224x224 instead of configs[1]'s 15 classes at the cfg's 416x416)."""
+def timed(fn, n=5, w=2):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, blocks, lblocks):
+    """More timings of the same model on the same device (N=1 only, ~2 s): the forward pass alone (north_star:
+    ">= 0.6x MFMA roofline on the Darknet-19 forward") and BASELINE configs[1] exactly as the cfg files spell it
+    (15 base classes, supports 416x416) -- or the metric-string episode when configs[1] is the headline."""
     peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-
-    def timed(fn, n=5, w=2):
-        for _ in range(w):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+    out = {}
 
     def fwd():
         with torch.no_grad():
             region(net(x, metax, mask), target)
 
-    out = {}
     t = timed(fwd)
     out["forward_only"] = {"what": "forward (train-mode BN) + RegionLoss forward/grad kernel, no backward, same episode",
                            "ms": t * 1e3, "episodes_per_s": 1.0 / t, "algorithmic_tflops": full_flops / t / 1e12,
-                           "frac_of_mfma_peak": full_flops / t / 1e12 / peak}
+                           "frac_of_mfma_peak_algorithmic": full_flops / t / 1e12 / peak}
     if args.mode == "train" and opt is not None:
-        x2, metax2, mask2, target2 = synth_episode(2000, args.batch, 20, args.size, 224)
+        other = (15, 416) if (args.classes, args.support) != (15, 416) else (20, 224)
+        x2, metax2, mask2, target2 = synth_episode(2000, args.batch, other[0], args.size, other[1])
         metax2, mask2 = metax2.to(dev), mask2.to(dev)
 
-        def train20():
+        def train_other():
             region.seen += args.batch
             opt.backward_and_step(region(net(x, metax2, mask2), target2))
 
-        t = timed(train20)
-        g = args.size // 32
-        fl = args.batch * det_flops_img + 20 * rw224_flops_img + 2.0 * 1024 * 30 * (20 - 1) * args.batch * g * g
-        out["metric_string_episode"] = {"what": "train step on B=%d queries %dx%d + 20 supports 224x224 (the shape in "
-                                                "BASELINE.json's metric string)" % (args.batch, args.size, args.size),
-                                        "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t,
-                                        "img_per_s": args.batch / t, "episode_forward_gflop": fl / 1e9}
+        t = timed(train_other)
+        fl = episode_flops(blocks, lblocks, args.batch, other[0], args.size, other[1])
+        key = "configs1_cfg_episode" if other == (15, 416) else "metric_string_episode"
+        out[key] = {"what": "train step on B=%d queries %dx%d + %d supports %dx%d (%s)"
+                            % (args.batch, args.size, args.size, other[0], other[1], other[1],
+                               "BASELINE configs[1] with the cfg's own support size and 15 base classes" if other == (15, 416)
+                               else "the shape in BASELINE.json's metric string"),
+                    "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t, "img_per_s": args.batch / t,
+                    "episode_forward_gflop": fl / 1e9, "dtype": args.dtype}
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_conv_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE
-    passes of this very command).  Counters cannot be read live; None if the summary is absent."""
-    p = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-    try:
-        return json.load(open(p))["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+def pmc_traffic(name):
+    """A committed rocprofv3 PMC summary (profiles/<name>, produced by tools/pmc_traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE passes of this very command).  Counters cannot be read live; None if the summary is absent."""
+    for rnd in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
+        try:
+            return json.load(open(p)), "profiles/%s_%s (offline rocprofv3 PMC passes of this command)" % (rnd, name)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -181,18 +259,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="query images per GPU")
-    ap.add_argument("--classes", type=int, default=15, help="episode classes N")
+    ap.add_argument("--batch", type=int, default=64, help="query images per GPU (weak) / per global episode (strong)")
+    ap.add_argument("--classes", type=int, default=20, help="episode classes N = support images")
     ap.add_argument("--size", type=int, default=416)
-    ap.add_argument("--support", type=int, default=416, help="support image side (cfg/reweighting_net.cfg: 416)")
+    ap.add_argument("--support", type=int, default=224, help="support image side (BASELINE.json metric: 224; cfg/reweighting_net.cfg: 416)")
     ap.add_argument("--mode", choices=["train", "forward"], default=None)
     ap.add_argument("--neg", default="1", help="cfg.neg_ratio ('full' or a number; metayolo.data uses 1)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="conv compute mode: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, fp32 "
-                         "accumulate, fp32 BN/loss/master weights and fp32 weight gradients (BASELINE C3/C5)")
-    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps that carry the per-launch HIP events")
+                         "accumulate, fp32 BN/loss/master weights (BASELINE C3/C5)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
+                         "the ranks, supports replicated (SURVEY 8e)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps that carry the per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / metric-string-episode timings")
+    ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle comparison on the cpu_baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / other-episode timings")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
     args = ap.parse_args()
 
@@ -218,6 +300,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    strong = args.scaling == "strong" and world > 1
+    if strong and args.batch % world:
+        raise SystemExit("--scaling strong needs --batch (%d) divisible by the number of ranks (%d)" % (args.batch, world))
+    local_batch = args.batch // world if strong else args.batch
+    global_batch = args.batch if strong else args.batch * world
 
     from fewshot_detection_amd import backward as bw
     from fewshot_detection_amd import cfgs, ops
@@ -237,8 +324,12 @@ def main():
         net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(args.dtype)
     region = net.models[len(net.models) - 1]
     region.verbose = False
-    x, metax, mask, target = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
-    x, metax, mask = x.to(dev), metax.to(dev), mask.to(dev)
+    if strong:      # one global episode: this rank's slice of the queries and targets, every support on every rank
+        gx, metax, mask, gt = synth_episode(1000, args.batch, args.classes, args.size, args.support)
+        x, target = gx[rank * local_batch:(rank + 1) * local_batch], gt[rank * local_batch:(rank + 1) * local_batch]
+    else:
+        x, metax, mask, target = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
+    x, metax, mask = x.to(dev).contiguous(), metax.to(dev), mask.to(dev)
 
     opt = None
     if args.mode == "train":
@@ -246,11 +337,12 @@ def main():
         # train_meta.py:123-147: lr = 0.001/factor/global_batch, wd = decay*global_batch*factor (factor 3 for
         # neg=1).  From RANDOM init (no pretrained darknet19 weights here) that step size diverges within
         # two steps, so the bench shrinks lr by 1e-4; the work per step is unchanged.
-        opt = EpisodeTrainer(net, lr=1e-4 * 0.001 / 3 / (args.batch * world), momentum=0.9,
-                             weight_decay=0.0005 * args.batch * world * 3, process_group=dist)
+        opt = EpisodeTrainer(net, lr=1e-4 * 0.001 / 3 / global_batch, momentum=0.9,
+                             weight_decay=0.0005 * global_batch * 3, process_group=dist)
+        opt.time_allreduce = world > 1
 
     def step():
-        region.seen += args.batch * world
+        region.seen += global_batch
         out = net(x, metax, mask)
         loss = region(out, target)
         if opt is not None:
@@ -265,26 +357,30 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # the per-launch event records below create thousands of python objects: keep the cyclic collector from
-    # stopping the host for a full-heap pass in the middle of the timed region
+    if opt is not None:
+        opt.allreduce_wait_ms = [0.0] * len(opt.buckets)
+    # the per-launch event records below create python objects: keep the cyclic collector from stopping the host for a
+    # full-heap pass in the middle of the timed region
     gc.collect()
     gc.disable()
-    # Per-launch HIP events (roofline) are recorded inside the timed region, on its first `prof_steps` steps only: each
-    # record is a barrier packet in the queue and 230 of them per step cost ~1 ms of the 39 ms step.
-    prof_steps = min(args.steps, args.profile_steps)
+    # Per-kernel HIP events (roofline) are recorded INSIDE the timed region, on its first `prof_steps` steps only: each
+    # record is a barrier packet in the queue and a few hundred of them per step cost ~1 ms of the step.
+    prof_steps = min(args.steps, args.profile_steps) if rank == 0 else 0
     prof = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ops.PROFILE = prof if i < prof_steps else None
+        if i == 0 and prof_steps:
+            ops.PROFILE = prof
+            ops.kernel_profile(True)
+        elif i == prof_steps and prof_steps:
+            ops.PROFILE = None
+            ops.kernel_profile(False)
         loss = step()
     ops.PROFILE = None
+    ops.kernel_profile(False)
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if rank != 0:                        # only rank 0 evaluates the per-launch events
-        for e in prof:
-            if e[4]:
-                ops.lib().fsd_event_destroy(e[4]); ops.lib().fsd_event_destroy(e[5])
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -293,76 +389,112 @@ def main():
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:
+        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        kp = ops.kernel_profile_collect()
+        per = max(1, prof_steps)
+
+        def mfma(cls):
+            k = kp[cls]
+            tf = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            return {"achieved": tf, "peak": peak if cls != "gemm_bf16" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / (peak if cls != "gemm_bf16" else PEAK_BF16_MFMA_TFLOPS),
+                    "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
+                    "avg_kernel_ms": k["ms"] / max(1, k["launches"]), "issued_gflop_per_step": k["work"] / per / 1e9}
+
+        def hbm(cls):
+            k = kp[cls]
+            gbs = k["work"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            return {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
+                    "algorithmic_mb_per_step": k["work"] / per / 1e6}
+
         conv_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
         conv_flops = sum(e[2] for e in prof)
-        exec_flops = sum(e[3] for e in prof)
-        # the MFMA kernel alone (events recorded inside the library right around conv_gemm_kernel)
-        L = ops.lib()
-        gemm = [(L.fsd_event_elapsed_ms(e[4], e[5]), e[3]) for e in prof if e[4]]
-        for e in prof:
-            if e[4]:
-                L.fsd_event_destroy(e[4]); L.fsd_event_destroy(e[5])
-        gemm = [(m, f) for m, f in gemm if m > 0]
-        gemm_ms = sum(m for m, _ in gemm)
-        gemm_flops = sum(f for _, f in gemm)
-        gemm_tflops = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        if args.per_layer:
-            per = len(prof) // max(1, prof_steps)
-            for i in range(per):
-                ms_i = sum(prof[s * per + i][0].elapsed_time(prof[s * per + i][1]) for s in range(prof_steps)) / prof_steps
+        algorithmic = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        if args.per_layer and prof_steps:
+            n_l = len(prof) // prof_steps
+            for i in range(n_l):
+                ms_i = sum(prof[s_ * n_l + i][0].elapsed_time(prof[s_ * n_l + i][1]) for s_ in range(prof_steps)) / prof_steps
                 fl = prof[i][2]
                 sys.stderr.write("conv launch %2d: %8.3f ms  %8.2f GFLOP  %6.1f TFLOP/s\n" % (i, ms_i, fl / 1e9, fl / ms_i / 1e9))
         blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
-        det = conv_flops_per_image(blocks, args.size)
-        full_flops = (args.batch * det + args.classes * conv_flops_per_image(lblocks, args.support)
-                      + 2.0 * 1024 * 30 * args.classes * args.batch * (args.size // 32) ** 2
-                      - args.batch * 2.0 * 1024 * 30 * (args.size // 32) ** 2)
+        full_flops = episode_flops(blocks, lblocks, local_batch, args.classes, args.size, args.support)
         ms = elapsed / args.steps * 1e3
+        episodes_per_step = 1 if strong else world
+        dom = "gemm_fwd" if args.dtype == "f32" or kp["gemm_bf16"]["ms"] < kp["gemm_fwd"]["ms"] else "gemm_bf16"
+        roof = mfma(dom)
+        traffic, traffic_src = pmc_traffic("conv_traffic.json")
+        is_c2 = (args.mode == "train" and local_batch == 64 and args.dtype == "f32")
+        roof.update({
+            "bound": "mfma",
+            "kernel": ("conv_gemm_kernel: the fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernel behind the direct "
+                       "3x3/1x1 convolutions, the data gradients and the 36 / 16 position GEMMs of the Winograd layers"
+                       if dom == "gemm_fwd" else "conv_gemm_bf16_kernel: bf16-operand MFMA implicit GEMM"),
+            "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
+                    "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
+                    "its own duration, HIP events recorded by the library right around every launch on the launch stream "
+                    "during the first `profiled_steps` timed steps; avg_kernel_ms is what rocprofv3 --kernel-trace --stats "
+                    "shows for this kernel (profiles/)",
+            "profiled_steps": prof_steps,
+            "traffic": (traffic or {}).get("hbm_bytes_per_launch") if is_c2 else None,
+            "traffic_source": traffic_src if is_c2 else None,
+            "traffic_note": "HBM bytes per CONV LAUNCH (direct kernel, or transform + GEMM + transform of a Winograd layer), "
+                            "FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes; measured on the configs[1] episode",
+            "algorithmic_speedup": {
+                "what": "direct-convolution FLOPs (2*k*k*Cin*Cout*pixels, SURVEY 8d) of the forward + data-gradient conv "
+                        "launches / the HIP-event time of those launches (transforms included)",
+                "algorithmic_tflops": algorithmic, "x_mfma_peak": algorithmic / peak,
+                "conv_launch_ms_per_step": conv_ms / per, "launches_per_step": len(prof) // per},
+            "wgrad_kernel": dict(mfma("gemm_wgrad"), kernel="wgrad_kernel: fp32 MFMA weight-gradient reduction GEMMs "
+                                                            "(direct layers and the F(3x3,4x4) Winograd batches)"),
+            "hbm": dict(hbm("wino_transform"), bound="hbm",
+                        kernel="Winograd input / output / gradient transform kernels (wino4_input, wino4_output, wino4_dy, ...)",
+                        note="achieved = algorithmic bytes (activation once + transformed positions once, per launch) / "
+                             "kernel duration"),
+            "hbm_other": {"bn_leaky_pool_backward": hbm("act_bwd"), "bn_leaky_pool_forward": hbm("act_fwd"),
+                          "region_loss": hbm("region"), "sgd": hbm("sgd"), "first_layer": hbm("first_layer")},
+        })
+        if kp["gemm_bf16"]["launches"] and dom != "gemm_bf16":
+            roof["bf16_kernels"] = mfma("gemm_bf16")
+        mf = kp["gemm_fwd"]["ms"] + kp["gemm_wgrad"]["ms"] + kp["gemm_bf16"]["ms"]
+        mw = kp["gemm_fwd"]["work"] + kp["gemm_wgrad"]["work"] + kp["gemm_bf16"]["work"]
+        roof["mfma_all"] = {"issued_tflops": mw / (mf * 1e-3) / 1e12 if mf > 0 else 0.0, "kernel_ms_per_step": mf / per,
+                            "issued_gflop_per_step": mw / per / 1e9,
+                            "frac_of_step_time": (mf / per) / ms if ms > 0 else 0.0,
+                            "whole_step_issued_tflops": (mw / per) / (ms * 1e-3) / 1e12}
+        roof["timed_kernel_ms_per_step"] = sum(v["ms"] for v in kp.values()) / per
+        sname = "B=%d queries %dx%d + N=%d supports %dx%d" % (local_batch, args.size, args.size, args.classes,
+                                                                args.support, args.support)
+        which = ("the episode of BASELINE.json's metric string (64x416x416 query + 20x224x224 support) on configs[1]'s "
+                 "darknet_dynamic.cfg + reweighting_net.cfg base-training model"
+                 if (args.batch, args.classes, args.size, args.support) == (64, 20, 416, 224) else
+                 "BASELINE configs[1] darknet_dynamic.cfg + reweighting_net.cfg base-training episode")
         res = {
             "metric": "episodes/sec (%dx%dx%d query + %dx%dx%d support) %s" % (
                 args.batch, args.size, args.size, args.classes, args.support, args.support,
                 "train step (fwd + RegionLoss + bwd + SGD)" if args.mode == "train" else "forward + RegionLoss fwd/grad"),
-            "value": world * args.steps / elapsed, "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "value": episodes_per_step * args.steps / elapsed, "unit": "episodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "img_per_s": world * args.batch * args.steps / elapsed,
+            "img_per_s": global_batch * args.steps / elapsed,
             "loss": loss_val,
-            "config": {"workload": "BASELINE configs[1]: darknet_dynamic.cfg + reweighting_net.cfg base-training "
-                                   "episode, B=%d queries %dx%d + N=%d supports %dx%d per GPU, %s, neg_ratio=%s"
-                                   % (args.batch, args.size, args.size, args.classes, args.support, args.support,
-                                      "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
-                       "mode": args.mode, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+            "config": {"workload": "%s: %s per %s, %s, neg_ratio=%s" % (
+                           which, sname, "rank (supports replicated, queries split)" if strong else "GPU",
+                           "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
+                       "mode": args.mode, "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "episode_forward_gflop": full_flops / 1e9},
-            "roofline": {"bound": "mfma",
-                         "kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM: direct 3x3/1x1 convolutions and the 36 / 16 "
-                                   "batched GEMMs of the Winograd F(4x4,3x3) / F(2x2,3x3) layers; forward + data gradient)"
-                         if args.dtype == "f32" else "conv_gemm_bf16_kernel (bf16 implicit-GEMM conv, all launches)",
-                         "note": "achieved/frac follow the contract: ALGORITHMIC direct-convolution FLOPs "
-                                 "(2*k*k*Cin*Cout*pixels, SURVEY 8d) / HIP-event time of the conv launches (a launch = one "
-                                 "direct kernel, or Winograd input transform + batched GEMM + output transform). Winograd "
-                                 "issues 4x / 2.25x fewer multiplications on its layers, which is why the algorithmic rate "
-                                 "can exceed the MFMA peak; `mfma_kernel` is the hardware-utilisation view: FLOPs really "
-                                 "issued by conv_gemm_kernel / its own duration (events recorded right around that kernel; "
-                                 "avg_kernel_ms is what rocprofv3 --stats shows for conv_gemm_kernel)",
-                         "achieved": achieved, "peak": (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                         "unit": "TFLOP/s",
-                         "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                         "traffic": pmc_traffic() if args.mode == "train" and args.batch == 64 and args.dtype == "f32" else None,
-                         "mfma_kernel": {"issued_tflops": gemm_tflops, "frac": gemm_tflops / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                                         "kernel_ms_per_step": gemm_ms / max(1, prof_steps),
-                                         "avg_kernel_ms": gemm_ms / max(1, len(gemm)), "kernels_timed": len(gemm)},
-                         "launch_issued_tflops": exec_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                         "flop_per_launch": conv_flops / max(1, len(prof)),
-                         "avg_launch_ms": conv_ms / max(1, len(prof)),
-                         "launches_per_step": len(prof) // max(1, prof_steps), "profiled_steps": prof_steps,
-                         "conv_ms_per_step": conv_ms / max(1, prof_steps)},
+            "roofline": roof,
         }
+        if opt is not None:
+            res["dp"] = {"world_size": opt.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
+                         "gradient_buckets": len(opt.buckets), "bucket_mb": [4e-6 * (hi - lo) for lo, hi in opt.buckets],
+                         "allreduce_wait_ms_per_step": [v / args.steps for v in opt.allreduce_wait_ms]}
         if world == 1 and not args.no_extras:
-            res["also_measured"] = extras(net, region, opt, args, dev, x, metax, mask, target, full_flops,
-                                          conv_flops_per_image(blocks, args.size), conv_flops_per_image(lblocks, 224))
+            res["also_measured"] = extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, blocks, lblocks)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(dyn_cfg, rw_cfg, args, full_flops)
+            res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev)
+            if parity is not None:
+                res["parity"] = parity
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

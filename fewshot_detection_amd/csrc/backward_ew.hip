@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fsdet.h"
+#include "profile.hpp"
 
 namespace {
 
@@ -423,6 +424,8 @@ extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float
   a.C = channels; a.pool = pool; a.pixels = (long long)batch * height * width; a.slope = slope;
   const int cg = channels / 4;
   const int gl = cg <= 8 ? 8 : cg <= 16 ? 16 : cg <= 32 ? 32 : 64;    // channel-group lanes per block
+  // algorithmic bytes: read dz (+ dz_full) and y, write dt
+  fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * ((double)batch * a.OH * a.OW + (dz_full ? 3.0 : 2.0) * a.pixels), stream);
   if (pool == 1) {
     // window-major: a block covers cells_per_block cells = one partial row (fsd_bn_act_pool_bwd_rows)
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
@@ -461,6 +464,7 @@ extern "C" int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const
   (void)hipGetLastError();
   if (!dt || !y || !coef || !mean || !invstd || (channels & 3) || (y_ld & 3)) return FSD_ERR_ARG;
   const long long total = pixels * (channels / 4);
+  fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * 3.0 * pixels, stream);      // read dt, y; write dy
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
                      invstd, channels, total);
   return (int)hipGetLastError();
@@ -523,6 +527,7 @@ extern "C" int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, fl
   if (count == 0) return FSD_OK;
   long long blocks = (count + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  fsd_prof::Scope prof(fsd_prof::kSgd, 20.0 * count, stream);          // w, g, m read; w, m written
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, grad, momentum_buf, lr, momentum,
                      weight_decay, first_step, count);
   return (int)hipGetLastError();

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "fsdet.h"
 #include "conv_common.hpp"
+#include "profile.hpp"
 
 namespace {
 
@@ -332,18 +333,14 @@ inline int tile_cfg(int cin, int ksize, int cout, bool nchw = false) {
   return (cout <= 32 && !nchw) ? kTile128x32 : kTile64;
 }
 
-// measurement aid (fsd_profile_next_gemm): events recorded around the next MFMA conv kernel launched by this thread
-thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
-
 template <typename K>
 int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipEvent_t ev0 = t_ev_start, ev1 = t_ev_stop;
-  t_ev_start = t_ev_stop = nullptr;
-  if (ev0) (void)hipEventRecord(ev0, stream);
+  // issued MFMA work of this launch: every output row x column x (padded) reduction element, all batches
+  const double rows = (double)a.M - (double)a.m_base;
+  fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * rows * a.Cout * ((double)a.nk * kBK) * a.batches, stream);
   hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, a.batches), dim3(threads), lds, stream, a);
-  if (ev1) (void)hipEventRecord(ev1, stream);
   return (int)hipGetLastError();
 }
 
@@ -434,18 +431,6 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   if (big) return pick == 'c' ? launch<128, 128, 2, 2, 2>(a, false, stream) : launch<128, 128, 2, 2, 2, true>(a, false, stream);
   return launch<64, 64, 2, 2, 1>(a, false, stream);
 }
-
-extern "C" void* fsd_event_create(void) {
-  hipEvent_t e = nullptr;
-  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
-}
-extern "C" void fsd_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
-extern "C" float fsd_event_elapsed_ms(void* start, void* stop) {
-  float ms = -1.f;
-  if (!start || !stop || hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
-  return hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? ms : -1.f;
-}
-extern "C" void fsd_profile_next_gemm(void* start, void* stop) { t_ev_start = (hipEvent_t)start; t_ev_stop = (hipEvent_t)stop; }
 
 extern "C" size_t fsd_packed_weight_elems(int rows, int red, int ksize) {
   return (size_t)round_up(rows, 128) * (size_t)round_up(ksize * ksize * round_up(red, 4), kBK);

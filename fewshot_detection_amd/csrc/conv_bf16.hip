@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include "fsdet.h"
 #include "conv_common.hpp"
+#include "profile.hpp"
 
 namespace {
 
@@ -210,6 +211,7 @@ int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
     auto k = conv_gemm_bf16_kernel<BM, BN, WM, WN, NCHW, FAST>;                                                 \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
+    fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * ((double)a.M - a.m_base) * a.Cout * ((double)a.nk * kBKh), stream); \
     hipLaunchKernelGGL(k, grid, block, lds, stream, a);                                                         \
     return (int)hipGetLastError();                                                                              \
   } while (0)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fsdet.h"
+#include "profile.hpp"
 
 namespace {
 
@@ -149,6 +150,7 @@ extern "C" int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w
   a.H = height; a.W = width; a.cin = cin; a.Cout = cout; a.pixels = pixels;
   const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
   a.ppw = (int)((per + 63) / 64 * 64);
+  fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + 4.0 * cout), stream);
   hipLaunchKernelGGL(conv_first_kernel, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fsdet.h"
+#include "profile.hpp"
 
 namespace {
 
@@ -290,6 +291,8 @@ extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* 
   const int cg = channels / 4;
   const long long total = (long long)batch * OH * OW * cg;
   const dim3 grid(blocks_for(total, 256)), block(256);
+  // algorithmic bytes: read y once, write z once
+  fsd_prof::Scope prof(fsd_prof::kActFwd, 4.0 * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
   if (pool == 0)
     hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else if (pool == 1)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fsdet.h"
+#include "profile.hpp"
 
 namespace {
 
@@ -338,6 +339,9 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
                9 * (kThreads / 64) * sizeof(double);
   lds = (lds + 15) & ~(size_t)15;
   if (lds > 64 * 1024) return FSD_ERR_UNSUPPORTED;
+  // algorithmic bytes of the loss: head output read once, its gradient written once, the float64 targets read once
+  const double io_bytes = 2.0 * 4.0 * rows * (double)num_anchors * (5 + num_classes) * height * width + 8.0 * rows * (double)target_len;
+  fsd_prof::Scope prof(fsd_prof::kRegion, io_bytes, stream);
   hipLaunchKernelGGL(region_rows_kernel, dim3(rows), dim3(kThreads), lds, stream, p);
 
   int groups, n_logits;

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "fsdet.h"
 #include "conv_common.hpp"
+#include "profile.hpp"
 
 namespace {
 
@@ -477,6 +478,8 @@ inline int f32_variant() {
 inline int tile_of(int bf16) { return (bf16 || f32_variant() == 1 || f32_variant() == 2) ? 128 : 64; }
 
 int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
+  // issued MFMA work: dW[Cout][ncols] reduced over M pixel rows, per batch (grid.z)
+  fsd_prof::Scope prof(bf16 ? fsd_prof::kGemmBf16 : fsd_prof::kGemmWgrad, 2.0 * a.M * (double)a.Cout * a.ncols * grid.z, stream);
   if (bf16) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
     hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
@@ -590,8 +593,11 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
-                       dim3(kThreads), lds, stream, a);
+    {
+      fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
+      hipLaunchKernelGGL((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
+                         dim3(kThreads), lds, stream, a);
+    }
     if (pl.tail_rows) {                                      // the last < 32 rows -> workspace slot `splits`
       WgradArgs t = a;
       t.dy = dy + full * dy_ld; t.x = x + full * x_ld; t.ws = ws + (long long)pl.splits * cout * cin;
@@ -600,6 +606,7 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
       t.n_tiles = (cin + 63) / 64;
       t.pix_per_split = kBK;
       const size_t lds1 = (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
+      fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * t.M * (double)cout * cin * batches, stream);
       hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true>), dim3(t.m_tiles * t.n_tiles, 1, batches), dim3(kThreads), lds1,
                          stream, t);
     }
@@ -650,8 +657,11 @@ extern "C" int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, co
   a.dt_ld = (unsigned)dt_ld; a.y_ld = (unsigned)y_ld; a.x_ld = (unsigned)x_ld;
   a.H = height; a.W = width; a.Cout = cout; a.pixels = pixels;
   a.ppw = round_up((int)((pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 16);
-  if (cin == 4) hipLaunchKernelGGL(wgrad_first_kernel<true>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad_first_kernel<false>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  {
+    fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (8.0 * cout + 16.0), stream);
+    if (cin == 4) hipLaunchKernelGGL(wgrad_first_kernel<true>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(wgrad_first_kernel<false>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  }
   if (blocks <= 8)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(1, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
   else

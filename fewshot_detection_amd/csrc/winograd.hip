@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include "fsdet.h"
 #include "conv_common.hpp"
+#include "profile.hpp"
 
 namespace {
 
@@ -735,6 +736,8 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   const long long n_in = T * (cin / 4);
   const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
   if (!V) {
+    // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
+    fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
       hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
@@ -749,6 +752,7 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   if (rc != 0) return rc;
   const int tpb = tiles_per_block(T);
   const unsigned bx = (unsigned)((T + tpb - 1) / tpb);
+  fsd_prof::Scope prof_out(fsd_prof::kWinoXform, 4.0 * cout * ((double)batch * height * width + (double)P * T), stream);
   if (tile == 2) {
     hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cout / 4 + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
                        bn_partial, height, width, TH, TW, cout, T, tpb);
@@ -811,6 +815,8 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   const long long n_in = T * (cin / 4), n_dy = T * (cout / 4);
   const float* V = v_kept;                                   // the forward pass's B^T d B, if the caller kept it
   if (!V) {
+    // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
+    fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
       hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
@@ -821,6 +827,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   }
   const float* Wg = wt_in;                                   // already transformed (fsd_wino_grad_transforms)
   if (!Wg) {
+    fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cout * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
       hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
                          height, width, TH, TW, cout, T);
@@ -851,6 +858,7 @@ extern "C" int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const 
   const long long T = tiles_of(batch, height, width, 4);
   if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   const long long n = T * (channels / 2);
+  fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (2.0 * batch * height * width + 2.0 * 36 * T), stream);
   hipLaunchKernelGGL(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
                      mean, invstd, v_out, wt_out, height, width, TH, TW, channels, T);
   return (int)hipGetLastError();
@@ -866,6 +874,8 @@ extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float*
   const long long T = tiles_of(batch, height, width, 4);
   if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   const long long n = T * (channels / 4);
+  // reads dt and y, writes dy (in place) and the 36 transformed positions
+  fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (3.0 * batch * height * width + 36.0 * T), stream);
   hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
                      height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd);
   return (int)hipGetLastError();

@@ -139,8 +139,6 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        g0, g1 = L.fsd_event_create(), L.fsd_event_create()     # around the MFMA kernel alone
-        L.fsd_profile_next_gemm(g0, g1)
         e0.record()
     v = None
     if keep_v is not None:
@@ -152,7 +150,7 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
-        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles, g0, g1))
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles))
     return y, partial
 
 
@@ -183,8 +181,9 @@ WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where 
 # run at 4.5 TB/s at L2 level against 7.8 TB/s for the single-tensor transforms), so it is off by default.
 FUSE_WINO_GRAD = os.environ.get("FSD_FUSE_WINO_GRAD", "0") == "1"
 WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
-PROFILE = None      # bench.py sets this to a list, one entry per conv launch: (start_event, end_event, algorithmic_flops,
-                    # executed_mfma_flops, gemm_start, gemm_stop) -- the last two are fsd_event handles around the MFMA kernel alone
+PROFILE = None      # bench.py sets this to a list, one entry per conv launch (forward / data gradient; a Winograd launch =
+                    # transform + GEMM + transform): (start_event, end_event, algorithmic_flops, executed_mfma_flops).
+                    # Per-KERNEL timing is the library's job (fsd_profile_enable / fsd_profile_collect).
 
 
 def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None):
@@ -202,12 +201,8 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
         tiles = (lib().fsd_conv_row_tiles_bf16(xv.pixels) if bf16
                  else lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize))
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
-    g0 = g1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if not bf16:
-            g0, g1 = lib().fsd_event_create(), lib().fsd_event_create()
-            lib().fsd_profile_next_gemm(g0, g1)
         e0.record()
     fn = lib().fsd_conv2d_fwd_bf16 if bf16 else lib().fsd_conv2d_fwd
     check(fn(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
@@ -216,7 +211,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
-                        2.0 * ksize * ksize * xv.C * cout * xv.pixels, g0, g1))
+                        2.0 * ksize * ksize * xv.C * cout * xv.pixels))
     return y, partial
 
 
@@ -236,7 +231,7 @@ def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False):
                                xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_c4_fwd")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels, None, None))
+        PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels))
     return y, partial
 
 
@@ -475,3 +470,21 @@ def head_unfold_bwd(dweff, head_w, dyn, param=None):
 def sgd_step(w, g, buf, lr, momentum, weight_decay, first):
     check(lib().fsd_sgd_step(w.data_ptr(), g.data_ptr(), buf.data_ptr(), lr, momentum, weight_decay,
                              1 if first else 0, w.numel(), _stream()), "fsd_sgd_step")
+
+
+PROFILE_CLASSES = ("gemm_fwd", "gemm_wgrad", "wino_transform", "act_bwd", "act_fwd", "region", "sgd", "first_layer",
+                   "gemm_bf16")
+
+
+def kernel_profile(enable):
+    """Switch the library's per-kernel-class HIP-event recording on / off (include/fsdet.h)."""
+    lib().fsd_profile_enable(1 if enable else 0)
+
+
+def kernel_profile_collect():
+    """-> {class: dict(ms, work, launches)} summed over everything recorded since the last collect (synchronises)."""
+    import ctypes as C
+    n = lib().fsd_profile_num_classes()
+    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+    check(lib().fsd_profile_collect(ms, work, cnt, n), "fsd_profile_collect")
+    return {PROFILE_CLASSES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n)}

@@ -287,13 +287,22 @@ int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dy
 int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
                  float weight_decay, int first_step, long long count, hipStream_t stream);
 
-/* Measurement aids (bench.py): HIP events owned by the library's runtime, and a one-shot hook that records a pair of
- * them immediately before / after the NEXT fp32 MFMA convolution kernel (conv_gemm_kernel) this thread launches --
- * inside fsd_conv2d_fwd or inside the Winograd pipeline -- on the stream that launch uses. */
-void* fsd_event_create(void);
-void fsd_event_destroy(void* event);
-float fsd_event_elapsed_ms(void* start, void* stop);   /* waits for `stop`; < 0 on error */
-void fsd_profile_next_gemm(void* start, void* stop);
+/* Measurement aid (bench.py): while enabled, every launch of the kernel classes below is bracketed by HIP events on the
+ * stream it is launched on and booked with its work figure; fsd_profile_collect waits for the recorded events, returns
+ * per class the summed kernel time [ms], the summed work and the number of launches, and clears the records.
+ *   class 0 conv_gemm_kernel (fp32 MFMA forward / data-gradient / Winograd position GEMMs)   work = MFMA FLOPs issued
+ *   class 1 wgrad_kernel (fp32 MFMA weight-gradient reduction GEMMs)                          work = MFMA FLOPs issued
+ *   class 2 Winograd input / output / gradient transforms                                     work = algorithmic bytes
+ *   class 3 BatchNorm / leaky / maxpool backward passes                                       work = algorithmic bytes
+ *   class 4 BatchNorm + leaky + maxpool forward pass                                          work = algorithmic bytes
+ *   class 5 region-loss kernels                                                               work = algorithmic bytes
+ *   class 6 fused SGD step                                                                    work = algorithmic bytes
+ *   class 7 first-layer direct-operand kernels                                                work = algorithmic bytes
+ *   class 8 bf16-operand MFMA GEMM kernels                                                    work = MFMA FLOPs issued
+ * Arrays must hold fsd_profile_num_classes() entries.  Off by default: one relaxed load per launch. */
+void fsd_profile_enable(int on);
+int fsd_profile_num_classes(void);
+int fsd_profile_collect(double* ms, double* work, long long* launches, int n_classes);
 
 const char* fsd_version(void);
 

@@ -24,6 +24,10 @@ def test_algorithmic_flops_match_baseline_md(tmp_path):
     assert abs(rw416 / 1e9 - 9.053) < 0.002 and abs(rw224 / 1e9 - 2.598) < 0.002
     c2 = 64 * det + 15 * rw416 + head * 15 * 64 - 64 * head               # the expression bench.py uses (B=64, N=15)
     assert abs(c2 / 1e9 - 2022.0) < 0.5                                   # "episode forward, C2 (Sm=416)"
+    blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
+    assert abs(bench.episode_flops(blocks, lblocks, 64, 15, 416, 416) / 1e9 - 2022.0) < 0.5
+    assert abs(bench.episode_flops(blocks, lblocks, 64, 20, 416, 224) / 1e9 - 1941.5) < 0.5    # the metric-string episode
+    assert abs(bench.episode_flops(blocks, lblocks, 32, 20, 416, 416) / 1e9 - 1125.8) < 0.5    # C4
     det608 = bench.conv_flops_per_image(parse_cfg(dyn_cfg), 608) - 2.0 * 1024 * 30 * 19 * 19
     assert abs(det608 / 1e9 - 62.624) < 0.005                             # C5 detector GFLOP / image
 

@@ -107,3 +107,37 @@ def test_bench_two_ranks_one_json_line():
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
     assert res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 8
     assert res["value"] > 0 and "roofline" in res and "cpu_baseline" not in res
+
+
+def _run_bench(extra, env_extra, nproc=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
+               "--steps", "2", "--warmup", "1", "--batch", "4", "--classes", "3", "--size", "160", "--support", "160"] + extra
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            break
+        sys.stderr.write("bench.py attempt %d failed:\n%s\n" % (attempt, out.stderr[-3000:]))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count('{"metric"') == 1, out.stdout
+    start = out.stdout.index('{"metric"')
+    return json.loads(out.stdout[start:].splitlines()[0])
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu():
+    """--scaling strong: ONE global episode, its queries split over the ranks, supports replicated."""
+    res = _run_bench(["--scaling", "strong"], {"FSD_BENCH_BACKEND": "gloo"})
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert abs(res["img_per_s"] - 4 * res["value"]) < 1e-6 * res["img_per_s"]        # one 4-query episode per step
+    assert res["dp"]["world_size"] == 2 and len(res["dp"]["allreduce_wait_ms_per_step"]) == res["dp"]["gradient_buckets"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: >= 2 GPUs")
+def test_bench_two_ranks_over_rccl():
+    """The real transport: two ranks, one MI355X each, backend nccl (= RCCL over xGMI).  Self-skips on 1-GPU boxes."""
+    for scaling in ("weak", "strong"):
+        res = _run_bench(["--scaling", scaling], {"FSD_BENCH_BACKEND": "nccl"})
+        assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["dp"]["world_size"] == 2
+        assert res["dp"]["backend"] == "nccl" and res["value"] > 0
