@@ -23,6 +23,7 @@ PROTOTYPES = {
     "fsd_region_loss_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p,
                                      _f, _f, _f, _f, _f, _ll, _i, _i, _i, _p, _p]),
     "fsd_region_decode": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _f, _i, _i, _i, _p]),
+    "fsd_region_nms": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "fsd_packed_weight_elems": (_sz, [_i, _i, _i]),
     "fsd_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "fsd_conv_row_tiles": (_i, [_ll, _i, _i, _i]),

@@ -442,3 +442,89 @@ extern "C" int fsd_region_decode(const float* output, float* boxes, int* counts,
   hipLaunchKernelGGL(region_decode_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, p);
   return (int)hipGetLastError();
 }
+
+// ---- greedy non-maximum suppression (utils.nms, utils.py:85-104) --------------------------------
+namespace {
+
+constexpr int kNmsMax = 2048;       // boxes per (image, class) row held in LDS (19x19x5 = 1805 at 608x608)
+
+// One workgroup per (image, class) row of fsd_region_decode's output.  The reference sorts the row by the FLOAT32
+// value 1 - det_conf (a FloatTensor, utils.py:89-93) -- distinct confidences can share a key, and ties keep the
+// visiting order -- then walks it: a box that is still alive suppresses (det_conf := 0) every later box whose
+// python-double IoU with it exceeds the threshold.  Here: 64-bit composite keys {fp32 bits of 1-det, visiting order,
+// slot} sorted with a bitonic network in LDS, then the same walk with the inner loop spread over the workgroup.
+__global__ __launch_bounds__(kThreads) void region_nms_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                               int cap, float thresh, int* __restrict__ keep_idx,
+                                                               int* __restrict__ keep_counts) {
+  __shared__ unsigned long long s_key[kNmsMax];
+  __shared__ float s_box[kNmsMax][5];       // cx, cy, w, h, det in sorted order
+  __shared__ int s_alive[kNmsMax];
+  __shared__ int s_total;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  int n = counts[row];
+  n = n < cap ? n : cap;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const float* rb = boxes + (long long)row * cap * 8;
+  for (int i = tid; i < np2; i += kThreads) {
+    unsigned long long k = ~0ull;           // padding sorts last
+    if (i < n) {
+      const float key = 1.0f - rb[i * 8 + 5];
+      k = ((unsigned long long)__float_as_uint(key) << 32) | ((unsigned long long)(unsigned)rb[i * 8] << 16) | (unsigned)i;
+    }
+    s_key[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < np2 / 2; t += kThreads) {
+        const int lo = 2 * t - (t & (stride - 1));          // index with bit `stride` clear
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = s_key[lo], b = s_key[hi];
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += kThreads) {
+    const int slot = (int)(s_key[i] & 0xffffu);
+    const float* b = rb + slot * 8;
+    s_box[i][0] = b[1]; s_box[i][1] = b[2]; s_box[i][2] = b[3]; s_box[i][3] = b[4]; s_box[i][4] = b[5];
+    s_alive[i] = b[5] > 0.f ? 1 : 0;
+  }
+  __syncthreads();
+  const double th = (double)thresh;
+  for (int i = 0; i < n; ++i) {
+    if (s_alive[i]) {                        // uniform: every thread reads the same LDS word after the barrier
+      const double x1 = s_box[i][0], y1 = s_box[i][1], w1 = s_box[i][2], h1 = s_box[i][3];
+      for (int j = i + 1 + tid; j < n; j += kThreads)
+        if (s_alive[j] && iou_f64(x1, y1, w1, h1, s_box[j][0], s_box[j][1], s_box[j][2], s_box[j][3]) > th) s_alive[j] = 0;
+      __syncthreads();
+    }
+  }
+  // compaction of the survivors in sorted order (wave 0, ballot prefix)
+  if (tid < 64) {
+    int off = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + tid;
+      const bool flag = i < n && s_alive[i];
+      const unsigned long long m = __ballot(flag);
+      if (flag) keep_idx[(long long)row * cap + off + __popcll(m & ((1ull << tid) - 1ull))] = (int)(s_key[i] & 0xffffu);
+      off += __popcll(m);
+    }
+    if (tid == 0) { keep_counts[row] = off; s_total = off; }
+  }
+}
+
+}  // namespace
+
+extern "C" int fsd_region_nms(const float* boxes, const int* counts, int rows, int cap, float nms_thresh, int* keep_idx,
+                              int* keep_counts, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!boxes || !counts || !keep_idx || !keep_counts || rows < 1 || cap < 1) return FSD_ERR_ARG;
+  if (cap > kNmsMax) return FSD_ERR_UNSUPPORTED;          // also keeps slot and visiting order inside 16 bits
+  hipLaunchKernelGGL(region_nms_kernel, dim3(rows), dim3(kThreads), 0, stream, boxes, counts, cap, nms_thresh, keep_idx,
+                     keep_counts);
+  return (int)hipGetLastError();
+}

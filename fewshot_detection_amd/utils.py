@@ -56,12 +56,13 @@ def bbox_ious(boxes1, boxes2, x1y1x2y2=True):
     return carea / (w1 * h1 + w2 * h2 - carea)
 
 
-def nms(boxes, nms_thresh):
-    """Greedy NMS over python box lists [cx, cy, w, h, det_conf, ...]; reference utils.py:85-104.
-    Suppressed boxes get det_conf = 0 in place, like the reference."""
+def _nms_host(boxes, nms_thresh):
+    """utils.nms on plain python lists, statement for statement (the float32 sort key 1 - det_conf included)."""
+    import numpy as np
     if len(boxes) == 0:
         return boxes
-    order = sorted(range(len(boxes)), key=lambda i: 1 - boxes[i][4])
+    keys = [float(np.float32(1.0) - np.float32(b[4])) for b in boxes]
+    order = sorted(range(len(boxes)), key=lambda i: keys[i])
     out = []
     for pos, i in enumerate(order):
         bi = boxes[i]
@@ -72,6 +73,62 @@ def nms(boxes, nms_thresh):
                 if bbox_iou(bi, bj, x1y1x2y2=False) > nms_thresh:
                     bj[4] = 0
     return out
+
+
+class _DecodedBatch(object):
+    """Device-resident result of one fsd_region_decode call, shared by the per-row box lists it produced, so that the
+    first `nms(row, thresh)` on any of them runs fsd_region_nms for ALL rows of the batch in one launch."""
+
+    def __init__(self, boxes_dev, counts_dev, counts_host, positions):
+        self.boxes_dev, self.counts_dev = boxes_dev, counts_dev
+        self.counts = counts_host            # survivors per row
+        self.positions = positions           # per row: slot -> position in the reference-ordered python list
+        self._nms = {}
+
+    def kept_positions(self, thresh):
+        import numpy as np
+
+        from ._lib import check, lib
+        key = float(thresh)
+        if key not in self._nms:
+            rows, cap = self.boxes_dev.shape[0], self.boxes_dev.shape[1]
+            keep_idx = torch.empty((rows, cap), dtype=torch.int32, device=self.boxes_dev.device)
+            keep_cnt = torch.empty(rows, dtype=torch.int32, device=self.boxes_dev.device)
+            check(lib().fsd_region_nms(self.boxes_dev.data_ptr(), self.counts_dev.data_ptr(), rows, cap, key,
+                                       keep_idx.data_ptr(), keep_cnt.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "fsd_region_nms")
+            cnt = keep_cnt.cpu().numpy()
+            top = int(cnt.max()) if rows else 0
+            idx = keep_idx[:, :max(top, 1)].cpu().numpy()
+            self._nms[key] = [self.positions[r][idx[r, :cnt[r]]] if cnt[r] else np.zeros(0, np.int64)
+                              for r in range(rows)]
+        return self._nms[key]
+
+
+class BoxList(list):
+    """A row of get_region_boxes[_v2]: a plain list of [cx, cy, w, h, det_conf, cls_conf, cls_id] (the reference's
+    return type) that remembers where its boxes live on the device."""
+    __slots__ = ("_batch", "_row", "_n")
+
+
+NMS_MAX_DEVICE_ROW = 2048      # fsd_region_nms holds one row in LDS
+
+
+def nms(boxes, nms_thresh):
+    """Greedy NMS over box lists [cx, cy, w, h, det_conf, ...]; reference utils.py:85-104.  Suppressed boxes get
+    det_conf = 0 in place, like the reference.  Rows that came out of get_region_boxes[_v2] unmodified are suppressed
+    on the device (fsd_region_nms, all rows of their batch in one launch); anything else takes the host loop."""
+    if len(boxes) == 0:
+        return boxes
+    batch = getattr(boxes, "_batch", None)
+    if batch is None or boxes._n != len(boxes) or batch.boxes_dev.shape[1] > NMS_MAX_DEVICE_ROW:
+        return _nms_host(boxes, nms_thresh)
+    kept = batch.kept_positions(nms_thresh)[boxes._row]
+    alive = set(int(p) for p in kept)
+    for pos, b in enumerate(boxes):
+        if pos not in alive:
+            b[4] = 0                        # the reference's in-place side effect on suppressed boxes
+    return [boxes[int(p)] for p in kept]
 
 
 def convert2cpu(gpu_matrix):
@@ -121,11 +178,20 @@ def _decode(output, rows_per_image, conf_thresh, num_classes, anchors, num_ancho
     top = int(n.max()) if rows else 0
     host = boxes[:, :max(top, 1)].cpu().numpy()
     all_boxes = []
+    positions = []
     for r in range(rows):
         b = host[r, :n[r]]
-        b = b[np.argsort(b[:, 0], kind="stable")]         # restore the reference's (cy, cx, anchor) order
-        all_boxes.append([[float(v[1]), float(v[2]), float(v[3]), float(v[4]), float(v[5]), float(v[6]), int(v[7])]
-                          for v in b])
+        order = np.argsort(b[:, 0], kind="stable")        # restore the reference's (cy, cx, anchor) order
+        pos = np.empty(len(order), np.int64)
+        pos[order] = np.arange(len(order))
+        positions.append(pos)
+        row = BoxList([float(v[1]), float(v[2]), float(v[3]), float(v[4]), float(v[5]), float(v[6]), int(v[7])]
+                      for v in b[order])
+        row._row, row._n = r, len(order)
+        all_boxes.append(row)
+    batch = _DecodedBatch(boxes, counts, n, positions)
+    for row in all_boxes:
+        row._batch = batch
     return all_boxes
 
 

@@ -82,6 +82,16 @@ int fsd_region_decode(const float* output, float* boxes, int* counts, int rows, 
                       float conf_thresh, int only_objectness, int softmax_over_rows, int cap,
                       hipStream_t stream);
 
+/* Greedy non-maximum suppression = utils.nms (utils.py:85-104) on fsd_region_decode's output, one workgroup per
+ * (image, class) row: sort by the float32 key 1 - det_conf (ties keep the reference's visiting order), then every
+ * surviving box suppresses the later boxes whose IoU (centre format, double arithmetic like utils.bbox_iou) with it
+ * exceeds nms_thresh.
+ *   keep_idx    [rows][cap] int32: slots (second index of `boxes`) of the kept boxes, in the reference's output order
+ *   keep_counts [rows] int32
+ * cap <= 2048 (19x19x5 = 1805 cells at 608x608), else FSD_ERR_UNSUPPORTED. */
+int fsd_region_nms(const float* boxes, const int* counts, int rows, int cap, float nms_thresh, int* keep_idx,
+                   int* keep_counts, hipStream_t stream);
+
 /* ---- convolution as implicit GEMM on the fp32 matrix cores -------------------------------- */
 /* Packed weight: [round_up(rows,128)][round_up(taps*round_up(red,4), 32)] floats, K-major,
  * k = tap*red4 + r.  mode 0 (forward, replaces nn.Conv2d weight use, darknet_meta.py:236-250):

@@ -13,6 +13,12 @@ Outputs (committed, small):
     region_v2_*.npz      RegionLossV2 forward + autograd gradient + build_targets tensors
     region_v1.npz        RegionLoss (v1) forward + gradient
     decode_v2.npz        utils.get_region_boxes_v2 + utils.nms
+    decode_valid.npz     the call valid_ensemble.py:148 makes: get_region_boxes_v2(.., only_objectness=0, validation=1)
+                         at conf 0.005 + utils.nms at 0.45 (dense rows: ~all cells survive the threshold)
+    ensemble.npz         valid_ensemble.py:86-100,137-166 on the mini net: running mean of the reweighting vectors over
+                         support batches -> detect_forward -> decode -> NMS
+
+`python make_golden.py NAME...` regenerates only the named fixtures (decode_valid, ensemble); no argument = all.
 
 The GPU box has no /root/reference; tests there read only these files.
 """
@@ -247,6 +253,87 @@ def gold_decode_extra(u):
     np.savez_compressed(os.path.join(HERE, "decode_extra.npz"), **out)
 
 
+def _flat(rows):
+    return np.array([[r] + [float(v) for v in bx] for r, bl in enumerate(rows) for bx in bl], np.float64).reshape(-1, 8)
+
+
+def gold_decode_valid(u):
+    """valid_ensemble.py:148: get_region_boxes_v2(output, n_cls, 0.005, 1, anchors, 5, 0, 1) and :166 nms(boxes, 0.45)."""
+    out = {}
+    for k, (bs, cs, g, scale, shift) in enumerate([(1, 2, 13, 1.0, 0.0), (1, 2, 19, 1.3, -1.0), (1, 2, 7, 0.02, 0.0)]):
+        torch.manual_seed(60 + k)
+        o = torch.randn(bs * cs, 30, g, g) * scale
+        o[:, 4::6] += shift
+        if k == 2:
+            # nearly equal objectness everywhere: many boxes share the float32 sort key 1 - det_conf
+            o[:, 4::6] = torch.round(o[:, 4::6] * 2e4) / 2e4 + 3.0
+        boxes = u.get_region_boxes_v2(o, cs, 0.005, 1, ANCH, 5, 0, 1)
+        flat = _flat(boxes)
+        kept = _flat([u.nms(bl, 0.45) for bl in boxes])
+        out.update({"v%d_output" % k: o.numpy(), "v%d_cfg" % k: np.array([bs, cs, g]),
+                    "v%d_boxes" % k: flat, "v%d_kept" % k: kept})
+    np.savez_compressed(os.path.join(HERE, "decode_valid.npz"), conf_thresh=0.005, nms_thresh=0.45, **out)
+
+
+def _load_stream(net, path):
+    """Read a darknet weight stream into the REFERENCE model.  (The reference's own load_conv_bn copies a flat buffer
+    into a 4-D parameter, cfg.py:455, which torch 0.3.1 allowed and current torch refuses; the field order below is
+    the one its save_conv_bn / save_conv wrote the file in, cfg.py:457-481.)"""
+    buf = np.fromfile(path, dtype=np.float32)[4:]
+    pos = 0
+
+    def pull(t):
+        nonlocal pos
+        t.data.copy_(torch.from_numpy(buf[pos:pos + t.numel()]).view_as(t))
+        pos += t.numel()
+
+    for blocks, models in ((net.blocks, net.models), (net.learnet_blocks, net.learnet_models)):
+        for ind, blk in enumerate(blocks[1:]):
+            if blk["type"] != "convolutional":
+                continue
+            m = models[ind]
+            if net.is_dynamic(blk) and m[0].weight is None:
+                continue
+            if int(blk["batch_normalize"]):
+                for t in (m[1].bias, m[1].weight, m[1].running_mean, m[1].running_var, m[0].weight):
+                    pull(t)
+            else:
+                pull(m[0].bias)
+                pull(m[0].weight)
+    assert pos == buf.size, (pos, buf.size)
+
+
+def gold_ensemble(dm, u):
+    """valid_ensemble.py:86-100 (running mean of the reweighting vectors over all support batches, by class id) and
+    :137-166 (detect_forward with the averaged vectors, decode, NMS) on the reduced-width twin of the meta detector."""
+    torch.manual_seed(70)
+    net = dm.Darknet(os.path.join(HERE, "mini_dynamic.cfg"), os.path.join(HERE, "mini_reweight.cfg"))
+    _load_stream(net, os.path.join(HERE, "mini.weights"))
+    net.eval()
+    n_cls = 3
+    clsids = [0, 2, 1, 0, 2, 2, 1, 0, 0]
+    metax = torch.rand(len(clsids), 3, 64, 64)
+    mask = torch.zeros(len(clsids), 1, 64, 64)
+    for i in range(len(clsids)):
+        mask[i, 0, 3 * i:30 + 3 * i, 2 * i:25 + 4 * i] = 1
+    enews = [0.0] * n_cls
+    cnt = [0.0] * n_cls
+    with torch.no_grad():
+        for lo, hi in ((0, 4), (4, 8), (8, 9)):                      # the loader's batches
+            dw = net.meta_forward(metax[lo:hi], mask[lo:hi])[0]
+            for ci, c in enumerate(clsids[lo:hi]):
+                enews[c] = enews[c] * cnt[c] / (cnt[c] + 1) + dw[ci] / (cnt[c] + 1)
+                cnt[c] += 1
+        dynamic_weights = [torch.stack(enews)]
+        x = torch.rand(2, 3, 160, 160)
+        output = net.detect_forward(x, dynamic_weights)
+    boxes = u.get_region_boxes_v2(output, n_cls, 0.005, net.num_classes, net.anchors, net.num_anchors, 0, 1)
+    kept = [u.nms(bl, 0.45) for bl in boxes]
+    np.savez_compressed(os.path.join(HERE, "ensemble.npz"), metax=metax.numpy(), mask=mask.numpy(), clsids=np.array(clsids),
+                        batches=np.array([[0, 4], [4, 8], [8, 9]]), x=x.numpy(), vectors=dynamic_weights[0].numpy(),
+                        output=output.numpy(), boxes=_flat(boxes), kept=_flat(kept))
+
+
 def gold_episode(im):
     """image.fill_truth_detection_meta / fill_truth_detection on random label files (out-of-range boxes, degenerate
     boxes, classes outside the base set, more than 50 boxes)."""
@@ -282,6 +369,15 @@ def gold_episode(im):
 
 def main():
     assert ref_shim.available(), "needs /root/reference"
+    only = set(sys.argv[1:])
+    if only:
+        u = ref_shim.load("utils")
+        if "decode_valid" in only:
+            gold_decode_valid(u)
+        if "ensemble" in only:
+            gold_ensemble(ref_shim.load("darknet_meta"), u)
+        print("golden vectors written to", HERE, sorted(only))
+        return
     u = ref_shim.load("utils")
     cfgmod = ref_shim.load("cfg")
     rl = ref_shim.load("region_loss")
@@ -296,6 +392,8 @@ def main():
     gold_region_v1(rl, cfgmod)
     gold_decode(u)
     gold_decode_extra(u)
+    gold_decode_valid(u)
+    gold_ensemble(dm, u)
     gold_episode(ref_shim.load("image"))
     print("golden vectors written to", HERE)
 

@@ -18,6 +18,8 @@ own (python-2, CUDA) execution:
   * `pred_boxes[i]` row -> `.tolist()` (0.3.1 element access gave python doubles)
   * `size_average=False/True` -> `reduction='sum'/'mean'`
   * `easydict` (absent) -> a 10-line attribute dict
+  * `torch.sort(det_confs)` in utils.nms -> `stable=True` (tie order of equal float32 keys is unspecified in torch and
+    version dependent; pinned to the visiting order)
 
 It is used by tests/golden/make_golden.py to mint fixtures from the reference
 itself, and by `-m "not gpu"` tests (skipped when /root/reference is absent).
@@ -90,6 +92,10 @@ _SUBS = {
     ],
     "utils": [
         ("anchor_step = len(anchors)/num_anchors", "anchor_step = len(anchors)//num_anchors"),
+        # utils.nms sorts the FLOAT32 keys 1 - det_conf; torch.sort leaves the order of EQUAL keys unspecified (and the
+        # CPU implementation differs between torch versions).  The fixtures pin ties to the boxes' visiting order, the
+        # only order that is a property of the algorithm rather than of one library build.
+        ("_,sortIds = torch.sort(det_confs)", "_,sortIds = torch.sort(det_confs, stable=True)"),
     ],
     "cfg": [],
     "dynamic_conv": [("import pdb", "pdb = None")],

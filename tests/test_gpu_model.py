@@ -187,10 +187,11 @@ def test_load_weights_after_a_forward_invalidates_packed_weights(dev, tmp_path):
     d = np.load(os.path.join(GOLD, "mini_forward.npz"))
     x, metax, mask = (torch.from_numpy(d[k]).to(dev) for k in ("x", "metax", "mask"))
     other = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
-    torch.manual_seed(5)
-    with torch.no_grad():
-        for p in other.parameters():
-            p.uniform_(-0.3, 0.3)
+    other.load_weights(os.path.join(GOLD, "mini.weights"))
+    with torch.no_grad():                                       # a second checkpoint: every conv filter flipped and scaled
+        for name, p in other.named_parameters():
+            if "conv" in name and name.endswith("weight"):
+                p.mul_(-0.7)
     p_other = str(tmp_path / "other.weights")
     other.save_weights(p_other)
     net = _mini(dev).eval()
@@ -206,10 +207,13 @@ def test_load_weights_after_a_forward_invalidates_packed_weights(dev, tmp_path):
     # a user's raw in-place edit through .data followed by the documented invalidation call
     from fewshot_detection_amd.engine import bump_weight_epoch
     with torch.no_grad():
-        net.models[0][0].weight.data.mul_(0.5)
+        net.models[21][0].weight.data.mul_(-3.0)               # 96 -> 64 3x3: runs from the packed K-major copy
         bump_weight_epoch()
         third = net(x, metax, mask)
-    assert float((third - second).abs().max()) > 1e-6
+        fresh_net.models[21][0].weight.data.mul_(-3.0)
+        bump_weight_epoch()
+        fresh3 = fresh_net(x, metax, mask)
+    assert float((third - second).abs().max()) > 1e-3 and torch.equal(third, fresh3)
 
 
 def test_network_inputs_are_validated(dev):

@@ -203,3 +203,45 @@ def test_region_targets_with_bad_class_ids_are_refused_on_the_host():
     dead = rows.copy()
     dead[0, 5:10] = [99, 0.0, 0.5, 0.1, 0.1]               # behind the zero terminator: never read, never refused
     _validate_targets(dead, 3)
+
+
+def test_host_nms_matches_reference_on_dense_rows_and_key_ties():
+    """utils.nms on plain lists == the reference's (tests/golden/decode_valid.npz: conf 0.005 -> ~all cells survive;
+    case v2 has many boxes sharing the float32 sort key 1 - det_conf, which only a stable sort on THAT key orders
+    like the reference)."""
+    from fewshot_detection_amd import utils
+    d = np.load(os.path.join(GOLD, "decode_valid.npz"))
+    for k in (2, 0):
+        boxes, kept = d["v%d_boxes" % k], d["v%d_kept" % k]
+        rows = sorted(set(boxes[:, 0].astype(int)))[:2]               # the O(n^2) python loop: two rows are enough
+        mine = []
+        for r in rows:
+            lst = [[float(v) for v in b[1:]] for b in boxes if int(b[0]) == r]
+            mine += [[r] + b for b in utils.nms(lst, float(d["nms_thresh"]))]
+        want = kept[np.isin(kept[:, 0].astype(int), rows)]
+        assert np.array_equal(np.array(mine), want), k
+
+
+def test_reweight_ensemble_running_mean_is_the_reference_expression():
+    from fewshot_detection_amd.ensemble import ReweightEnsemble, mean_by_group
+    g = torch.Generator().manual_seed(0)
+    clsids = [0, 2, 1, 0, 2, 2, 1, 0, 0]
+    dw = torch.randn(len(clsids), 8, 1, 1, generator=g)
+    ens = ReweightEnsemble(3)
+    enews, cnt = [0.0] * 3, [0.0] * 3
+    for lo, hi in ((0, 4), (4, 8), (8, 9)):
+        ens.add([dw[lo:hi]], torch.tensor(clsids[lo:hi]))
+        for ci, c in enumerate(clsids[lo:hi]):                             # valid_ensemble.py:96-98
+            enews[c] = enews[c] * cnt[c] / (cnt[c] + 1) + dw[lo:hi][ci] / (cnt[c] + 1)
+            cnt[c] += 1
+    out = ens.dynamic_weights()
+    assert len(out) == 1 and out[0].shape == (3, 8, 1, 1) and torch.equal(out[0], torch.stack(enews))
+    assert ens.counts == [4.0, 2.0, 3.0]
+    for c in range(3):
+        rows = [i for i, k in enumerate(clsids) if k == c]
+        assert torch.allclose(out[0][c], dw[rows].mean(0), atol=1e-6)
+    m = mean_by_group([dw], [4, 2, 3])
+    assert torch.allclose(m[0][1], dw[4:6].mean(0))
+    import pytest
+    with pytest.raises(ValueError):
+        ReweightEnsemble(4).dynamic_weights()
