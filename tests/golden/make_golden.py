@@ -328,10 +328,11 @@ def gold_ensemble(dm, u):
         x = torch.rand(2, 3, 160, 160)
         output = net.detect_forward(x, dynamic_weights)
     boxes = u.get_region_boxes_v2(output, n_cls, 0.005, net.num_classes, net.anchors, net.num_anchors, 0, 1)
+    flat = _flat(boxes)                                              # before nms zeroes suppressed det_confs in place
     kept = [u.nms(bl, 0.45) for bl in boxes]
     np.savez_compressed(os.path.join(HERE, "ensemble.npz"), metax=metax.numpy(), mask=mask.numpy(), clsids=np.array(clsids),
                         batches=np.array([[0, 4], [4, 8], [8, 9]]), x=x.numpy(), vectors=dynamic_weights[0].numpy(),
-                        output=output.numpy(), boxes=_flat(boxes), kept=_flat(kept))
+                        output=output.numpy(), boxes=flat, kept=_flat(kept))
 
 
 def gold_episode(im):
