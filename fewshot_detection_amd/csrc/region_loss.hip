@@ -459,7 +459,6 @@ __global__ __launch_bounds__(kThreads) void region_nms_kernel(const float* __res
   __shared__ unsigned long long s_key[kNmsMax];
   __shared__ float s_box[kNmsMax][5];       // cx, cy, w, h, det in sorted order
   __shared__ int s_alive[kNmsMax];
-  __shared__ int s_total;
   const int row = blockIdx.x, tid = threadIdx.x;
   int n = counts[row];
   n = n < cap ? n : cap;
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void region_nms_kernel(const float* __res
       if (flag) keep_idx[(long long)row * cap + off + __popcll(m & ((1ull << tid) - 1ull))] = (int)(s_key[i] & 0xffffu);
       off += __popcll(m);
     }
-    if (tid == 0) { keep_counts[row] = off; s_total = off; }
+    if (tid == 0) keep_counts[row] = off;
   }
 }
 

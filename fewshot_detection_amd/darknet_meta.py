@@ -255,6 +255,8 @@ class Darknet(nn.Module):
         if int(self.learnet_blocks[0]["feat_layer"]) != 0:
             raise NotImplementedError("feat_layer != 0 is not used by any shipped cfg")
         inputs = [metax, mask] if cfg.metain_type in (2, 3) else [metax]
+        if mask is None:          # RGB + mask already interleaved per pixel (episode.DeviceAugmenter layout="nhwc4")
+            inputs = [metax]
         params = _flat_params(self.learnet_models)
         out = _NetFn.apply(self._meta, self.training, len(inputs), False, *(inputs + params))
         return [out]

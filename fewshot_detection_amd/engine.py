@@ -194,7 +194,12 @@ class Network(object):
                     raise ValueError("reweighting vectors must be float32 (got %s)" % v.dtype)
         B, _, H, W = inputs[0].shape
         ctot = sum(t.shape[1] for t in inputs)
-        if len(inputs) == 1:
+        t0 = inputs[0]
+        if (len(inputs) == 1 and t0.shape[1] == 4 and t0.stride(1) == 1 and (H * W > 1)
+                and t0.is_contiguous(memory_format=torch.channels_last) and t0.data_ptr() % 16 == 0):
+            # 16-byte NHWC4 pixels already (episode.DeviceAugmenter layout="nhwc4"): the first layer reads them in place
+            x = View(t0.detach().permute(0, 2, 3, 1).reshape(B * H * W, 4), B, H, W, 4)
+        elif len(inputs) == 1:
             x = ops.nchw_to_nhwc(inputs[0])
         else:
             x = ops.new_view(B, H, W, (ctot + 3) // 4 * 4, inputs[0].device)

@@ -1,12 +1,20 @@
-"""Host-side episode bookkeeping around the hot path (label side): the per-class target rows RegionLossV2
-consumes, the support mask, and the learning-rate schedule of train_meta.py.  Plain numpy / python, same arithmetic and
-the same order-dependent quirks as the reference; pinned by tests/golden/episode.npz (minted from the reference's own
-functions).  The image side of the input pipeline (PIL crop / resize / HSV jitter) is NOT here.
+"""Episode input pipeline around the hot path.
+
+Label side (host, numpy; same arithmetic and order-dependent quirks as the reference, pinned by
+tests/golden/episode.npz): the per-class target rows RegionLossV2 consumes, the support mask, the LR schedule.
 
     fill_truth_detection_meta  <- image.py:144-192       fill_truth_detection <- image.py:90-141
     support_mask               <- dataset.py:378-398     lr_factor / adjust_learning_rate <- train_meta.py:123-163
+
+Image side (device): `draw_augmentation` consumes python's `random` exactly like image.data_augmentation +
+random_distort_image (image.py:36-76), `index_tables` / `distort_luts` turn one draw into the small tables the gather
+kernel needs, and `DeviceAugmenter` runs fsd_augment_batch: jitter crop + NEAREST resize + flip + HSV distortion +
+ToTensor for a whole batch in one launch, output = the network input (NCHW, or channels-last RGB+mask pixels that the
+first-layer kernels read without a layout pass).  Bit-exact with the reference on Pillow's 2018 defaults
+(tests/golden/augment.npz); the host only decodes the image files.
 """
 import os
+import random as _random
 
 import numpy as np
 
@@ -129,3 +137,152 @@ def adjust_learning_rate(batch, learning_rate, steps, scales, batch_size):
         else:
             break
     return lr, lr / batch_size
+
+
+# ---- image side ----------------------------------------------------------------------------------
+
+def draw_augmentation(ow, oh, jitter=0.2, hue=0.1, saturation=1.5, exposure=1.5, rand=_random):
+    """One image's random draws, in the order image.data_augmentation (image.py:52-76) and random_distort_image
+    (image.py:36-47) make them: pleft, pright, ptop, pbot, flip, then hue, saturation, exposure (each scale = one
+    uniform + one randint).  Returns the crop / flip / colour parameters and the (flip, dx, dy, sx, sy) the label
+    warp needs (fill_truth_detection* take 1/sx, 1/sy, image.py:241-244)."""
+    dw, dh = int(ow * jitter), int(oh * jitter)
+    pleft = rand.randint(-dw, dw)
+    pright = rand.randint(-dw, dw)
+    ptop = rand.randint(-dh, dh)
+    pbot = rand.randint(-dh, dh)
+    flip = rand.randint(1, 10000) % 2
+    swidth = ow - pleft - pright
+    sheight = oh - ptop - pbot
+    sx = float(swidth) / ow
+    sy = float(sheight) / oh
+    dx = (float(pleft) / ow) / sx
+    dy = (float(ptop) / oh) / sy
+    dhue = rand.uniform(-hue, hue)
+
+    def rand_scale(s):
+        scale = rand.uniform(1, s)
+        return scale if rand.randint(1, 10000) % 2 else 1. / scale
+    dsat = rand_scale(saturation)
+    dexp = rand_scale(exposure)
+    return dict(pleft=pleft, ptop=ptop, swidth=swidth, sheight=sheight, flip=flip, dx=dx, dy=dy, sx=sx, sy=sy,
+                hue=dhue, sat=dsat, val=dexp)
+
+
+def _nearest_table(box_w, out_w):
+    """Pillow's NEAREST resize of a box_w-wide image to out_w columns: source column per output column.  The running
+    sum `xo += scale` in double (Geometry.c ImagingScaleAffine) decides exact ties, so it is restated as a loop."""
+    tab = np.empty(out_w, np.int64)
+    scale = float(box_w) / float(out_w)
+    xo = scale * 0.5
+    for x in range(out_w):
+        tab[x] = int(xo)
+        xo += scale
+    tab[tab >= box_w] = -1
+    return tab
+
+
+def index_tables(p, ow, oh, shape):
+    """(xtab, ytab) int32 for fsd_augment_batch: source column / row of every output column / row, -1 where the
+    jittered crop box leaves the image (Pillow fills with black).  p = draw_augmentation(...) or None (plain resize,
+    data_augmentation(flag=False)).  shape = (width, height) like the reference's `shape`."""
+    out_w, out_h = int(shape[0]), int(shape[1])
+    if p is None:
+        return _nearest_table(ow, out_w).astype(np.int32), _nearest_table(oh, out_h).astype(np.int32)
+    cw, ch = p["swidth"] - 1, p["sheight"] - 1          # crop box (l, t, l + swidth - 1, t + sheight - 1), image.py:69
+    if cw < 1 or ch < 1:
+        raise ValueError("degenerate crop box %dx%d" % (cw, ch))
+    xs, ys = _nearest_table(cw, out_w), _nearest_table(ch, out_h)
+    xs = np.where(xs >= 0, xs + p["pleft"], -1)
+    ys = np.where(ys >= 0, ys + p["ptop"], -1)
+    xs = np.where((xs >= 0) & (xs < ow), xs, -1)
+    ys = np.where((ys >= 0) & (ys < oh), ys, -1)
+    if p["flip"]:
+        xs = xs[::-1]
+    return np.ascontiguousarray(xs, np.int32), np.ascontiguousarray(ys, np.int32)
+
+
+def _clip8(v):
+    v = int(v)                     # the reference's Pillow converted point() tables with C (int): truncation
+    return 0 if v < 0 else 255 if v > 255 else v
+
+
+def distort_luts(hue, sat, val):
+    """(3, 256) uint8: the tables image.distort_image applies to the H, S, V bands (image.py:19-34)."""
+    def change_hue(x):
+        x += hue * 255
+        if x > 255:
+            x -= 255
+        if x < 0:
+            x += 255
+        return x
+    return np.array([[_clip8(change_hue(i)) for i in range(256)],
+                     [_clip8(i * sat) for i in range(256)],
+                     [_clip8(i * val) for i in range(256)]], np.uint8)
+
+
+class DeviceAugmenter(object):
+    """Batch of decoded uint8 RGB images (any sizes) -> the float network input on the device.
+
+        aug = DeviceAugmenter(device)
+        params = [draw_augmentation(im.shape[1], im.shape[0]) for im in images]      # or None per image: plain resize
+        x = aug(images, params, (416, 416))                        # (B, 3, 416, 416) float32, contiguous NCHW
+        x4 = aug(images, params, (416, 416), layout="nhwc4")      # (B, 4, 416, 416) channels_last: zero-copy input
+        m4 = aug(supports, params, (416, 416), layout="nhwc4", mask_boxes=[(x1, y1, x2, y2), ...])   # RGB + mask
+    """
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceAugmenter needs a HIP device (there is no CPU fallback)")
+
+    def __call__(self, images, params, shape, layout="nchw", mask_boxes=None):
+        import torch
+
+        from ._lib import check, lib
+        if layout not in ("nchw", "nhwc4"):
+            raise ValueError("layout must be 'nchw' or 'nhwc4'")
+        if mask_boxes is not None and layout != "nhwc4":
+            raise ValueError("the support mask is channel 3 of the nhwc4 layout")
+        B = len(images)
+        if B < 1 or len(params) != B or (mask_boxes is not None and len(mask_boxes) != B):
+            raise ValueError("images / params / mask_boxes must have the same, non-zero length")
+        out_w, out_h = int(shape[0]), int(shape[1])
+        offs, widths, chunks, xt, yt, luts = [], [], [], [], [], []
+        any_lut = any(p is not None for p in params)
+        pos = 0
+        for im, p in zip(images, params):
+            a = np.ascontiguousarray(np.asarray(im), np.uint8)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("images must be (H, W, 3) uint8 RGB arrays, got %s" % (a.shape,))
+            oh, ow = a.shape[:2]
+            offs.append(pos)
+            widths.append(ow)
+            chunks.append(a.reshape(-1))
+            pos += a.size
+            xs, ys = index_tables(p, ow, oh, (out_w, out_h))
+            xt.append(xs)
+            yt.append(ys)
+            if any_lut:
+                luts.append(distort_luts(p["hue"], p["sat"], p["val"]) if p is not None
+                            else np.tile(np.arange(256, dtype=np.uint8), (3, 1)))
+        dev = self.device
+        src = torch.from_numpy(np.concatenate(chunks)).to(dev, non_blocking=True)
+        off_d = torch.tensor(offs, dtype=torch.int64).to(dev, non_blocking=True)
+        w_d = torch.tensor(widths, dtype=torch.int32).to(dev, non_blocking=True)
+        xt_d = torch.from_numpy(np.stack(xt)).to(dev, non_blocking=True)
+        yt_d = torch.from_numpy(np.stack(yt)).to(dev, non_blocking=True)
+        lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True) if any_lut else None
+        mb_d = None
+        if mask_boxes is not None:
+            mb_d = torch.tensor([[int(v) for v in b] for b in mask_boxes], dtype=torch.int32).to(dev, non_blocking=True)
+        if layout == "nchw":
+            out = torch.empty((B, 3, out_h, out_w), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((B, 4, out_h, out_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        check(lib().fsd_augment_batch(src.data_ptr(), off_d.data_ptr(), w_d.data_ptr(), xt_d.data_ptr(), yt_d.data_ptr(),
+                                      0 if lut_d is None else lut_d.data_ptr(), 0 if mb_d is None else mb_d.data_ptr(),
+                                      out.data_ptr(), B, out_h, out_w, 0 if layout == "nchw" else 1,
+                                      torch.cuda.current_stream().cuda_stream), "fsd_augment_batch")
+        return out

@@ -297,6 +297,21 @@ int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dy
 int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
                  float weight_decay, int first_step, long long count, hipStream_t stream);
 
+/* Episode input pipeline on the device = the image half of the reference's CPU loader: image.data_augmentation
+ * (jitter crop, NEAREST resize, horizontal flip, HSV distortion; image.py:13-87) + ToTensor (train_meta.py:176-178).
+ * One gather kernel from packed uint8 RGB (HWC) source images to the float network input.
+ *   src / img_off [B] / img_w [B]   packed source images, byte offset and width of image b
+ *   xtab [B][out_w], ytab [B][out_h] int32: source column / row of every output column / row, or -1 = outside the
+ *        image (black); crop offset, Pillow's nearest-neighbour arithmetic and the flip are folded in by the host
+ *        (episode.index_tables)
+ *   luts [B][3][256] uint8 (nullable): the H, S, V tables of image.distort_image; null = no colour distortion
+ *   mask_box [B][4] int32 x1, y1, x2, y2 (nullable, layout 1 only): support-mask rectangle (dataset.py:378-398)
+ *   layout 0: out = (B, 3, out_h, out_w) float NCHW;  layout 1: out = (B, out_h, out_w, 4) float, channel 3 = mask / 0
+ * Bit-exact with the reference run on Pillow with the 2018 defaults (tests/golden/augment.npz). */
+int fsd_augment_batch(const unsigned char* src, const long long* img_off, const int* img_w, const int* xtab,
+                      const int* ytab, const unsigned char* luts, const int* mask_box, float* out, int batch, int out_h,
+                      int out_w, int layout, hipStream_t stream);
+
 /* Measurement aid (bench.py): while enabled, every launch of the kernel classes below is bracketed by HIP events on the
  * stream it is launched on and booked with its work figure; fsd_profile_collect waits for the recorded events, returns
  * per class the summed kernel time [ms], the summed work and the number of launches, and clears the records.

@@ -18,7 +18,9 @@ Outputs (committed, small):
     ensemble.npz         valid_ensemble.py:86-100,137-166 on the mini net: running mean of the reweighting vectors over
                          support batches -> detect_forward -> decode -> NMS
 
-`python make_golden.py NAME...` regenerates only the named fixtures (decode_valid, ensemble); no argument = all.
+    augment.npz          image.data_augmentation (jitter crop, NEAREST resize, flip, HSV distortion) on synthetic images
+
+`python make_golden.py NAME...` regenerates only the named fixtures (decode_valid, ensemble, augment); no argument = all.
 
 The GPU box has no /root/reference; tests there read only these files.
 """
@@ -335,6 +337,29 @@ def gold_ensemble(dm, u):
                         output=output.numpy(), boxes=flat, kept=_flat(kept))
 
 
+def gold_augment(im):
+    """image.data_augmentation (crop with jitter, NEAREST resize, flip, HSV distortion; image.py:13-87) on synthetic
+    images with python's seeded `random`, as dataset.py:240-247 calls it (jitter .2, hue .1, saturation / exposure 1.5)."""
+    from PIL import Image
+    rng = np.random.RandomState(11)
+    out = {}
+    cases = [((50, 37), (32, 32)), ((64, 48), (32, 32)), ((33, 70), (48, 48)), ((41, 41), (64, 64)), ((20, 90), (32, 32)),
+             ((120, 80), (96, 96))]
+    for k, ((ow, oh), shape) in enumerate(cases):
+        arr = rng.randint(0, 256, (oh, ow, 3)).astype(np.uint8)
+        arr[: oh // 3, : ow // 2] = rng.randint(0, 256, 3)               # flat patches: grey / saturated colours too
+        arr[oh // 2:, ow // 2:] = np.array([200, 200, 200])
+        random.seed(100 + k)
+        img, flip, dx, dy, sx, sy = im.data_augmentation(Image.fromarray(arr), shape, 0.2, 0.1, 1.5, 1.5)
+        nxt = random.random()                                            # pins how many draws were consumed
+        plain, *_ = im.data_augmentation(Image.fromarray(arr), shape, 0.2, 0.1, 1.5, 1.5, flag=False)
+        out.update({"in%d" % k: arr, "shape%d" % k: np.array(shape), "out%d" % k: np.array(img),
+                    "plain%d" % k: np.array(plain), "par%d" % k: np.array([flip, dx, dy, sx, sy]),
+                    "next_random%d" % k: nxt})
+    out["n"] = len(cases)
+    np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
+
+
 def gold_episode(im):
     """image.fill_truth_detection_meta / fill_truth_detection on random label files (out-of-range boxes, degenerate
     boxes, classes outside the base set, more than 50 boxes)."""
@@ -377,6 +402,8 @@ def main():
             gold_decode_valid(u)
         if "ensemble" in only:
             gold_ensemble(ref_shim.load("darknet_meta"), u)
+        if "augment" in only:
+            gold_augment(ref_shim.load("image"))
         print("golden vectors written to", HERE, sorted(only))
         return
     u = ref_shim.load("utils")
@@ -396,6 +423,7 @@ def main():
     gold_decode_valid(u)
     gold_ensemble(dm, u)
     gold_episode(ref_shim.load("image"))
+    gold_augment(ref_shim.load("image"))
     print("golden vectors written to", HERE)
 
 

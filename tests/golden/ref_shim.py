@@ -18,6 +18,8 @@ own (python-2, CUDA) execution:
   * `pred_boxes[i]` row -> `.tolist()` (0.3.1 element access gave python doubles)
   * `size_average=False/True` -> `reduction='sum'/'mean'`
   * `easydict` (absent) -> a 10-line attribute dict
+  * image.py: `resize(shape)` -> `resize(shape, Image.NEAREST)` and `point(f)` -> `point(int(f))`: the defaults of the
+    reference's Pillow (< 7.0: NEAREST resize; <= 8: C-int truncation of point() tables), which newer Pillow changed
   * `torch.sort(det_confs)` in utils.nms -> `stable=True` (tie order of equal float32 keys is unspecified in torch and
     version dependent; pinned to the visiting order)
 
@@ -98,6 +100,15 @@ _SUBS = {
         ("_,sortIds = torch.sort(det_confs)", "_,sortIds = torch.sort(det_confs, stable=True)"),
     ],
     "cfg": [],
+    "image": [
+        # Pillow < 7.0 (the reference's era) resized with NEAREST by default; >= 7.0 with BICUBIC
+        ("cropped.resize(shape)", "cropped.resize(shape, Image.NEAREST)"),
+        ("img = img.resize(shape)", "img = img.resize(shape, Image.NEAREST)"),
+        # Pillow <= 8 converted point() table entries with C (int) truncation; >= 9 rounds half-to-even
+        ("cs[1].point(lambda i: i * sat)", "cs[1].point(lambda i: int(i * sat))"),
+        ("cs[2].point(lambda i: i * val)", "cs[2].point(lambda i: int(i * val))"),
+        ("cs[0] = cs[0].point(change_hue)", "cs[0] = cs[0].point(lambda i: int(change_hue(i)))"),
+    ],
     "dynamic_conv": [("import pdb", "pdb = None")],
     "pooling": [],
 }

@@ -29,9 +29,27 @@ def timed(fn, iters=5):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def timed_classes(fn, iters=5):
+    """-> (wall ms, {kernel class: ms}) per call, from the library's per-kernel HIP events."""
+    fn()
+    torch.cuda.synchronize()
+    ops.kernel_profile(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters * 1e3
+    ops.kernel_profile(False)
+    kp = ops.kernel_profile_collect()
+    return wall, {k: v["ms"] / iters for k, v in kp.items() if v["launches"]}
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     dev = torch.device("cuda:0")
+    batch = int(os.environ.get("FSD_LB_BATCH", "64"))
+    global SHAPES
+    SHAPES = [(batch,) + s[1:] for s in SHAPES]
     if os.environ.get("FSD_WINO4") == "0":
         ops.WINOGRAD4 = False
     if os.environ.get("FSD_WINO4_MIN_CH"):
@@ -51,9 +69,14 @@ def main():
                 wp = ops.pack_weight(w)
                 ms = timed(lambda: ops.conv2d(x, wp, cout, k))
             line += "  fwd[%s] %7.3f ms %6.1f TF" % (tile or "d", ms, flops / ms / 1e9)
+            if tile:
+                _, cl = timed_classes(lambda: ops.conv3x3_wino(x, wp, cout, tile=tile))
+                line += " (gemm %.3f xform %.3f)" % (cl.get("gemm_fwd", 0), cl.get("wino_transform", 0))
         if what in ("wgrad", "all"):
             ms = timed(lambda: ops.conv2d_wgrad(dy, cout, x, cin, k))
             line += "  wgrad %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
+            _, cl = timed_classes(lambda: ops.conv2d_wgrad(dy, cout, x, cin, k))
+            line += " (gemm %.3f xform %.3f)" % (cl.get("gemm_wgrad", 0), cl.get("wino_transform", 0))
         print(line, flush=True)
 
 
