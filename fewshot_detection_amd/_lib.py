@@ -73,7 +73,7 @@ PROTOTYPES = {
     "fsd_add_inplace": (_i, [_p, _ll, _p, _ll, _ll, _i, _p]),
     "fsd_head_unfold_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
-    "fsd_augment_batch": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_augment_batch": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_profile_enable": (None, [_i]),
     "fsd_profile_num_classes": (_i, []),
     "fsd_profile_collect": (_i, [_p, _p, _p, _i]),

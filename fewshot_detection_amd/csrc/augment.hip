@@ -22,6 +22,7 @@ struct AugArgs {
   const int* xtab;           // [B][out_w] source column per output column, -1 = outside the image (black)
   const int* ytab;           // [B][out_h]
   const uint8_t* luts;       // [B][3][256] H, S, V tables, or null: no colour distortion
+  const int* distort;        // [B] 0 = skip the colour distortion for this image (its tables are ignored), or null = all on
   const int* mask_box;       // [B][4] x1, y1, x2, y2 of the support mask rectangle (NHWC4 channel 3), or null
   float* out;
   int out_h, out_w, layout;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     const uint8_t* px = a.src + a.img_off[bimg] + ((long long)sy * a.img_w[bimg] + sx) * 3;
     r = px[0]; g = px[1]; b = px[2];
   }
-  if (a.luts != nullptr) {
+  if (a.luts != nullptr && (a.distort == nullptr || a.distort[bimg] != 0)) {
     const uint8_t* l = a.luts + (long long)bimg * 768;
     int h, s, v;
     rgb2hsv(r, g, b, h, s, v);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
 }  // namespace
 
 extern "C" int fsd_augment_batch(const unsigned char* src, const long long* img_off, const int* img_w, const int* xtab,
-                                 const int* ytab, const unsigned char* luts, const int* mask_box, float* out, int batch,
+                                 const int* ytab, const unsigned char* luts, const int* distort, const int* mask_box, float* out, int batch,
                                  int out_h, int out_w, int layout, hipStream_t stream) {
   (void)hipGetLastError();
   if (!src || !img_off || !img_w || !xtab || !ytab || !out || batch < 1 || out_h < 1 || out_w < 1) return FSD_ERR_ARG;
@@ -110,7 +111,7 @@ extern "C" int fsd_augment_batch(const unsigned char* src, const long long* img_
   if (layout == 0 && mask_box) return FSD_ERR_UNSUPPORTED;        // the mask is channel 3 of the NHWC4 layout
   if (layout == 1 && (reinterpret_cast<uintptr_t>(out) & 15)) return FSD_ERR_ARG;
   AugArgs a;
-  a.src = src; a.img_off = img_off; a.img_w = img_w; a.xtab = xtab; a.ytab = ytab; a.luts = luts; a.mask_box = mask_box;
+  a.src = src; a.img_off = img_off; a.img_w = img_w; a.xtab = xtab; a.ytab = ytab; a.luts = luts; a.distort = distort; a.mask_box = mask_box;
   a.out = out; a.out_h = out_h; a.out_w = out_w; a.layout = layout;
   a.total = (long long)batch * out_h * out_w;
   const long long blocks = (a.total + 255) / 256;

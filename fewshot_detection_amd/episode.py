@@ -274,6 +274,9 @@ class DeviceAugmenter(object):
         xt_d = torch.from_numpy(np.stack(xt)).to(dev, non_blocking=True)
         yt_d = torch.from_numpy(np.stack(yt)).to(dev, non_blocking=True)
         lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True) if any_lut else None
+        on_d = None
+        if any_lut and any(p is None for p in params):      # plain-resize images inside a distorting batch
+            on_d = torch.tensor([0 if p is None else 1 for p in params], dtype=torch.int32).to(dev, non_blocking=True)
         mb_d = None
         if mask_boxes is not None:
             mb_d = torch.tensor([[int(v) for v in b] for b in mask_boxes], dtype=torch.int32).to(dev, non_blocking=True)
@@ -282,7 +285,8 @@ class DeviceAugmenter(object):
         else:
             out = torch.empty((B, 4, out_h, out_w), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         check(lib().fsd_augment_batch(src.data_ptr(), off_d.data_ptr(), w_d.data_ptr(), xt_d.data_ptr(), yt_d.data_ptr(),
-                                      0 if lut_d is None else lut_d.data_ptr(), 0 if mb_d is None else mb_d.data_ptr(),
+                                      0 if lut_d is None else lut_d.data_ptr(), 0 if on_d is None else on_d.data_ptr(),
+                                      0 if mb_d is None else mb_d.data_ptr(),
                                       out.data_ptr(), B, out_h, out_w, 0 if layout == "nchw" else 1,
                                       torch.cuda.current_stream().cuda_stream), "fsd_augment_batch")
         return out

@@ -305,11 +305,14 @@ int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, flo
  *        image (black); crop offset, Pillow's nearest-neighbour arithmetic and the flip are folded in by the host
  *        (episode.index_tables)
  *   luts [B][3][256] uint8 (nullable): the H, S, V tables of image.distort_image; null = no colour distortion
+ *   distort [B] int32 (nullable): 0 = image b skips the colour distortion (data_augmentation(flag=False) inside a
+ *        batch that otherwise distorts: the RGB->HSV->RGB round trip is not the identity); null = every image distorts
  *   mask_box [B][4] int32 x1, y1, x2, y2 (nullable, layout 1 only): support-mask rectangle (dataset.py:378-398)
  *   layout 0: out = (B, 3, out_h, out_w) float NCHW;  layout 1: out = (B, out_h, out_w, 4) float, channel 3 = mask / 0
  * Bit-exact with the reference run on Pillow with the 2018 defaults (tests/golden/augment.npz). */
 int fsd_augment_batch(const unsigned char* src, const long long* img_off, const int* img_w, const int* xtab,
-                      const int* ytab, const unsigned char* luts, const int* mask_box, float* out, int batch, int out_h,
+                      const int* ytab, const unsigned char* luts, const int* distort, const int* mask_box, float* out,
+                      int batch, int out_h,
                       int out_w, int layout, hipStream_t stream);
 
 /* Measurement aid (bench.py): while enabled, every launch of the kernel classes below is bracketed by HIP events on the
