@@ -73,6 +73,22 @@ PROTOTYPES = {
     "fsd_add_inplace": (_i, [_p, _ll, _p, _ll, _ll, _i, _p]),
     "fsd_head_unfold_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
+    "fsd_conv_row_tiles_h": (_i, [_ll]),
+    "fsd_conv2d_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_conv2d_wgrad_h_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "fsd_conv2d_wgrad_h": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "fsd_conv3x3_c4_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _p]),
+    "fsd_conv3x3_wgrad_c4_bnfused_h": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
+    "fsd_bn_act_pool_fwd_h": (_i, [_p, _ll, _p, _p, _f, _i, _p, _ll, _i, _i, _i, _i, _p]),
+    "fsd_transpose_batched_h": (_i, [_p, _i, _ll, _ll, _p, _i, _ll, _ll, _i, _i, _i, _p]),
+    "fsd_reorg_fwd_h": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
+    "fsd_global_maxpool_fwd_h": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_bn_act_pool_bwd_h": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _p, _p, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_bn_bwd_apply_h": (_i, [_p, _p, _ll, _p, _p, _p, _ll, _i, _p]),
+    "fsd_colsum_partials_h": (_i, [_p, _ll, _p, _ll, _i, _p]),
+    "fsd_reorg_bwd_h": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
+    "fsd_global_maxpool_bwd_h": (_i, [_p, _p, _p, _ll, _i, _i, _i, _i, _p]),
+    "fsd_add_inplace_h": (_i, [_p, _ll, _p, _ll, _ll, _i, _p]),
     "fsd_augment_batch": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_profile_enable": (None, [_i]),
     "fsd_profile_num_classes": (_i, []),

@@ -5,10 +5,16 @@
 #include <stdint.h>
 #include "fsdet.h"
 #include "profile.hpp"
+#include "ew_types.hpp"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using fsd_ew::bf16_t;
+using fsd_ew::f32x4;
+using fsd_ew::ld1;
+using fsd_ew::ld4;
+using fsd_ew::st1;
+using fsd_ew::st4;
 constexpr int kPixPerBlock = 256;     // pixels reduced by one block of the first pass
 constexpr int kSlots = 256;
 
@@ -17,17 +23,16 @@ inline unsigned blocks_for(long long n, int per) {
   return (unsigned)(b < 1 ? 1 : b);
 }
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-struct ActBwdArgs {
-  const float* dz;        // grad of the (pooled) block output, NHWC (B,OH,OW,C), stride dz_ld
-  const float* dz_full;   // optional grad of the un-pooled activation (a [route] tapped it)
-  const float* y;         // raw conv output (B,H,W,C), stride y_ld
+template <typename T>
+struct ActBwdArgsT {
+  const T* dz;            // grad of the (pooled) block output, NHWC (B,OH,OW,C), stride dz_ld
+  const T* dz_full;       // optional grad of the un-pooled activation (a [route] tapped it)
+  const T* y;             // raw conv output (B,H,W,C), stride y_ld
   const float* scale;     // BN affine (nullable = identity)
   const float* shift;
   const float* mean;      // BN batch statistics (nullable when no BN)
   const float* invstd;
-  float* dt;              // out: grad wrt the BN output / pre-activation, dense (pixels, C)
+  T* dt;                  // out: grad wrt the BN output / pre-activation, dense (pixels, C)
   float* partial;         // out: [blocks_x][C][2]  (sum dt, sum dt*xhat)
   long long dz_ld, dzf_ld, y_ld;
   int H, W, OH, OW, C, pool;
@@ -38,8 +43,8 @@ struct ActBwdArgs {
 
 // One block: GL channel groups (4 channels each) x 256/GL pixel lanes, looping over kPixPerBlock pixels.
 // GL follows the layer (8 for 32 channels ... 64 for >= 256) so that narrow layers keep every lane busy.
-template <int GL>
-__global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
+template <typename T, int GL>
+__global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgsT<T> p) {
   constexpr int NPL = 256 / GL;
   __shared__ float s_red[NPL][GL][8];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
         s1[k] += d[k];
         s2[k] += d[k] * ((yv[k] - mu[k]) * is[k]);
       }
-      *reinterpret_cast<f32x4*>(p.dt + pix * p.C + g * 4) = d;
+      st4<T>(p.dt + pix * p.C + g * 4, d);
     }
   }
 #pragma unroll
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgs p) {
 // pool == 1 (2x2 stride 2) specialisation: one thread per 2x2 CELL and 4 channels, so every y is
 // read once, the argmax is decided once and the (up to) four dt values are written together.
 // Cells on the odd border (no pooling window) only carry the dz_full / zero gradient.
-template <int GL>
-__global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
+template <typename T, int GL>
+__global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgsT<T> p) {
   constexpr int NPL = 256 / GL;
   __shared__ float s_red[NPL][GL][8];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgs p) {
           s1[k] += d[k];
           s2[k] += d[k] * ((yv[q][k] - mu[k]) * is[k]);
         }
-        *reinterpret_cast<f32x4*>(p.dt + pix * p.C + g * 4) = d;
+        st4<T>(p.dt + pix * p.C + g * 4, d);
       }
     }
   }
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   }
 }
 
-__global__ void bn_bwd_apply_kernel(float* __restrict__ dt, const float* __restrict__ y, long long y_ld,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(T* __restrict__ dt, const T* __restrict__ y, long long y_ld,
                                     const float* __restrict__ coef, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, int C, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,22 +306,24 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ dt, const float* __restr
   f32x4 d = ld4(dt + pix * C + g * 4);
 #pragma unroll
   for (int k = 0; k < 4; ++k) d[k] = c1[k] * (d[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
-  *reinterpret_cast<f32x4*>(dt + pix * C + g * 4) = d;
+  st4<T>(dt + pix * C + g * 4, d);
 }
 
 // column sums of a (rows, ld) matrix, any C: partial[blocks][C][2] with the second slot zero
-__global__ void colsum_kernel(const float* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows,
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows,
                               int ppb) {
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const long long r0 = (long long)blockIdx.x * ppb;
   float s = 0.f;
-  for (int i = 0; i < ppb && r0 + i < rows; ++i) s += m[(r0 + i) * ld + c];
+  for (int i = 0; i < ppb && r0 + i < rows; ++i) s += ld1<T>(m + (r0 + i) * ld + c);
   partial[((long long)blockIdx.x * C + c) * 2] = s;
   partial[((long long)blockIdx.x * C + c) * 2 + 1] = 0.f;
 }
 
-__global__ void reorg_bwd_kernel(const float* __restrict__ dout, long long dout_ld, float* __restrict__ dx, long long dx_ld,
+template <typename T>
+__global__ void reorg_bwd_kernel(const T* __restrict__ dout, long long dout_ld, T* __restrict__ dx, long long dx_ld,
                                  int H, int W, int C, int s, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -328,10 +336,11 @@ __global__ void reorg_bwd_kernel(const float* __restrict__ dout, long long dout_
   const int OH = H / s, OW = W / s;
   const int oi = iy / s, di = iy - oi * s, oj = ix / s, dj = ix - oj * s;
   const f32x4 v = ld4(dout + ((b * OH + oi) * (long long)OW + oj) * dout_ld + (di * s + dj) * C + g * 4);
-  *reinterpret_cast<f32x4*>(dx + ((b * H + iy) * (long long)W + ix) * dx_ld + g * 4) = v;
+  st4<T>(dx + ((b * H + iy) * (long long)W + ix) * dx_ld + g * 4, v);
 }
 
-__global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ argmax, float* __restrict__ dx,
+template <typename T>
+__global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ argmax, T* __restrict__ dx,
                                       long long dx_ld, int HW, int C, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, pixel, c)
   if (idx >= total) return;
@@ -339,16 +348,17 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int*
   const long long t = idx / C;
   const int pix = (int)(t % HW);
   const long long b = t / HW;
-  dx[(b * HW + pix) * dx_ld + c] = argmax[b * C + c] == pix ? dout[b * C + c] : 0.f;
+  st1<T>(dx + (b * HW + pix) * dx_ld + c, argmax[b * C + c] == pix ? dout[b * C + c] : 0.f);
 }
 
-__global__ void add_inplace_kernel(float* __restrict__ dst, long long dst_ld, const float* __restrict__ src, long long src_ld,
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ dst, long long dst_ld, const T* __restrict__ src, long long src_ld,
                                    int C, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % C);
   const long long r = idx / C;
-  dst[r * dst_ld + c] += src[r * src_ld + c];
+  st1<T>(dst + r * dst_ld + c, ld1<T>(dst + r * dst_ld + c) + ld1<T>(src + r * src_ld + c));
 }
 
 // d head_w[o,c] = sum_n dWeff[n*O+o, c] * dyn[n,c];  d dyn[n,c] = sum_o dWeff[n*O+o, c] * head_w[o,c]
@@ -407,17 +417,19 @@ extern "C" int fsd_bn_act_pool_bwd_rows(int batch, int height, int width, int po
 
 extern "C" size_t fsd_reduce_workspace_bytes(int channels) { return (size_t)kSlots * channels * 2 * sizeof(double); }
 
-extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
-                                   const float* y, long long y_ld, const float* scale, const float* shift,
-                                   const float* mean, const float* invstd, float slope, int pool, float* dt,
-                                   float* partial, int batch, int height, int width, int channels,
-                                   hipStream_t stream) {
+namespace {
+
+template <typename T>
+int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long long dz_full_ld, const T* y, long long y_ld,
+                         const float* scale, const float* shift, const float* mean, const float* invstd, float slope,
+                         int pool, T* dt, float* partial, int batch, int height, int width, int channels,
+                         hipStream_t stream) {
   (void)hipGetLastError();
   if (!dz || !y || !dt || !partial || batch < 1 || channels < 4 || (channels & 3) || (dz_ld & 3) || (y_ld & 3))
     return FSD_ERR_ARG;
   if (dz_full && (dz_full_ld & 3)) return FSD_ERR_ARG;
   if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
-  ActBwdArgs a;
+  ActBwdArgsT<T> a;
   a.dz = dz; a.dz_full = dz_full; a.y = y; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
   a.dt = dt; a.partial = partial; a.dz_ld = dz_ld; a.dzf_ld = dz_full_ld; a.y_ld = y_ld;
   a.H = height; a.W = width; a.OH = pool == 1 ? height / 2 : height; a.OW = pool == 1 ? width / 2 : width;
@@ -425,25 +437,46 @@ extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float
   const int cg = channels / 4;
   const int gl = cg <= 8 ? 8 : cg <= 16 ? 16 : cg <= 32 ? 32 : 64;    // channel-group lanes per block
   // algorithmic bytes: read dz (+ dz_full) and y, write dt
-  fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * ((double)batch * a.OH * a.OW + (dz_full ? 3.0 : 2.0) * a.pixels), stream);
+  fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * ((double)batch * a.OH * a.OW + (dz_full ? 3.0 : 2.0) * a.pixels), stream);
   if (pool == 1) {
     // window-major: a block covers cells_per_block cells = one partial row (fsd_bn_act_pool_bwd_rows)
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
     a.ppb = 4 * cells_per_block(cells);
     const dim3 grid(blocks_for(cells, a.ppb / 4), (cg + gl - 1) / gl);
-    if (gl == 8) hipLaunchKernelGGL(act_bwd_pool2_kernel<8>, grid, dim3(256), 0, stream, a);
-    else if (gl == 16) hipLaunchKernelGGL(act_bwd_pool2_kernel<16>, grid, dim3(256), 0, stream, a);
-    else if (gl == 32) hipLaunchKernelGGL(act_bwd_pool2_kernel<32>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(act_bwd_pool2_kernel<64>, grid, dim3(256), 0, stream, a);
+    if (gl == 8) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 8>), grid, dim3(256), 0, stream, a);
+    else if (gl == 16) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 16>), grid, dim3(256), 0, stream, a);
+    else if (gl == 32) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 32>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 64>), grid, dim3(256), 0, stream, a);
     return (int)hipGetLastError();
   }
   a.ppb = pix_per_block(a.pixels);
   const dim3 grid(blocks_for(a.pixels, a.ppb), (cg + gl - 1) / gl);
-  if (gl == 8) hipLaunchKernelGGL(act_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
-  else if (gl == 16) hipLaunchKernelGGL(act_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
-  else if (gl == 32) hipLaunchKernelGGL(act_bwd_kernel<32>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(act_bwd_kernel<64>, grid, dim3(256), 0, stream, a);
+  if (gl == 8) hipLaunchKernelGGL((act_bwd_kernel<T, 8>), grid, dim3(256), 0, stream, a);
+  else if (gl == 16) hipLaunchKernelGGL((act_bwd_kernel<T, 16>), grid, dim3(256), 0, stream, a);
+  else if (gl == 32) hipLaunchKernelGGL((act_bwd_kernel<T, 32>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((act_bwd_kernel<T, 64>), grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_bn_act_pool_bwd(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
+                                   const float* y, long long y_ld, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, float slope, int pool, float* dt,
+                                   float* partial, int batch, int height, int width, int channels,
+                                   hipStream_t stream) {
+  return bn_act_pool_bwd_impl<float>(dz, dz_ld, dz_full, dz_full_ld, y, y_ld, scale, shift, mean, invstd, slope, pool, dt,
+                                     partial, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_bn_act_pool_bwd_h(const void* dz, long long dz_ld, const void* dz_full, long long dz_full_ld,
+                                     const void* y, long long y_ld, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, float slope, int pool, void* dt,
+                                     float* partial, int batch, int height, int width, int channels,
+                                     hipStream_t stream) {
+  return bn_act_pool_bwd_impl<bf16_t>(static_cast<const bf16_t*>(dz), dz_ld, static_cast<const bf16_t*>(dz_full), dz_full_ld,
+                                      static_cast<const bf16_t*>(y), y_ld, scale, shift, mean, invstd, slope, pool,
+                                      static_cast<bf16_t*>(dt), partial, batch, height, width, channels, stream);
 }
 
 extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long count, int channels, const float* scale,
@@ -459,56 +492,112 @@ extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long cou
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const float* coef, const float* mean,
-                                const float* invstd, long long pixels, int channels, hipStream_t stream) {
+namespace {
+
+template <typename T>
+int bn_bwd_apply_impl(T* dt, const T* y, long long y_ld, const float* coef, const float* mean, const float* invstd,
+                      long long pixels, int channels, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dt || !y || !coef || !mean || !invstd || (channels & 3) || (y_ld & 3)) return FSD_ERR_ARG;
   const long long total = pixels * (channels / 4);
-  fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * 3.0 * pixels, stream);      // read dt, y; write dy
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
+  fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * 3.0 * pixels, stream);      // read dt, y; write dy
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
                      invstd, channels, total);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
-                                   hipStream_t stream) {
+template <typename T>
+int colsum_impl(const T* m, long long ld, float* partial, long long rows, int channels, hipStream_t stream) {
   (void)hipGetLastError();
   if (!m || !partial || rows < 1 || channels < 1) return FSD_ERR_ARG;
   const int ppb = pix_per_block(rows);      // partial rows = fsd_act_bwd_rows(rows)
-  hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(rows, ppb), (channels + 255) / 256), dim3(256), 0, stream, m,
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(blocks_for(rows, ppb), (channels + 255) / 256), dim3(256), 0, stream, m,
                      ld, partial, channels, rows, ppb);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_reorg_bwd(const float* dout, long long dout_ld, float* dx, long long dx_ld, int batch, int height,
-                             int width, int channels, int stride, hipStream_t stream) {
+template <typename T>
+int reorg_bwd_impl(const T* dout, long long dout_ld, T* dx, long long dx_ld, int batch, int height, int width, int channels,
+                   int stride, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dout || !dx || stride < 1 || height % stride || width % stride || (channels & 3) || (dout_ld & 3) || (dx_ld & 3))
     return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * (channels / 4);
-  hipLaunchKernelGGL(reorg_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, dout_ld, dx, dx_ld,
+  hipLaunchKernelGGL(reorg_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, dout_ld, dx, dx_ld,
                      height, width, channels, stride, total);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_global_maxpool_bwd(const float* dout, const int* argmax, float* dx, long long dx_ld, int batch,
-                                      int height, int width, int channels, hipStream_t stream) {
+template <typename T>
+int global_maxpool_bwd_impl(const float* dout, const int* argmax, T* dx, long long dx_ld, int batch, int height, int width,
+                            int channels, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dout || !argmax || !dx) return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * channels;
-  hipLaunchKernelGGL(global_max_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, argmax, dx, dx_ld,
+  hipLaunchKernelGGL(global_max_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, argmax, dx, dx_ld,
                      height * width, channels, total);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_add_inplace(float* dst, long long dst_ld, const float* src, long long src_ld, long long rows,
-                               int channels, hipStream_t stream) {
+template <typename T>
+int add_inplace_impl(T* dst, long long dst_ld, const T* src, long long src_ld, long long rows, int channels,
+                     hipStream_t stream) {
   (void)hipGetLastError();
   if (!dst || !src || rows < 1 || channels < 1) return FSD_ERR_ARG;
   const long long total = rows * channels;
-  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dst, dst_ld, src, src_ld,
+  hipLaunchKernelGGL(add_inplace_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dst, dst_ld, src, src_ld,
                      channels, total);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const float* coef, const float* mean,
+                                const float* invstd, long long pixels, int channels, hipStream_t stream) {
+  return bn_bwd_apply_impl<float>(dt, y, y_ld, coef, mean, invstd, pixels, channels, stream);
+}
+extern "C" int fsd_bn_bwd_apply_h(void* dt, const void* y, long long y_ld, const float* coef, const float* mean,
+                                  const float* invstd, long long pixels, int channels, hipStream_t stream) {
+  return bn_bwd_apply_impl<bf16_t>(static_cast<bf16_t*>(dt), static_cast<const bf16_t*>(y), y_ld, coef, mean, invstd, pixels,
+                                   channels, stream);
+}
+
+extern "C" int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
+                                   hipStream_t stream) {
+  return colsum_impl<float>(m, ld, partial, rows, channels, stream);
+}
+extern "C" int fsd_colsum_partials_h(const void* m, long long ld, float* partial, long long rows, int channels,
+                                     hipStream_t stream) {
+  return colsum_impl<bf16_t>(static_cast<const bf16_t*>(m), ld, partial, rows, channels, stream);
+}
+
+extern "C" int fsd_reorg_bwd(const float* dout, long long dout_ld, float* dx, long long dx_ld, int batch, int height,
+                             int width, int channels, int stride, hipStream_t stream) {
+  return reorg_bwd_impl<float>(dout, dout_ld, dx, dx_ld, batch, height, width, channels, stride, stream);
+}
+extern "C" int fsd_reorg_bwd_h(const void* dout, long long dout_ld, void* dx, long long dx_ld, int batch, int height,
+                               int width, int channels, int stride, hipStream_t stream) {
+  return reorg_bwd_impl<bf16_t>(static_cast<const bf16_t*>(dout), dout_ld, static_cast<bf16_t*>(dx), dx_ld, batch, height,
+                                width, channels, stride, stream);
+}
+
+extern "C" int fsd_global_maxpool_bwd(const float* dout, const int* argmax, float* dx, long long dx_ld, int batch,
+                                      int height, int width, int channels, hipStream_t stream) {
+  return global_maxpool_bwd_impl<float>(dout, argmax, dx, dx_ld, batch, height, width, channels, stream);
+}
+extern "C" int fsd_global_maxpool_bwd_h(const float* dout, const int* argmax, void* dx, long long dx_ld, int batch,
+                                        int height, int width, int channels, hipStream_t stream) {
+  return global_maxpool_bwd_impl<bf16_t>(dout, argmax, static_cast<bf16_t*>(dx), dx_ld, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_add_inplace(float* dst, long long dst_ld, const float* src, long long src_ld, long long rows,
+                               int channels, hipStream_t stream) {
+  return add_inplace_impl<float>(dst, dst_ld, src, src_ld, rows, channels, stream);
+}
+extern "C" int fsd_add_inplace_h(void* dst, long long dst_ld, const void* src, long long src_ld, long long rows,
+                                 int channels, hipStream_t stream) {
+  return add_inplace_impl<bf16_t>(static_cast<bf16_t*>(dst), dst_ld, static_cast<const bf16_t*>(src), src_ld, rows, channels,
+                                  stream);
 }
 
 extern "C" int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dyn, float* d_head_w,

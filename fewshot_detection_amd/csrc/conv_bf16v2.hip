@@ -1,0 +1,580 @@
+// bf16 mode of the convolution path (BASELINE configs[2] / [4]: "bf16 MFMA path"): activations, their gradients and
+// the packed weights live in HBM as bfloat16, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense
+// chip peak, 16x the fp32 matrix rate), BatchNorm statistics come from the fp32 accumulators.
+//
+// Forward / data gradient (conv_bf16_dma_kernel): implicit GEMM, M = B*H*W pixels, N = Cout, K = taps*Cin.
+//   * Both operands are K-contiguous in HBM (NHWC activations, [Cout][tap][Cin] weights), so a k-chunk of a tile row is
+//     one 128-byte (BK = 64) or 64-byte (BK = 32, the Cin = 32 layers) run: staged with global_load_lds, 16 B per lane,
+//     no staging registers, no ds_write.  The DMA writes LDS linearly (wave base + lane*16 B); bank conflicts are
+//     avoided by permuting which 16-byte k-group of its row each lane FETCHES (same cache line) and undoing the
+//     permutation in the fragment read: group g of row r sits at g ^ ((r >> 1) & 7) (128-B rows) resp.
+//     g ^ ((r >> 2) & 3) (64-B rows), which makes every 16-lane service group of the ds_read_b128 fragment reads hit 16
+//     distinct 16-byte slots.  Image-border taps and rows past M fetch a zero page.
+//   * The weight rows of a 64-channel block are staged EVEN channels first, then ODD (a free permutation of the DMA
+//     source), so the two accumulators of a wave hold channel 2l and 2l+1 in lane l: one v_cvt_pk_bf16_f32 packs them
+//     and the epilogue stores 4 bytes per lane, 128 contiguous bytes per pixel row, straight from registers.
+//   * Two LDS stages; the DMA of chunk k+1 is in flight under the MFMAs of chunk k.
+//
+// Weight gradient (wgrad_bf16_tr_kernel): dW[co][tap][ci] = sum_pix dy[pix][co] * x[pix + tap][ci], M = Cout, N = Cin
+// per tap, K = pixels.  In HBM both operands are [k = pixel][m = channel] -- transposed with respect to what an MFMA
+// operand register wants (8 consecutive k per lane) -- so the tiles are staged as they lie (DMA, 16 channels x 32
+// pixels per instruction) and the fragments are read with ds_read_b64_tr_b16, the LDS transpose read.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "fsdet.h"
+#include "conv_common.hpp"
+#include "profile.hpp"
+
+namespace {
+
+using namespace fsd_conv;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+__device__ __attribute__((aligned(16))) u16 g_zero_page_h[64];     // 128 zero bytes: padding source of the DMA path
+
+struct ConvHArgs {
+  const u16* x;        // activations, bf16 NHWC, pixel stride x_ld elements
+  const u16* w;        // packed weights, bf16 [rows padded to 128][Kpad]
+  const float* bias;   // [Cout] or null
+  void* y;             // bf16 NHWC (pixel stride y_ld elements) or float NCHW
+  float* bn_partial;   // [m_tiles][Cout][2] or null
+  long long x_ld, y_ld;
+  int H, W, HW, M, Cout, ks, pad;
+  int nk;              // k-chunks
+  int cpt;             // chunks per tap (Cin / BK)
+  int Kpad;            // packed weight row stride (elements)
+  int m_tiles, n_tiles;
+};
+
+
+// global -> LDS DMA of 16 bytes per lane (LDS destination = wave-uniform base + lane * 16).  The address spaces are
+// spelled out: with generic pointers the builtin's implicit conversions fail SILENTLY in some template contexts on the
+// host pass (no diagnostic, the kernel's host stub is simply not emitted -> undefined symbol at load time).
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(u16, a) | ((unsigned)__builtin_bit_cast(u16, b) << 16);
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT>
+__global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BK == 64 || BK == 32, "k-chunk of 64 or 32 bf16");
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  static_assert(TN == 2, "a wave owns one even/odd pair of 32-channel accumulators");
+  constexpr int LPR = BK / 8;                 // lanes (16-byte groups) per tile row
+  constexpr int RPP = 256 / LPR;              // tile rows staged per pass of the workgroup
+  constexpr int RPW = 64 / LPR;               // ... per wave instruction
+  constexpr int A_PER_T = BM / RPP, B_PER_T = BN / RPP;
+  constexpr int STAGE = (BM + BN) * BK;       // elements per LDS stage
+  constexpr int HSH = BK == 64 ? 1 : 2, HMASK = LPR - 1;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
+
+  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int r0 = tid / LPR, pg = tid % LPR;
+  const int g_src = pg ^ ((r0 >> HSH) & HMASK);        // logical k-group this lane fetches for its physical slot
+
+  // im2col bookkeeping of this thread's A rows
+  int a_y[A_PER_T], a_x[A_PER_T];
+  unsigned a_pix[A_PER_T];
+#pragma unroll
+  for (int j = 0; j < A_PER_T; ++j) {
+    const int pix = m0 + r0 + RPP * j;
+    const int b = pix / p.HW;
+    const int rem = pix - b * p.HW;
+    const int yy = rem / p.W;
+    a_y[j] = pix < p.M ? yy : -(1 << 20);
+    a_x[j] = rem - yy * p.W;
+    a_pix[j] = (unsigned)pix;
+  }
+  // B rows: LDS row r of a 64-row block holds channel 2*(r % 32) + (r / 32) % 2 of that block
+  const u16* wrow[B_PER_T];
+#pragma unroll
+  for (int j = 0; j < B_PER_T; ++j) {
+    const int r = r0 + RPP * j;
+    const int ch = (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1);
+    wrow[j] = p.w + (long long)(n0 + ch) * p.Kpad + g_src * 8;
+  }
+  const unsigned x_ld = (unsigned)p.x_ld;
+  unsigned a_off[A_PER_T];
+  unsigned tap_mask = 0;
+  int f_tap = 0, f_cc = 0;
+  auto retap = [&]() {
+    const int ky = f_tap / p.ks, kx = f_tap - ky * p.ks;
+    const int dy = ky - p.pad, dx = kx - p.pad;
+    const int shift = dy * p.W + dx;
+    tap_mask = 0;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const bool ok = (unsigned)(a_y[j] + dy) < (unsigned)p.H && (unsigned)(a_x[j] + dx) < (unsigned)p.W;
+      a_off[j] = ok ? (a_pix[j] + (unsigned)shift) * x_ld + (unsigned)(g_src * 8) : 0u;
+      tap_mask |= ok ? (1u << j) : 0u;
+    }
+  };
+  retap();
+
+  auto gload_lds = [&](int kc, u16* st) {
+    const unsigned coff = (unsigned)f_cc * BK;
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      const u16* src = (tap_mask >> j) & 1u ? p.x + (a_off[j] + coff) : g_zero_page_h + pg * 8;
+      dma16(src, st + (j * RPP + wave * RPW) * BK);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j)
+      dma16(wrow[j] + kc * BK, st + (BM + j * RPP + wave * RPW) * BK);
+    if (++f_cc == p.cpt) {
+      f_cc = 0;
+      ++f_tap;
+      retap();
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int hl = ((lane & 31) >> HSH) & HMASK;
+  auto compute = [&](const u16* st) {
+    const u16* sa = st + (wm * TM * 32 + (lane & 31)) * BK;
+    const u16* sb = st + (BM + wn * TN * 32 + (lane & 31)) * BK;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int ko = (((2 * s + (lane >> 5)) ^ hl) & HMASK) * 8;
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * BK + ko);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * BK + ko);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = NCHW_F32_OUT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  gload_lds(0, smem_h);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kc = 0; kc < p.nk; ++kc) {
+    if (kc + 1 < p.nk) gload_lds(kc + 1, smem_h + (cur ^ 1) * STAGE);     // that buffer was last read before the previous barrier
+    compute(smem_h + cur * STAGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ----
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+  if constexpr (!NCHW_F32_OUT) {
+    // lane l holds channels 2l (accumulator 0) and 2l+1 (accumulator 1) of its wave's 64-channel block
+    const int n = n0 + wn * 64 + 2 * c_lane;
+    const bool n_ok = n < p.Cout;                                   // Cout is even (launcher)
+    float bv0 = 0.f, bv1 = 0.f;
+    if (p.bias != nullptr && n_ok) { bv0 = p.bias[n]; bv1 = p.bias[n + 1]; }
+    u16* yb = static_cast<u16*>(p.y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        if (n_ok && m < p.M)
+          *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(acc[i][0][r] + bv0, acc[i][1][r] + bv1);
+      }
+    if (p.bn_partial != nullptr) {
+      // per-tile column sums of the fp32 accumulators (rows past M are exact zeros: zero-page operands)
+      float* s_stat = reinterpret_cast<float*>(smem_h);            // [WAVES_M][BN][2]
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32) {
+          const int col = wn * 64 + 2 * c_lane + j;
+          s_stat[(wm * BN + col) * 2 + 0] = s;
+          s_stat[(wm * BN + col) * 2 + 1] = q;
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          s += s_stat[(w * BN + tid) * 2 + 0];
+          q += s_stat[(w * BN + tid) * 2 + 1];
+        }
+        const int nn = n0 + tid;
+        if (nn < p.Cout) {
+          float* dst = p.bn_partial + ((long long)mt * p.Cout + nn) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
+      }
+    }
+  } else {
+    // operands were swapped: accumulator rows = channels (2*rho + j of the wave's block), columns = pixels
+    float* yf = static_cast<float*>(p.y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + c_lane;
+      const int b = m / p.HW;
+      const int hw = m - b * p.HW;
+      const bool m_ok = m < p.M;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * 64 + 2 * ((r & 3) + 8 * (r >> 2) + r_lane) + j;
+          if (m_ok && n < p.Cout) {
+            const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+            yf[((long long)b * p.Cout + n) * p.HW + hw] = acc[i][j][r] + bv;
+          }
+        }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(u16);
+  const dim3 grid(a.m_tiles * a.n_tiles), block(256);
+  fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.nk * BK), stream);
+  if (nchw) {
+    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+  } else {
+    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" int fsd_conv_row_tiles_h(long long pixels) { return (int)((pixels + 127) / 128); }
+
+extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
+                                long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                                int ksize, int out_nchw_f32, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x_bf16 || !w_packed_bf16 || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
+  if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
+  if (cin % 32 || (x_ld & 7) || x_ld < cin) return FSD_ERR_UNSUPPORTED;      // 16-byte DMA pieces of 8 channels
+  if (!out_nchw_f32 && ((cout & 1) || (y_ld & 1) || y_ld < cout)) return FSD_ERR_UNSUPPORTED;
+  if (out_nchw_f32 && bn_partial) return FSD_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x_bf16) & 15) || (reinterpret_cast<uintptr_t>(w_packed_bf16) & 15)) return FSD_ERR_ARG;
+  if (!out_nchw_f32 && (reinterpret_cast<uintptr_t>(y) & 3)) return FSD_ERR_ARG;
+  const long long pixels = (long long)batch * height * width;
+  if (pixels > 0x7fffffffLL - 512 || (pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
+  ConvHArgs a;
+  a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;
+  a.bn_partial = bn_partial; a.x_ld = x_ld; a.y_ld = y_ld;
+  a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
+  a.Cout = cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
+  a.Kpad = round_up(ksize * ksize * cin, 64);                    // row stride of fsd_pack_conv_weight_bf16
+  const int bk = cin % 64 == 0 ? 64 : 32;
+  a.nk = ksize * ksize * cin / bk;
+  a.cpt = cin / bk;
+  a.m_tiles = (int)((pixels + 127) / 128);
+  const bool nchw = out_nchw_f32 != 0;
+  if (cout <= 64 && !nchw) {
+    a.n_tiles = 1;
+    return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);
+  }
+  a.n_tiles = (cout + 127) / 128;
+  return bk == 64 ? launch_conv<128, 128, 64, 2, 2>(a, nchw, stream) : launch_conv<128, 128, 32, 2, 2>(a, nchw, stream);
+}
+
+// ================= weight gradient: K = pixels, fragments through the LDS transpose read =====================
+namespace {
+
+struct WgradHArgs {
+  const u16* dy;       // (pixels, dy_ld) bf16, columns [0, Cout)
+  const u16* x;        // (pixels, x_ld) bf16, columns [0, Cin)
+  float* ws;           // [splits][Cout][taps * Cin]
+  long long dy_ld, x_ld;
+  int H, W, M, Cout, Cin, ks, pad;
+  int m_tiles, n_tiles, taps;
+  int pix_per_split;   // multiple of 32
+};
+
+// Stage a [32 pixels][CH channels] bf16 tile as it lies in HBM.  CH*2-byte rows, written lane-linear by the DMA; the
+// 16-byte piece a lane FETCHES is permuted inside its row (XOR below) so that the transpose reads that follow are
+// bank-conflict free: a 32-lane half reads 4 consecutive pixel rows x 2 sixteen-channel blocks = 8 pieces of 32 B, which
+// must land in 8 different 32-byte bank ranges.
+template <int CH>
+struct TileGeom {
+  static constexpr int LPR = CH / 8;            // lanes per pixel row
+  static constexpr int RPI = 64 / LPR;          // pixel rows per wave instruction
+  static constexpr int PASSES = 32 / (4 * RPI) > 0 ? 32 / (4 * RPI) : 1;
+  static constexpr int ROWS_PER_PASS = 4 * RPI; // 16 (CH = 128), 32 (CH = 64), 64 (CH = 32: only the first 32 used)
+  __device__ static __forceinline__ int swz(int row) {      // XOR mask on the 16-byte piece index of a row
+    return CH == 128 ? ((row & 3) << 2) : CH == 64 ? ((row & 2) << 1) : 0;
+  }
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile of at least 32 x 32");
+  typedef TileGeom<BM> GA;
+  typedef TileGeom<BN> GB;
+  constexpr int STAGE = 32 * (BM + BN);           // elements per LDS stage
+  extern __shared__ __attribute__((aligned(16))) u16 smem_w[];
+
+  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tap = L % p.taps;
+  const int t2 = L / p.taps;
+  const int nt = t2 % p.n_tiles, mt = t2 / p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int ky = tap / p.ks, kx = tap - ky * p.ks;
+  const int dyo = ky - p.pad, dxo = kx - p.pad;
+  const int shift = dyo * p.W + dxo;
+  const long long pix0 = (long long)blockIdx.y * p.pix_per_split;
+  long long pix_end = pix0 + p.pix_per_split;
+  if (pix_end > p.M) pix_end = p.M;
+  const int nk = (int)((pix_end - pix0 + 31) / 32);
+
+  // this lane's piece of an A row: channels m0 + a_piece*8 .. +7 (logical), rows a_row + ROWS_PER_PASS * pass
+  const int a_row = wave * GA::RPI + lane / GA::LPR, a_pp = lane % GA::LPR;
+  const int b_row = wave * GB::RPI + lane / GB::LPR, b_pp = lane % GB::LPR;
+  // image coordinates of the B rows of this thread (they advance by 32 pixels per chunk)
+  int b_y[GB::PASSES], b_x[GB::PASSES];
+  const float inv_w = 1.0f / (float)p.W;
+#pragma unroll
+  for (int j = 0; j < GB::PASSES; ++j) {
+    const long long pp = pix0 + b_row + GB::ROWS_PER_PASS * j;
+    const long long q = pp / p.W;
+    b_x[j] = (int)(pp - q * p.W);
+    b_y[j] = (int)(q % p.H);
+  }
+
+  auto stage = [&](int kc, u16* st) {
+    const long long base = pix0 + (long long)kc * 32;
+#pragma unroll
+    for (int j = 0; j < GA::PASSES; ++j) {
+      const int row = a_row + GA::ROWS_PER_PASS * j;
+      if (GA::ROWS_PER_PASS * j + wave * GA::RPI < 32) {            // CH = 32: 64 rows per pass, only 32 exist
+        const int piece = a_pp ^ GA::swz(row);
+        const long long pix = base + row;
+        const bool ok = row < 32 && pix < pix_end && (m0 + piece * 8) < p.Cout;
+        const u16* src = ok ? p.dy + pix * p.dy_ld + m0 + piece * 8 : g_zero_page_h;
+        dma16(src, st + (GA::ROWS_PER_PASS * j + wave * GA::RPI) * BM);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GB::PASSES; ++j) {
+      const int row = b_row + GB::ROWS_PER_PASS * j;
+      if (GB::ROWS_PER_PASS * j + wave * GB::RPI < 32) {
+        const int piece = b_pp ^ GB::swz(row);
+        const long long pix = base + row;
+        const bool ok = row < 32 && pix < pix_end && (n0 + piece * 8) < p.Cin &&
+                        (unsigned)(b_y[j] + dyo) < (unsigned)p.H && (unsigned)(b_x[j] + dxo) < (unsigned)p.W;
+        const u16* src = ok ? p.x + (pix + shift) * p.x_ld + n0 + piece * 8 : g_zero_page_h;
+        dma16(src, st + 32 * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
+      }
+      // advance this row's image coordinates by one chunk (32 pixels); (x + 0.5) / W is never within 1/(2W) of an integer
+      int xx = b_x[j] + 32;
+      const int q = (int)(((float)xx + 0.5f) * inv_w);
+      xx -= q * p.W;
+      int yy = b_y[j] + q;
+      if (yy >= p.H) yy -= p.H;
+      if (yy >= p.H) yy -= p.H;
+      if (yy >= p.H) yy -= p.H;
+      b_x[j] = xx;
+      b_y[j] = yy;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read geometry: 16-lane group G = lane >> 4 reads pixel rows kb + (L >> 2), channels cb + 4 * (L & 3)
+  const int G = lane >> 4, Lq = lane & 15;
+  auto frag = [&](const u16* tile, int CH, int ch0, int krow, int swzmask) -> bf16x8 {
+    const int row = krow + (Lq >> 2);
+    const int ch = ch0 + 16 * (G & 1) + 4 * (Lq & 3);
+    const int piece = (ch >> 3) ^ swzmask;
+    const u16* a = tile + row * CH + piece * 8 + (ch & 7);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 4 * CH));
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = __builtin_bit_cast(__bf16, lo[e]);
+      v[4 + e] = __builtin_bit_cast(__bf16, hi[e]);
+    }
+    return v;
+  };
+  auto compute = [&](const u16* st) {
+    const u16* sa = st;
+    const u16* sb = st + 32 * BM;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int krow = s * 16 + (G >> 1) * 8;
+      const int row_lo = krow + (Lq >> 2);                        // the +4 rows of the second read share (row & 3)
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = frag(sa, BM, (wm * TM + i) * 32, krow, GA::swz(row_lo));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = frag(sb, BN, (wn * TN + j) * 32, krow, GB::swz(row_lo));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    stage(0, smem_w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk) stage(kc + 1, smem_w + (cur ^ 1) * STAGE);
+      compute(smem_w + cur * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  const int ncols = p.taps * p.Cin;
+  float* out = p.ws + (long long)blockIdx.y * p.Cout * ncols;
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + c_lane;
+    if (n >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        if (m < p.Cout) out[(long long)m * ncols + tap * p.Cin + n] = acc[i][j][r];
+      }
+  }
+}
+
+// ws[split][cout][tap * cin + ci] -> dW[cout][cin][taps] (OIHW), fixed summation order
+__global__ __launch_bounds__(256) void wgrad_h_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                             int cout, int cin, int taps) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over (co, tap, ci): coalesced reads
+  const long long total = (long long)cout * taps * cin;
+  if (idx >= total) return;
+  const int ci = (int)(idx % cin);
+  const long long t = idx / cin;
+  const int tap = (int)(t % taps);
+  const int co = (int)(t / taps);
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + idx];
+  dw[((long long)co * cin + ci) * taps + tap] = s;
+}
+
+inline int wgrad_h_splits(long long pixels, int tiles) {
+  int s = (2048 + tiles - 1) / tiles;                 // ~8 resident workgroups per CU
+  const long long max_s = (pixels + 511) / 512;       // at least 16 chunks per split
+  if (s > max_s) s = (int)max_s;
+  return s < 1 ? 1 : s > 1024 ? 1024 : s;
+}
+
+inline void wgrad_h_tiles(int cout, int cin, int* bm, int* bn) {
+  *bm = cout <= 64 ? 64 : 128;
+  *bn = cin <= 32 ? 32 : cin <= 64 ? 64 : 128;
+  if (*bn == 32) *bm = 128;                            // the 32-wide variant runs 4 x 1 waves of 32 rows
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)32 * (BM + BN) * sizeof(u16);
+  fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
+  hipLaunchKernelGGL((wgrad_bf16_tr_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles * a.taps, splits), dim3(256), lds,
+                     stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
+  int bm, bn;
+  wgrad_h_tiles(cout, cin, &bm, &bn);
+  const int tiles = ((cout + bm - 1) / bm) * ((cin + bn - 1) / bn) * ksize * ksize;
+  const int splits = wgrad_h_splits((long long)batch * height * width, tiles);
+  return (size_t)splits * cout * ksize * ksize * cin * sizeof(float);
+}
+
+extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const void* x_bf16, long long x_ld, float* dw_oihw,
+                                  void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                  int cout, int ksize, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dy_bf16 || !x_bf16 || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 || cin < 1 || cout < 1)
+    return FSD_ERR_ARG;
+  if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
+  if ((cin & 7) || (cout & 7) || (dy_ld & 7) || (x_ld & 7) || dy_ld < cout || x_ld < cin) return FSD_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dy_bf16) & 15) || (reinterpret_cast<uintptr_t>(x_bf16) & 15)) return FSD_ERR_ARG;
+  const long long pixels = (long long)batch * height * width;
+  if (pixels > 0x7fffffffLL - 4096) return FSD_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsd_conv2d_wgrad_h_workspace_bytes(batch, height, width, cin, cout, ksize)) return FSD_ERR_WORKSPACE;
+  WgradHArgs a;
+  a.dy = static_cast<const u16*>(dy_bf16); a.x = static_cast<const u16*>(x_bf16); a.ws = static_cast<float*>(workspace);
+  a.dy_ld = dy_ld; a.x_ld = x_ld; a.H = height; a.W = width; a.M = (int)pixels; a.Cout = cout; a.Cin = cin;
+  a.ks = ksize; a.pad = (ksize - 1) / 2; a.taps = ksize * ksize;
+  int bm, bn;
+  wgrad_h_tiles(cout, cin, &bm, &bn);
+  a.m_tiles = (cout + bm - 1) / bm;
+  a.n_tiles = (cin + bn - 1) / bn;
+  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles * a.taps);
+  a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), 32);
+  int rc;
+  if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);
+  else if (bm == 128 && bn == 128) rc = launch_wgrad_h<128, 128, 2, 2>(a, splits, stream);
+  else if (bm == 128 && bn == 64) rc = launch_wgrad_h<128, 64, 2, 2>(a, splits, stream);
+  else if (bm == 64 && bn == 128) rc = launch_wgrad_h<64, 128, 2, 2>(a, splits, stream);
+  else rc = launch_wgrad_h<64, 64, 2, 2>(a, splits, stream);
+  if (rc != 0) return rc;
+  const long long total = (long long)cout * a.taps * cin;
+  hipLaunchKernelGGL(wgrad_h_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const float*>(workspace), dw_oihw, splits, cout, cin, a.taps);
+  return (int)hipGetLastError();
+}

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include "fsdet.h"
 #include "profile.hpp"
+#include "ew_types.hpp"
 
 namespace {
 
@@ -20,13 +21,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FirstFwdArgs {
-  const float* x; const float* w; const float* bias; float* y; float* partial;
+  const float* x; const float* w; const float* bias; void* y; float* partial;     // y: float or bf16 (kernel template)
   unsigned x_ld, y_ld;
   int H, W, cin, Cout;
   long long pixels;
   int ppw;                          // pixels per wave (multiple of 32)
 };
 
+template <typename TO>
 __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
   __shared__ float s_red[4][32][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,13 +73,13 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
     }
     // rows of this lane: (r & 3) + 8 * (r >> 2) + 4h; byte offsets advance by whole pixel rows of y
     char* y_b = reinterpret_cast<char*>(p.y);
-    const unsigned ys = p.y_ld * 4u;
-    unsigned off = ((unsigned)base + 4u * h) * ys + (unsigned)co * 4u;
+    const unsigned ys = p.y_ld * (unsigned)sizeof(TO);
+    unsigned off = ((unsigned)base + 4u * h) * ys + (unsigned)co * (unsigned)sizeof(TO);
     if (base + 32 <= p_end) {                        // whole tile inside this wave's run (wave-uniform)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
-        *reinterpret_cast<float*>(y_b + off) = v + bv;
+        fsd_ew::st1<TO>(reinterpret_cast<TO*>(y_b + off), v + bv);
         s1 += v;
         s2 += v * v;
         off += ((r & 3) == 3) ? 5u * ys : ys;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
       for (int r = 0; r < 16; ++r) {
         if ((r & 3) + 8 * (r >> 2) + 4 * h < left) {
           const float v = acc[r];
-          *reinterpret_cast<float*>(y_b + off) = v + bv;
+          fsd_ew::st1<TO>(reinterpret_cast<TO*>(y_b + off), v + bv);
           s1 += v;
           s2 += v * v;
         }
@@ -134,9 +136,11 @@ extern "C" int fsd_conv3x3_c4_partial_rows(int batch, int height, int width) {
   return first_fwd_blocks((long long)batch * height * width);
 }
 
-extern "C" int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w_oihw, const float* bias, float* y,
-                                  long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
-                                  hipStream_t stream) {
+namespace {
+
+template <typename TO>
+int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const float* bias, TO* y, long long y_ld,
+                    float* bn_partial, int batch, int height, int width, int cin, int cout, hipStream_t stream) {
   (void)hipGetLastError();
   if (!x || !w_oihw || !y || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
   if (cin < 1 || cin > 4 || cout % 32 || x_ld < 4 || (x_ld & 3) || y_ld < cout) return FSD_ERR_UNSUPPORTED;
@@ -150,7 +154,24 @@ extern "C" int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w
   a.H = height; a.W = width; a.cin = cin; a.Cout = cout; a.pixels = pixels;
   const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
   a.ppw = (int)((per + 63) / 64 * 64);
-  fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + 4.0 * cout), stream);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + (double)sizeof(TO) * cout), stream);
+  hipLaunchKernelGGL(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_conv3x3_c4_fwd(const float* x, long long x_ld, const float* w_oihw, const float* bias, float* y,
+                                  long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                                  hipStream_t stream) {
+  return conv_first_impl<float>(x, x_ld, w_oihw, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, stream);
+}
+
+/* bf16 mode: the same fp32 arithmetic (fp32 input pixels, fp32 weights), the raw output stored as bfloat16; the BatchNorm
+ * partial sums still come from the fp32 accumulators. */
+extern "C" int fsd_conv3x3_c4_fwd_h(const float* x, long long x_ld, const float* w_oihw, const float* bias, void* y_bf16,
+                                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                                    hipStream_t stream) {
+  return conv_first_impl<fsd_ew::bf16_t>(x, x_ld, w_oihw, bias, static_cast<fsd_ew::bf16_t*>(y_bf16), y_ld, bn_partial, batch,
+                                         height, width, cin, cout, stream);
 }

@@ -5,10 +5,16 @@
 #include <stdint.h>
 #include "fsdet.h"
 #include "profile.hpp"
+#include "ew_types.hpp"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using fsd_ew::bf16_t;
+using fsd_ew::f32x4;
+using fsd_ew::ld1;
+using fsd_ew::ld4;
+using fsd_ew::st1;
+using fsd_ew::st4;
 constexpr int kBnSlots = 256;
 
 inline unsigned blocks_for(long long n, int per) {
@@ -114,11 +120,11 @@ __device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 sc, f32x4 sh, float s
   return r;
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restrict__ y, long long y_ld,
+template <typename T, int POOL>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, long long y_ld,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float slope,
-                                                          float* __restrict__ z, long long z_ld, int H, int W,
+                                                          T* __restrict__ z, long long z_ld, int H, int W,
                                                           int OH, int OW, int cg, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restric
   const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 out;
   if constexpr (POOL == 0) {
-    out = affine_act(*reinterpret_cast<const f32x4*>(y + opix * y_ld + g * 4), sc, sh, slope);
+    out = affine_act(ld4<T>(y + opix * y_ld + g * 4), sc, sh, slope);
   } else {
     const int ox = (int)(opix % OW);
     const long long t = opix / OW;
@@ -136,37 +142,38 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* __restric
     const long long b = t / OH;
     const int y0 = POOL == 1 ? 2 * oy : oy, x0 = POOL == 1 ? 2 * ox : ox;
     const int y1 = (y0 + 1 < H) ? y0 + 1 : H - 1, x1 = (x0 + 1 < W) ? x0 + 1 : W - 1;   // replicate pad (stride 1)
-    const float* base = y + (b * H * (long long)W) * y_ld + g * 4;
-    const f32x4 v00 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * y_ld), sc, sh, slope);
-    const f32x4 v01 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x1) * y_ld), sc, sh, slope);
-    const f32x4 v10 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * y_ld), sc, sh, slope);
-    const f32x4 v11 = affine_act(*reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * y_ld), sc, sh, slope);
+    const T* base = y + (b * H * (long long)W) * y_ld + g * 4;
+    const f32x4 v00 = affine_act(ld4<T>(base + ((long long)y0 * W + x0) * y_ld), sc, sh, slope);
+    const f32x4 v01 = affine_act(ld4<T>(base + ((long long)y0 * W + x1) * y_ld), sc, sh, slope);
+    const f32x4 v10 = affine_act(ld4<T>(base + ((long long)y1 * W + x0) * y_ld), sc, sh, slope);
+    const f32x4 v11 = affine_act(ld4<T>(base + ((long long)y1 * W + x1) * y_ld), sc, sh, slope);
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
   }
-  *reinterpret_cast<f32x4*>(z + opix * z_ld + g * 4) = out;
+  st4<T>(z + opix * z_ld + g * 4, out);
 }
 
 // ---- batched 2-D transpose through LDS (NCHW <-> NHWC) ---------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, long long sbs, long long srs,
-                                                        float* __restrict__ dst, long long dbs, long long drs,
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, long long sbs, long long srs,
+                                                        TD* __restrict__ dst, long long dbs, long long drs,
                                                         int rows, int cols) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-  const float* s = src + (long long)b * sbs;
-  float* d = dst + (long long)b * dbs;
+  const TS* s = src + (long long)b * sbs;
+  TD* d = dst + (long long)b * dbs;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + 8 * k, c = c0 + tx;
-    if (r < rows && c < cols) tile[ty + 8 * k][tx] = s[(long long)r * srs + c];
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = ld1<TS>(s + (long long)r * srs + c);
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + ty + 8 * k, r = r0 + tx;
-    if (r < rows && c < cols) d[(long long)c * drs + r] = tile[tx][ty + 8 * k];
+    if (r < rows && c < cols) st1<TD>(d + (long long)c * drs + r, tile[tx][ty + 8 * k]);
   }
 }
 
@@ -193,7 +200,8 @@ __global__ void fill_kernel(float* dst, float v, long long n) {
 }
 
 // ---- reorg (space to depth), NHWC ------------------------------------------------------------
-__global__ void reorg_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ out, long long out_ld,
+template <typename T>
+__global__ void reorg_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ out, long long out_ld,
                              int H, int W, int C, int s, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -205,22 +213,23 @@ __global__ void reorg_kernel(const float* __restrict__ x, long long x_ld, float*
   const long long b = t / H;
   const int OH = H / s, OW = W / s;
   const int oi = iy / s, di = iy - oi * s, oj = ix / s, dj = ix - oj * s;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4);
-  *reinterpret_cast<f32x4*>(out + ((b * OH + oi) * (long long)OW + oj) * out_ld + (di * s + dj) * C + g * 4) = v;
+  const f32x4 v = ld4<T>(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 4);
+  st4<T>(out + ((b * OH + oi) * (long long)OW + oj) * out_ld + (di * s + dj) * C + g * 4, v);
 }
 
 // ---- global max pool: (B, HW, C) -> (B, C) -----------------------------------------------------
-__global__ void global_max_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ out,
+template <typename T>
+__global__ void global_max_kernel(const T* __restrict__ x, long long x_ld, float* __restrict__ out,
                                   int* __restrict__ argmax, int HW, int C, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % C);
   const long long b = idx / C;
-  const float* p = x + b * HW * x_ld + c;
-  float best = p[0];
+  const T* p = x + b * HW * x_ld + c;
+  float best = ld1<T>(p);
   int arg = 0;
   for (int i = 1; i < HW; ++i) {
-    const float v = p[(long long)i * x_ld];
+    const float v = ld1<T>(p + (long long)i * x_ld);
     if (v > best || v != v) { best = v; arg = i; }
   }
   out[idx] = best;
@@ -280,9 +289,11 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, const float* shift,
-                                   float slope, int pool, float* z, long long z_ld, int batch, int height,
-                                   int width, int channels, hipStream_t stream) {
+namespace {
+
+template <typename T>
+int bn_act_pool_impl(const T* y, long long y_ld, const float* scale, const float* shift, float slope, int pool, T* z,
+                     long long z_ld, int batch, int height, int width, int channels, hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!y || !z || batch < 1 || channels < 4 || (channels & 3) || (y_ld & 3) || (z_ld & 3)) return FSD_ERR_ARG;
   if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
@@ -292,26 +303,68 @@ extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* 
   const long long total = (long long)batch * OH * OW * cg;
   const dim3 grid(blocks_for(total, 256)), block(256);
   // algorithmic bytes: read y once, write z once
-  fsd_prof::Scope prof(fsd_prof::kActFwd, 4.0 * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
+  fsd_prof::Scope prof(fsd_prof::kActFwd, (double)sizeof(T) * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
   if (pool == 0)
-    hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, 0>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else if (pool == 1)
-    hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, 1>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else
-    hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    hipLaunchKernelGGL((bn_act_pool_kernel<T, 2>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
-                                     float* dst, long long dst_batch_stride, long long dst_row_stride, int batch,
-                                     int rows, int cols, hipStream_t stream) {
+}  // namespace
+
+extern "C" int fsd_bn_act_pool_fwd(const float* y, long long y_ld, const float* scale, const float* shift,
+                                   float slope, int pool, float* z, long long z_ld, int batch, int height,
+                                   int width, int channels, hipStream_t stream) {
+  return bn_act_pool_impl<float>(y, y_ld, scale, shift, slope, pool, z, z_ld, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_bn_act_pool_fwd_h(const void* y, long long y_ld, const float* scale, const float* shift,
+                                     float slope, int pool, void* z, long long z_ld, int batch, int height,
+                                     int width, int channels, hipStream_t stream) {
+  return bn_act_pool_impl<bf16_t>(static_cast<const bf16_t*>(y), y_ld, scale, shift, slope, pool, static_cast<bf16_t*>(z),
+                                  z_ld, batch, height, width, channels, stream);
+}
+
+namespace {
+
+template <typename TS, typename TD>
+int transpose_impl(const TS* src, long long src_batch_stride, long long src_row_stride, TD* dst, long long dst_batch_stride,
+                   long long dst_row_stride, int batch, int rows, int cols, hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!src || !dst || batch < 1 || rows < 1 || cols < 1 || batch > 65535) return FSD_ERR_ARG;
   const dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
+  hipLaunchKernelGGL((transpose_kernel<TS, TD>), grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
                      dst_batch_stride, dst_row_stride, rows, cols);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_transpose_batched(const float* src, long long src_batch_stride, long long src_row_stride,
+                                     float* dst, long long dst_batch_stride, long long dst_row_stride, int batch,
+                                     int rows, int cols, hipStream_t stream) {
+  return transpose_impl<float, float>(src, src_batch_stride, src_row_stride, dst, dst_batch_stride, dst_row_stride, batch,
+                                      rows, cols, stream);
+}
+
+extern "C" int fsd_transpose_batched_h(const void* src, int src_bf16, long long src_batch_stride, long long src_row_stride,
+                                       void* dst, int dst_bf16, long long dst_batch_stride, long long dst_row_stride,
+                                       int batch, int rows, int cols, hipStream_t stream) {
+  if (src_bf16 && dst_bf16)
+    return transpose_impl<bf16_t, bf16_t>(static_cast<const bf16_t*>(src), src_batch_stride, src_row_stride,
+                                          static_cast<bf16_t*>(dst), dst_batch_stride, dst_row_stride, batch, rows, cols, stream);
+  if (src_bf16)
+    return transpose_impl<bf16_t, float>(static_cast<const bf16_t*>(src), src_batch_stride, src_row_stride,
+                                         static_cast<float*>(dst), dst_batch_stride, dst_row_stride, batch, rows, cols, stream);
+  if (dst_bf16)
+    return transpose_impl<float, bf16_t>(static_cast<const float*>(src), src_batch_stride, src_row_stride,
+                                         static_cast<bf16_t*>(dst), dst_batch_stride, dst_row_stride, batch, rows, cols, stream);
+  return transpose_impl<float, float>(static_cast<const float*>(src), src_batch_stride, src_row_stride,
+                                      static_cast<float*>(dst), dst_batch_stride, dst_row_stride, batch, rows, cols, stream);
 }
 
 extern "C" int fsd_nchw_to_nhwc4(const float* src, float* dst, int batch, int channels, long long hw, hipStream_t stream) {
@@ -333,26 +386,53 @@ extern "C" int fsd_fill(float* dst, float value, long long count, hipStream_t st
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, int batch, int height,
-                             int width, int channels, int stride, hipStream_t stream) {
+namespace {
+
+template <typename T>
+int reorg_impl(const T* x, long long x_ld, T* out, long long out_ld, int batch, int height, int width, int channels,
+               int stride, hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !out || stride < 1 || height % stride || width % stride || (channels & 3) || (x_ld & 3) || (out_ld & 3))
     return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * (channels / 4);
-  hipLaunchKernelGGL(reorg_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, out_ld, height,
+  hipLaunchKernelGGL(reorg_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, out_ld, height,
                      width, channels, stride, total);
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch, int height,
-                                      int width, int channels, hipStream_t stream) {
+template <typename T>
+int global_maxpool_impl(const T* x, long long x_ld, float* out, int* argmax, int batch, int height, int width, int channels,
+                        hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !out || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
   if (height != width) return FSD_ERR_UNSUPPORTED;   // pooling.py:23-27 assumes a square map
   const long long total = (long long)batch * channels;
-  hipLaunchKernelGGL(global_max_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, argmax,
+  hipLaunchKernelGGL(global_max_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, argmax,
                      height * width, channels, total);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, int batch, int height,
+                             int width, int channels, int stride, hipStream_t stream) {
+  return reorg_impl<float>(x, x_ld, out, out_ld, batch, height, width, channels, stride, stream);
+}
+
+extern "C" int fsd_reorg_fwd_h(const void* x, long long x_ld, void* out, long long out_ld, int batch, int height,
+                               int width, int channels, int stride, hipStream_t stream) {
+  return reorg_impl<bf16_t>(static_cast<const bf16_t*>(x), x_ld, static_cast<bf16_t*>(out), out_ld, batch, height, width,
+                            channels, stride, stream);
+}
+
+extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch, int height,
+                                      int width, int channels, hipStream_t stream) {
+  return global_maxpool_impl<float>(x, x_ld, out, argmax, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_global_maxpool_fwd_h(const void* x, long long x_ld, float* out, int* argmax, int batch, int height,
+                                        int width, int channels, hipStream_t stream) {
+  return global_maxpool_impl<bf16_t>(static_cast<const bf16_t*>(x), x_ld, out, argmax, batch, height, width, channels, stream);
 }
 
 extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,

@@ -16,6 +16,7 @@
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
+#include "ew_types.hpp"
 
 namespace {
 
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   B[k][(tap,ci)] = x[pix + k + shift(tap)][ci]      taps 0..7 = 32 columns  (L1/L2-resident 16-B pixels)
 // and the ninth tap (4 columns) is a 4-FMA side sum per lane.  One wave owns a contiguous run of pixels.
 struct FirstArgs {
-  const float* dt; const float* y; const float* coef; const float* mean; const float* invstd; const float* x;
+  const void* dt; const void* y;    // float or bf16 (template parameter of the kernel), same leading dimensions in ELEMENTS
+  const float* coef; const float* mean; const float* invstd; const float* x;
   float* ws;                        // [blocks][Cout][36]
   unsigned dt_ld, y_ld, x_ld;
   int H, W, Cout;
@@ -342,8 +344,9 @@ struct FirstArgs {
 
 // SIDE = false: 3 input channels, the 27 (tap, ci) columns fit one 32-wide MFMA tile.
 // SIDE = true : 4 input channels, taps 0..7 in the tile and the ninth tap as a 4-FMA side sum per lane.
-template <bool SIDE>
+template <bool SIDE, typename T>
 __global__ __launch_bounds__(256) void wgrad_first_kernel(FirstArgs p) {
+  constexpr unsigned ES = sizeof(T);                         // bytes per dt / y element
   __shared__ float s_out[4][32 * 36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -370,10 +373,10 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(FirstArgs p) {
     const char* dt_b = reinterpret_cast<const char*>(p.dt);
     const char* y_b = reinterpret_cast<const char*>(p.y);
     const char* x_b = reinterpret_cast<const char*>(p.x);
-    unsigned off_dt = ((unsigned)pix0 * p.dt_ld + co) * 4u, off_y = ((unsigned)pix0 * p.y_ld + co) * 4u;
+    unsigned off_dt = ((unsigned)pix0 * p.dt_ld + co) * ES, off_y = ((unsigned)pix0 * p.y_ld + co) * ES;
     unsigned off_x = (unsigned)pix0 * p.x_ld * 4u;
-    const unsigned safe_dt = ((unsigned)p_begin * p.dt_ld + co) * 4u, safe_y = ((unsigned)p_begin * p.y_ld + co) * 4u;
-    const unsigned step_dt = 8u * p.dt_ld, step_y = 8u * p.y_ld, step_x = 8u * p.x_ld;      // two pixels, in bytes
+    const unsigned safe_dt = ((unsigned)p_begin * p.dt_ld + co) * ES, safe_y = ((unsigned)p_begin * p.y_ld + co) * ES;
+    const unsigned step_dt = 2u * ES * p.dt_ld, step_y = 2u * ES * p.y_ld, step_x = 8u * p.x_ld;      // two pixels, in bytes
     const int kb = ((dyo * p.W + dxo) * (int)p.x_ld + ci) * 4, k8 = (p.W + 1) * (int)p.x_ld * 4;
     int rel = h;                                             // pixel index of this lane within the wave's run
     // Operands of 4 k-steps (8 pixels).  Loads are unconditional from clamped (always mapped) offsets and the
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(FirstArgs p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bool valid = rel < len;
-        g.dtv[s] = *reinterpret_cast<const float*>(dt_b + (valid ? off_dt : safe_dt));
-        g.yv[s] = *reinterpret_cast<const float*>(y_b + (valid ? off_y : safe_y));
+        g.dtv[s] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(dt_b + (valid ? off_dt : safe_dt)));
+        g.yv[s] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + (valid ? off_y : safe_y)));
         const bool okb = valid && col_ok && (unsigned)(yy + dyo) < (unsigned)p.H && (unsigned)(xx + dxo) < (unsigned)p.W;
         g.bv[s] = *reinterpret_cast<const float*>(x_b + (okb ? off_x + (unsigned)kb : 0u));
         g.mask |= (valid ? 1u : 0u) << s;
@@ -637,10 +640,12 @@ extern "C" size_t fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(int batch, int he
   return (size_t)first_blocks((long long)batch * height * width) * cout * 36 * sizeof(float);
 }
 
-extern "C" int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* y, long long y_ld,
-                                            const float* coef, const float* mean, const float* invstd, const float* x,
-                                            long long x_ld, float* dw_oihw, void* workspace, size_t workspace_bytes,
-                                            int batch, int height, int width, int cin, int cout, hipStream_t stream) {
+namespace {
+
+template <typename T>
+int wgrad_first_impl(const T* dt, long long dt_ld, const T* y, long long y_ld, const float* coef, const float* mean,
+                     const float* invstd, const float* x, long long x_ld, float* dw_oihw, void* workspace,
+                     size_t workspace_bytes, int batch, int height, int width, int cin, int cout, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dt || !y || !coef || !mean || !invstd || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1)
     return FSD_ERR_ARG;
@@ -658,15 +663,34 @@ extern "C" int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, co
   a.H = height; a.W = width; a.Cout = cout; a.pixels = pixels;
   a.ppw = round_up((int)((pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 16);
   {
-    fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (8.0 * cout + 16.0), stream);
-    if (cin == 4) hipLaunchKernelGGL(wgrad_first_kernel<true>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(wgrad_first_kernel<false>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (2.0 * sizeof(T) * cout + 16.0), stream);
+    if (cin == 4) hipLaunchKernelGGL((wgrad_first_kernel<true, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((wgrad_first_kernel<false, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   }
   if (blocks <= 8)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(1, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(2, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* y, long long y_ld,
+                                            const float* coef, const float* mean, const float* invstd, const float* x,
+                                            long long x_ld, float* dw_oihw, void* workspace, size_t workspace_bytes,
+                                            int batch, int height, int width, int cin, int cout, hipStream_t stream) {
+  return wgrad_first_impl<float>(dt, dt_ld, y, y_ld, coef, mean, invstd, x, x_ld, dw_oihw, workspace, workspace_bytes, batch,
+                                 height, width, cin, cout, stream);
+}
+
+extern "C" int fsd_conv3x3_wgrad_c4_bnfused_h(const void* dt, long long dt_ld, const void* y, long long y_ld,
+                                              const float* coef, const float* mean, const float* invstd, const float* x,
+                                              long long x_ld, float* dw_oihw, void* workspace, size_t workspace_bytes,
+                                              int batch, int height, int width, int cin, int cout, hipStream_t stream) {
+  return wgrad_first_impl<fsd_ew::bf16_t>(static_cast<const fsd_ew::bf16_t*>(dt), dt_ld, static_cast<const fsd_ew::bf16_t*>(y),
+                                          y_ld, coef, mean, invstd, x, x_ld, dw_oihw, workspace, workspace_bytes, batch,
+                                          height, width, cin, cout, stream);
 }
 
 extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {

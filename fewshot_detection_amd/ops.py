@@ -23,7 +23,8 @@ def require_device(*tensors):
 
 
 class View(object):
-    """NHWC activation: `t` is a 2-D (pixels, ld) buffer, channels [c0, c0+C) of each pixel."""
+    """NHWC activation: `t` is a 2-D (pixels, ld) buffer, channels [c0, c0+C) of each pixel.  The buffer is float32
+    (fp32 mode) or bfloat16 (bf16 storage mode); `ld` and `c0` count ELEMENTS."""
     __slots__ = ("t", "B", "H", "W", "C", "c0")
 
     def __init__(self, t, B, H, W, C, c0=0):
@@ -34,8 +35,12 @@ class View(object):
         return self.t.shape[1]
 
     @property
+    def bf16(self):
+        return self.t.dtype == torch.bfloat16
+
+    @property
     def ptr(self):
-        return self.t.data_ptr() + 4 * self.c0
+        return self.t.data_ptr() + self.t.element_size() * self.c0
 
     @property
     def pixels(self):
@@ -45,8 +50,14 @@ class View(object):
         return self.t[:, self.c0:self.c0 + self.C]
 
 
-def new_view(B, H, W, C, device, ld=None):
-    return View(torch.empty((B * H * W, ld or C), dtype=torch.float32, device=device), B, H, W, C)
+def new_view(B, H, W, C, device, ld=None, dtype=torch.float32):
+    return View(torch.empty((B * H * W, ld or C), dtype=dtype, device=device), B, H, W, C)
+
+
+def like_view(v, C=None, ld=None, H=None, W=None):
+    """A fresh view with the storage type of `v` (fp32 or bf16 mode follows the activations)."""
+    return new_view(v.B, v.H if H is None else H, v.W if W is None else W, v.C if C is None else C, v.t.device, ld=ld,
+                    dtype=v.t.dtype)
 
 
 def fill(t, value):
@@ -54,24 +65,29 @@ def fill(t, value):
     return t
 
 
-def nchw_to_nhwc(x, pad_to=4, out=None):
-    """(B,C,H,W) contiguous -> View with channels padded (zeros) to a multiple of `pad_to`."""
+def nchw_to_nhwc(x, pad_to=4, out=None, dtype=torch.float32):
+    """(B,C,H,W) contiguous float32 -> View with channels padded (zeros) to a multiple of `pad_to`; `dtype` = storage
+    type of the result (torch.bfloat16 in bf16 mode)."""
     require_device(x)
     if x.dtype != torch.float32:
         raise ValueError("nchw_to_nhwc needs a float32 tensor (got %s)" % x.dtype)
     x = x.contiguous()
     B, Cc, H, W = x.shape
     Cp = (Cc + pad_to - 1) // pad_to * pad_to
-    if out is None and Cp == 4:            # network inputs: one pass, zero padding included
+    if out is None and Cp == 4 and dtype == torch.float32:            # network inputs: one pass, zero padding included
         out = new_view(B, H, W, 4, x.device)
         check(lib().fsd_nchw_to_nhwc4(x.data_ptr(), out.ptr, B, Cc, H * W, _stream()), "fsd_nchw_to_nhwc4")
         return out
     if out is None:
-        out = new_view(B, H, W, Cp, x.device)
+        out = new_view(B, H, W, Cp, x.device, dtype=dtype)
         if Cp != Cc:
-            fill(out.t, 0.0)
-    check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, out.ptr, H * W * out.ld, out.ld,
-                                      B, Cc, H * W, _stream()), "fsd_transpose_batched")
+            out.t.zero_()
+    if out.bf16:
+        check(lib().fsd_transpose_batched_h(x.data_ptr(), 0, Cc * H * W, H * W, out.ptr, 1, H * W * out.ld, out.ld,
+                                            B, Cc, H * W, _stream()), "fsd_transpose_batched_h")
+    else:
+        check(lib().fsd_transpose_batched(x.data_ptr(), Cc * H * W, H * W, out.ptr, H * W * out.ld, out.ld,
+                                          B, Cc, H * W, _stream()), "fsd_transpose_batched")
     return out
 
 
@@ -91,8 +107,12 @@ def write_channels(x, view, c_off):
 def nhwc_to_nchw(v):
     out = torch.empty((v.B, v.C, v.H, v.W), dtype=torch.float32, device=v.t.device)
     hw = v.H * v.W
-    check(lib().fsd_transpose_batched(v.ptr, hw * v.ld, v.ld, out.data_ptr(), v.C * hw, hw, v.B, hw, v.C,
-                                      _stream()), "fsd_transpose_batched")
+    if v.bf16:
+        check(lib().fsd_transpose_batched_h(v.ptr, 1, hw * v.ld, v.ld, out.data_ptr(), 0, v.C * hw, hw, v.B, hw, v.C,
+                                            _stream()), "fsd_transpose_batched_h")
+    else:
+        check(lib().fsd_transpose_batched(v.ptr, hw * v.ld, v.ld, out.data_ptr(), v.C * hw, hw, v.B, hw, v.C,
+                                          _stream()), "fsd_transpose_batched")
     return out
 
 
@@ -190,6 +210,8 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out)."""
     dev = xv.t.device
     partial = None
+    if xv.bf16:
+        return _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out)
     if nchw_out:
         y = torch.empty((xv.B, cout, xv.H, xv.W), dtype=torch.float32, device=dev)
         y_ptr, y_ld = y.data_ptr(), 0
@@ -215,11 +237,41 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     return y, partial
 
 
-def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False):
-    """First-layer 3x3 convolution of an NHWC4 view straight from the OIHW weights (HBM-bound direct-operand kernel)."""
+def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out):
+    """bf16 storage mode: bf16 NHWC activations x packed bf16 weights -> bf16 NHWC (or float NCHW for the head)."""
     L = lib()
     dev = xv.t.device
-    y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
+    if w_packed.dtype != torch.bfloat16:
+        raise ValueError("bf16 activations need bf16-packed weights")
+    partial = None
+    if nchw_out:
+        y = torch.empty((xv.B, cout, xv.H, xv.W), dtype=torch.float32, device=dev)
+        y_ptr, y_ld = y.data_ptr(), 0
+    else:
+        y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev, dtype=torch.bfloat16)
+        if not y.bf16:
+            raise ValueError("bf16 convolution needs a bf16 output view")
+        y_ptr, y_ld = y.ptr, y.ld
+    if bn_partial:
+        partial = torch.empty((L.fsd_conv_row_tiles_h(xv.pixels), cout, 2), dtype=torch.float32, device=dev)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(L.fsd_conv2d_fwd_h(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial), xv.B, xv.H, xv.W,
+                             xv.C, cout, ksize, 1 if nchw_out else 0, _stream()), "fsd_conv2d_fwd_h")
+    if PROFILE is not None:
+        e1.record()
+        fl = 2.0 * ksize * ksize * xv.C * cout * xv.pixels
+        PROFILE.append((e0, e1, fl, fl))
+    return y, partial
+
+
+def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False, out_dtype=torch.float32):
+    """First-layer 3x3 convolution of an NHWC4 view straight from the OIHW weights (HBM-bound direct-operand kernel).
+    out_dtype = torch.bfloat16 stores the raw output in bf16 (bf16 mode); the arithmetic is fp32 either way."""
+    L = lib()
+    dev = xv.t.device
+    y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev, dtype=out_dtype)
     partial = None
     if bn_partial:
         partial = torch.empty((L.fsd_conv3x3_c4_partial_rows(xv.B, xv.H, xv.W), cout, 2), dtype=torch.float32, device=dev)
@@ -227,8 +279,9 @@ def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.fsd_conv3x3_c4_fwd(xv.ptr, xv.ld, w.detach().contiguous().data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                               xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_c4_fwd")
+    fn = L.fsd_conv3x3_c4_fwd_h if y.bf16 else L.fsd_conv3x3_c4_fwd
+    check(fn(xv.ptr, xv.ld, w.detach().contiguous().data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+             xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_c4_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels))
@@ -255,25 +308,27 @@ def bn_finalize(partial, count, bn, training):
 
 def bn_act_pool(yv, scale, shift, slope, pool, out=None):
     OH, OW = (yv.H // 2, yv.W // 2) if pool == 1 else (yv.H, yv.W)
-    z = out if out is not None else new_view(yv.B, OH, OW, yv.C, yv.t.device)
-    check(lib().fsd_bn_act_pool_fwd(yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, z.ptr, z.ld,
-                                    yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_act_pool_fwd")
+    z = out if out is not None else like_view(yv, H=OH, W=OW)
+    if z.bf16 != yv.bf16:
+        raise ValueError("bn_act_pool: input and output views must share the storage type")
+    fn = lib().fsd_bn_act_pool_fwd_h if yv.bf16 else lib().fsd_bn_act_pool_fwd
+    check(fn(yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, z.ptr, z.ld,
+             yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_act_pool_fwd")
     return z
 
 
 def reorg(xv, stride, out=None):
-    z = out if out is not None else new_view(xv.B, xv.H // stride, xv.W // stride, xv.C * stride * stride,
-                                             xv.t.device)
-    check(lib().fsd_reorg_fwd(xv.ptr, xv.ld, z.ptr, z.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()),
-          "fsd_reorg_fwd")
+    z = out if out is not None else like_view(xv, C=xv.C * stride * stride, H=xv.H // stride, W=xv.W // stride)
+    fn = lib().fsd_reorg_fwd_h if xv.bf16 else lib().fsd_reorg_fwd
+    check(fn(xv.ptr, xv.ld, z.ptr, z.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()), "fsd_reorg_fwd")
     return z
 
 
 def global_maxpool(xv, want_argmax=False):
     out = torch.empty((xv.B, xv.C), dtype=torch.float32, device=xv.t.device)
     arg = torch.empty((xv.B, xv.C), dtype=torch.int32, device=xv.t.device) if want_argmax else None
-    check(lib().fsd_global_maxpool_fwd(xv.ptr, xv.ld, out.data_ptr(), _ptr(arg), xv.B, xv.H, xv.W, xv.C,
-                                       _stream()), "fsd_global_maxpool_fwd")
+    fn = lib().fsd_global_maxpool_fwd_h if xv.bf16 else lib().fsd_global_maxpool_fwd
+    check(fn(xv.ptr, xv.ld, out.data_ptr(), _ptr(arg), xv.B, xv.H, xv.W, xv.C, _stream()), "fsd_global_maxpool_fwd")
     return out, arg
 
 
@@ -357,6 +412,8 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
     param: the parameter this is the gradient of (lets a trainer's gradient sink receive it directly)."""
     L = lib()
     dev = xv.t.device
+    if xv.bf16 or dyv.bf16:
+        return _conv2d_wgrad_h(dyv, cout, xv, cin, ksize, param)
     if tile is None:
         tile = wino_tile(cin, cout, ksize, xv.H, xv.W) if dtype == "f32" else 0
     if dtype == "f32" and tile and cin == xv.C:
@@ -376,6 +433,20 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
     return dw
 
 
+def _conv2d_wgrad_h(dyv, cout, xv, cin, ksize, param):
+    """bf16 storage mode: dW (float, OIHW) from bf16 dy and bf16 x."""
+    L = lib()
+    dev = xv.t.device
+    if not (xv.bf16 and dyv.bf16):
+        raise ValueError("bf16 weight gradient needs bf16 dy and bf16 x")
+    ws_bytes = L.fsd_conv2d_wgrad_h_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    dw = grad_dst(param, (cout, cin, ksize, ksize), dev)
+    check(L.fsd_conv2d_wgrad_h(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H, xv.W,
+                               cin, cout, ksize, _stream()), "fsd_conv2d_wgrad_h")
+    return dw
+
+
 def c4_bnfused_eligible(xv, cout, ksize):
     """First-layer shape: NHWC4 input, 3x3, cout a multiple of 32 (darknet L0, reweighting-net L0)."""
     # the first-layer kernels address with 32-bit byte offsets: the (pixels, cout) activation must stay below 4 GiB
@@ -390,9 +461,12 @@ def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout, param=No
     ws_bytes = L.fsd_conv3x3_wgrad_c4_bnfused_workspace_bytes(xv.B, xv.H, xv.W, cout)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     dw = grad_dst(param, (cout, cin, 3, 3), dev)
-    check(L.fsd_conv3x3_wgrad_c4_bnfused(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(),
-                                         invstd.data_ptr(), xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes,
-                                         xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_wgrad_c4_bnfused")
+    if dt.bf16 != yv.bf16:
+        raise ValueError("dt and y must share the storage type")
+    fn = L.fsd_conv3x3_wgrad_c4_bnfused_h if dt.bf16 else L.fsd_conv3x3_wgrad_c4_bnfused
+    check(fn(dt.ptr, dt.ld, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(),
+             invstd.data_ptr(), xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes,
+             xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_wgrad_c4_bnfused")
     return dw
 
 
@@ -400,13 +474,16 @@ def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     """-> (dt View dense (pixels, C), partial [rows][C][2])."""
     L = lib()
     dev = yv.t.device
-    dt = new_view(yv.B, yv.H, yv.W, yv.C, dev)
+    dt = like_view(yv)
     partial = torch.empty((L.fsd_bn_act_pool_bwd_rows(yv.B, yv.H, yv.W, pool), yv.C, 2), dtype=torch.float32,
                           device=dev)
-    check(L.fsd_bn_act_pool_bwd(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
-                                0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift),
-                                _ptr(mean), _ptr(invstd), slope, pool, dt.ptr, partial.data_ptr(), yv.B, yv.H, yv.W,
-                                yv.C, _stream()), "fsd_bn_act_pool_bwd")
+    if dz.bf16 != yv.bf16 or (dz_full is not None and dz_full.bf16 != yv.bf16):
+        raise ValueError("gradient and activation views must share the storage type")
+    fn = L.fsd_bn_act_pool_bwd_h if yv.bf16 else L.fsd_bn_act_pool_bwd
+    check(fn(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
+             0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift),
+             _ptr(mean), _ptr(invstd), slope, pool, dt.ptr, partial.data_ptr(), yv.B, yv.H, yv.W,
+             yv.C, _stream()), "fsd_bn_act_pool_bwd")
     return dt, partial
 
 
@@ -424,36 +501,41 @@ def reduce_partials(partial, count, channels, scale=None, want_coef=False, param
 
 
 def bn_bwd_apply(dt, yv, coef, mean, invstd):
-    check(lib().fsd_bn_bwd_apply(dt.ptr, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                 yv.pixels, yv.C, _stream()), "fsd_bn_bwd_apply")
+    fn = lib().fsd_bn_bwd_apply_h if yv.bf16 else lib().fsd_bn_bwd_apply
+    check(fn(dt.ptr, yv.ptr, yv.ld, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+             yv.pixels, yv.C, _stream()), "fsd_bn_bwd_apply")
     return dt
 
 
 def colsum(v, channels, param=None):
     L = lib()
     partial = torch.empty((L.fsd_act_bwd_rows(v.pixels), channels, 2), dtype=torch.float32, device=v.t.device)
-    check(L.fsd_colsum_partials(v.ptr, v.ld, partial.data_ptr(), v.pixels, channels, _stream()),
-          "fsd_colsum_partials")
+    fn = L.fsd_colsum_partials_h if v.bf16 else L.fsd_colsum_partials
+    check(fn(v.ptr, v.ld, partial.data_ptr(), v.pixels, channels, _stream()), "fsd_colsum_partials")
     s, _, _ = reduce_partials(partial, v.pixels, channels, param0=param)
     return s
 
 
 def reorg_bwd(dout, xv, stride):
-    dx = new_view(xv.B, xv.H, xv.W, xv.C, xv.t.device)
-    check(lib().fsd_reorg_bwd(dout.ptr, dout.ld, dx.ptr, dx.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()),
-          "fsd_reorg_bwd")
+    dx = like_view(xv)
+    fn = lib().fsd_reorg_bwd_h if xv.bf16 else lib().fsd_reorg_bwd
+    check(fn(dout.ptr, dout.ld, dx.ptr, dx.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()), "fsd_reorg_bwd")
     return dx
 
 
 def global_maxpool_bwd(dout, arg, xv):
-    dx = new_view(xv.B, xv.H, xv.W, xv.C, xv.t.device)
-    check(lib().fsd_global_maxpool_bwd(dout.contiguous().data_ptr(), arg.data_ptr(), dx.ptr, dx.ld, xv.B, xv.H, xv.W,
-                                       xv.C, _stream()), "fsd_global_maxpool_bwd")
+    dx = like_view(xv)
+    fn = lib().fsd_global_maxpool_bwd_h if xv.bf16 else lib().fsd_global_maxpool_bwd
+    check(fn(dout.contiguous().data_ptr(), arg.data_ptr(), dx.ptr, dx.ld, xv.B, xv.H, xv.W, xv.C, _stream()),
+          "fsd_global_maxpool_bwd")
     return dx
 
 
 def add_inplace(dst, src):
-    check(lib().fsd_add_inplace(dst.ptr, dst.ld, src.ptr, src.ld, dst.pixels, dst.C, _stream()), "fsd_add_inplace")
+    if dst.bf16 != src.bf16:
+        raise ValueError("add_inplace: views must share the storage type")
+    fn = lib().fsd_add_inplace_h if dst.bf16 else lib().fsd_add_inplace
+    check(fn(dst.ptr, dst.ld, src.ptr, src.ld, dst.pixels, dst.C, _stream()), "fsd_add_inplace")
     return dst
 
 

@@ -297,6 +297,53 @@ int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dy
 int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
                  float weight_decay, int first_step, long long count, hipStream_t stream);
 
+/* ---- bf16 storage mode (BASELINE configs[2] / [4]) --------------------------------------------------------------
+ * The `_h` entry points are the bfloat16-storage twins of the functions above: every activation / activation-gradient
+ * tensor (`void*`) holds raw bfloat16 bits in the same NHWC layout with leading dimensions counted in ELEMENTS; all
+ * arithmetic, the BatchNorm partial sums and every parameter / parameter gradient stay float.  Arguments, shapes,
+ * return codes and the kernels behind them are otherwise identical (one kernel template, two instantiations). */
+int fsd_conv_row_tiles_h(long long pixels);          /* rows of the bn_partial array fsd_conv2d_fwd_h fills */
+/* bf16 activations x packed bf16 weights (fsd_pack_conv_weight_bf16) -> bf16 NHWC y (or float NCHW when out_nchw_f32),
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16, operands staged global -> LDS by DMA.  cin % 32 == 0, cout even. */
+int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
+                     long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout, int ksize,
+                     int out_nchw_f32, hipStream_t stream);
+size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize);
+/* dW (float, OIHW) from bf16 dy and bf16 x: K = pixels, fragments through the LDS transpose read. cin, cout % 8 == 0. */
+int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const void* x_bf16, long long x_ld, float* dw_oihw,
+                       void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin, int cout,
+                       int ksize, hipStream_t stream);
+int fsd_conv3x3_c4_fwd_h(const float* x, long long x_ld, const float* w_oihw, const float* bias, void* y_bf16,
+                         long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                         hipStream_t stream);
+int fsd_conv3x3_wgrad_c4_bnfused_h(const void* dt, long long dt_ld, const void* y, long long y_ld, const float* coef,
+                                   const float* mean, const float* invstd, const float* x, long long x_ld, float* dw_oihw,
+                                   void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                   int cout, hipStream_t stream);
+int fsd_bn_act_pool_fwd_h(const void* y, long long y_ld, const float* scale, const float* shift, float slope, int pool,
+                          void* z, long long z_ld, int batch, int height, int width, int channels, hipStream_t stream);
+/* src / dst each float (flag 0) or bf16 (flag 1) */
+int fsd_transpose_batched_h(const void* src, int src_bf16, long long src_batch_stride, long long src_row_stride, void* dst,
+                            int dst_bf16, long long dst_batch_stride, long long dst_row_stride, int batch, int rows,
+                            int cols, hipStream_t stream);
+int fsd_reorg_fwd_h(const void* x, long long x_ld, void* out, long long out_ld, int batch, int height, int width,
+                    int channels, int stride, hipStream_t stream);
+int fsd_global_maxpool_fwd_h(const void* x, long long x_ld, float* out, int* argmax, int batch, int height, int width,
+                             int channels, hipStream_t stream);
+int fsd_bn_act_pool_bwd_h(const void* dz, long long dz_ld, const void* dz_full, long long dz_full_ld, const void* y,
+                          long long y_ld, const float* scale, const float* shift, const float* mean, const float* invstd,
+                          float slope, int pool, void* dt, float* partial, int batch, int height, int width, int channels,
+                          hipStream_t stream);
+int fsd_bn_bwd_apply_h(void* dt, const void* y, long long y_ld, const float* coef, const float* mean, const float* invstd,
+                       long long pixels, int channels, hipStream_t stream);
+int fsd_colsum_partials_h(const void* m, long long ld, float* partial, long long rows, int channels, hipStream_t stream);
+int fsd_reorg_bwd_h(const void* dout, long long dout_ld, void* dx, long long dx_ld, int batch, int height, int width,
+                    int channels, int stride, hipStream_t stream);
+int fsd_global_maxpool_bwd_h(const float* dout, const int* argmax, void* dx, long long dx_ld, int batch, int height,
+                             int width, int channels, hipStream_t stream);
+int fsd_add_inplace_h(void* dst, long long dst_ld, const void* src, long long src_ld, long long rows, int channels,
+                      hipStream_t stream);
+
 /* Episode input pipeline on the device = the image half of the reference's CPU loader: image.data_augmentation
  * (jitter crop, NEAREST resize, horizontal flip, HSV distortion; image.py:13-87) + ToTensor (train_meta.py:176-178).
  * One gather kernel from packed uint8 RGB (HWC) source images to the float network input.
