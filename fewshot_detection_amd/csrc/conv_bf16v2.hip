@@ -438,14 +438,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
     const int ch = ch0 + 16 * (G & 1) + 4 * (Lq & 3);
     const int piece = (ch >> 3) ^ swzmask;
     const u16* a = tile + row * CH + piece * 8 + (ch & 7);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a + 4 * CH));
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = __builtin_bit_cast(__bf16, lo[e]);
-      v[4 + e] = __builtin_bit_cast(__bf16, hi[e]);
-    }
+    // the bf16-typed form of the builtin + one shufflevector: rebuilding the 8-element operand element by element from
+    // the v4i16 form (bit_cast short -> __bf16 per element) miscompiles on ROCm 7.2 (every element becomes element 0)
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a + 4 * CH));
+    const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return v;
   };
   auto compute = [&](const u16* st) {
