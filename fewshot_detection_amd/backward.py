@@ -26,6 +26,32 @@ def _accumulate(grads, view, g):
         grads[key] = g
 
 
+def _wgrad_h(net, dy, cout, xv, cin, k, weight):
+    """bf16 mode weight gradient; channel counts the transpose-read kernel does not take go through the fp32 kernel on
+    the same bf16-valued operands (non-standard cfgs only)."""
+    if dy.bf16 and xv.bf16 and cin % 8 == 0 and cout % 8 == 0 and xv.C == cin and dy.c0 % 8 == 0 and xv.c0 % 8 == 0:
+        return ops.conv2d_wgrad(dy, cout, xv, cin, k, param=weight)
+    net.fallback_convs += 1
+    return ops.conv2d_wgrad(ops.cast_view(dy, torch.float32), cout, ops.cast_view(xv, torch.float32), cin, k, "f32", tile=0,
+                            param=weight)
+
+
+def _dgrad_h(net, dy, conv, xv, k):
+    """bf16 mode data gradient (bf16 dy x bf16 rotated weights -> bf16 dx)."""
+    if dy.bf16 and dy.C % 32 == 0 and xv.C % 2 == 0 and dy.c0 % 8 == 0:
+        dx, _ = ops.conv2d(dy, net.cache.get(conv.weight, 1, "bf16"), xv.C, k)
+        return dx
+    net.fallback_convs += 1
+    dyf = ops.cast_view(dy, torch.float32)
+    if dyf.C % 4:
+        pad = torch.zeros((dyf.pixels, (dyf.C + 3) // 4 * 4), dtype=torch.float32, device=dyf.t.device)
+        pad[:, :dyf.C] = dyf.t
+        dyf = View(pad, dy.B, dy.H, dy.W, pad.shape[1])
+    wr = conv.weight.detach().to(torch.bfloat16).float()
+    dxf, _ = ops.conv2d(dyf, ops.pack_weight(wr, 1, "f32"), xv.C, k)
+    return ops.cast_view(dxf, torch.bfloat16)
+
+
 def _conv_backward(net, rec, grads, pgrads, first_input):
     gz = grads.pop(id(rec["z"]), None)
     gzf = grads.pop(id(rec["z_full"]), None) if rec.get("z_full") is not None else None
@@ -79,16 +105,21 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         dy = dt
     kept = rec.get("wino_v")
     wtile = rec.get("wino_tile") or 0
-    pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32" if wtile else net.compute_dtype,
-                                               wino_v=kept[0] if kept else None, param=conv.weight, tile=wtile,
-                                               wt_in=wt_in)
-    if xv is not first_input:
+    bf16 = net.compute_dtype == "bf16"
+    if bf16:
+        pgrads[id(conv.weight)] = _wgrad_h(net, dy, cout, xv, cin, k, conv.weight)
+    else:
+        pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32", wino_v=kept[0] if kept else None,
+                                                   param=conv.weight, tile=wtile, wt_in=wt_in)
+    if xv is not first_input and not rec.get("input_cast"):
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
-        tile = ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)
+        tile = 0 if bf16 else ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)
         if tile:
             dx, _ = ops.conv3x3_wino(dyv, net.cache.get(conv.weight, 1, "wino%d" % tile), xv.C, tile=tile)
+        elif bf16:
+            dx = _dgrad_h(net, dy, conv, xv, k)
         else:
-            dx, _ = ops.conv2d(dyv, net.cache.get(conv.weight, 1, net.compute_dtype), xv.C, k)
+            dx, _ = ops.conv2d(dyv, net.cache.get(conv.weight, 1, "f32"), xv.C, k)
         _accumulate(grads, xv, dx)
 
 
@@ -103,16 +134,23 @@ def run(net, tape, grad_out, params):
         kind = rec["kind"]
         if kind == "output":
             x = rec["x"]
-            g = ops.nchw_to_nhwc(grad_out.view(x.B, x.C, x.H, x.W), pad_to=4)
+            g = ops.nchw_to_nhwc(grad_out.view(x.B, x.C, x.H, x.W), pad_to=4, dtype=x.t.dtype)
             grads[id(x)] = View(g.t, x.B, x.H, x.W, x.C, 0)
         elif kind == "head":
             x, head, dyn, n_cls, o_ch = rec["x"], rec["head"], rec["dyn"], rec["n_cls"], rec["o_ch"]
             rows = n_cls * o_ch
-            g = ops.nchw_to_nhwc(grad_out.view(x.B, rows, x.H, x.W), pad_to=4)       # (B*HW, rows padded)
             w_eff = rec["w_eff"][:rows * x.C].view(rows, x.C, 1, 1)
-            dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, net.compute_dtype), x.C, 1)
+            if net.compute_dtype == "bf16":
+                # the loss gradient (float NCHW) becomes a bf16 NHWC matrix whose channel count is padded with zeros to a
+                # multiple of 64: the reduction dimension of its data-gradient GEMM, a row count the weight gradient takes
+                g = ops.nchw_to_nhwc(grad_out.view(x.B, rows, x.H, x.W), pad_to=64, dtype=torch.bfloat16)
+                dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, "bf16"), x.C, 1)
+                dweff = ops.conv2d_wgrad(g, g.C, x, x.C, 1)[:rows]
+            else:
+                g = ops.nchw_to_nhwc(grad_out.view(x.B, rows, x.H, x.W), pad_to=4)       # (B*HW, rows padded)
+                dx, _ = ops.conv2d(g, ops.pack_weight(w_eff, 1, "f32"), x.C, 1)
+                dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1, "f32")
             _accumulate(grads, x, dx)
-            dweff = ops.conv2d_wgrad(g, rows, x, x.C, 1, net.compute_dtype)
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach(), param=head.weight)
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn

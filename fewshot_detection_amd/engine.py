@@ -70,9 +70,11 @@ class Network(object):
         self.models = models
         self.layers = blocks[1:]
         self.cache = _WeightCache()
-        # "f32": exact fp32 MFMA.  "bf16": conv operands rounded to bf16, fp32 accumulate (BASELINE C3/C5);
-        # BatchNorm statistics, activations, loss, weight gradients and master weights stay fp32.
+        # "f32": exact fp32 MFMA, fp32 activations.  "bf16" (BASELINE configs[2] / [4]): activations and their gradients are
+        # STORED in HBM as bfloat16, convolutions run bf16 x bf16 -> fp32 on the bf16 matrix cores, BatchNorm statistics come
+        # from the fp32 accumulators; loss, parameter gradients, master weights and the optimizer stay fp32.
         self.compute_dtype = "f32"
+        self.fallback_convs = 0       # bf16 mode: convolutions whose channel counts the bf16 kernel does not take
         # static analysis: who is read by a [route], and which producers write into a concat buffer
         self.route_src = {}
         self.concat_of = {}
@@ -102,17 +104,38 @@ class Network(object):
         self.tapped = set(s for src in self.route_src.values() for s in src)
 
     # ---- helpers ---------------------------------------------------------------------------
+    @property
+    def act_dtype(self):
+        return torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+
     def _dest(self, ind, B, H, W, C, dev, bufs):
         """Output view for layer `ind`: a slice of its route's concat buffer, or a fresh tensor."""
         if ind in self.concat_of:
             route, off, total = self.concat_of[ind]
             if route not in bufs:
-                bufs[route] = ops.new_view(B, H, W, total, dev)
+                bufs[route] = ops.new_view(B, H, W, total, dev, dtype=self.act_dtype)
             big = bufs[route]
             if (big.B, big.H, big.W) != (B, H, W):
                 raise NotImplementedError("route over feature maps of different size (maybe_repeat)")
             return View(big.t, B, H, W, C, off)
-        return ops.new_view(B, H, W, C, dev)
+        return ops.new_view(B, H, W, C, dev, dtype=self.act_dtype)
+
+    def _conv_any(self, xv, conv, cout, k, bias, out, bn_partial):
+        """One non-Winograd, non-first-layer convolution in the network's storage mode -> (y view, partial sums)."""
+        if self.compute_dtype != "bf16":
+            wp = self.cache.get(conv.weight, 0, "f32")
+            return ops.conv2d(xv, wp, cout, k, bias=bias, out=out, bn_partial=bn_partial, cin_true=conv.weight.shape[1])
+        if xv.bf16 and xv.C % 32 == 0 and cout % 2 == 0 and xv.c0 % 8 == 0:
+            return ops.conv2d(xv, self.cache.get(conv.weight, 0, "bf16"), cout, k, bias=bias, out=out, bn_partial=bn_partial)
+        # channel counts outside the bf16 kernel (no shipped cfg has any past the first layer): the same arithmetic --
+        # bf16-rounded operands, fp32 accumulation, bf16 result -- on the fp32 kernel
+        self.fallback_convs += 1
+        xf = ops.cast_view(xv, torch.float32)
+        wr = conv.weight.detach().to(torch.bfloat16).float()
+        yf, partial = ops.conv2d(xf, ops.pack_weight(wr, 0, "f32"), cout, k, bias=bias, bn_partial=bn_partial,
+                                 cin_true=conv.weight.shape[1])
+        y = ops.cast_view(yf, torch.bfloat16, out=out)
+        return y, partial
 
     def _conv(self, ind, blk, xv, training, pool, bufs, tape):
         seq = self.models[ind]
@@ -127,15 +150,20 @@ class Network(object):
         slope = _slope(blk["activation"])
         # Winograd layers always run the fp32 Winograd pipeline: in bf16 mode it is both faster and more accurate than
         # the bf16 direct kernel (4x fewer multiplications beat the bf16 MFMA rate of a staging-bound kernel)
-        wino = ops.wino_tile(xv.C, cout, k, xv.H, xv.W)
-        first = not wino and ops.c4_bnfused_eligible(xv, cout, k)        # NHWC4 input: direct-operand first-layer kernel
-        wp = None if first else self.cache.get(conv.weight, 0, "wino%d" % wino if wino else self.compute_dtype)
+        bf16 = self.compute_dtype == "bf16"
+        wino = 0 if bf16 else ops.wino_tile(xv.C, cout, k, xv.H, xv.W)
+        first = not wino and not xv.bf16 and ops.c4_bnfused_eligible(xv, cout, k)   # NHWC4 input: direct-operand first-layer kernel
+        wp = self.cache.get(conv.weight, 0, "wino%d" % wino) if wino else None
         dev = xv.t.device
+        input_cast = False
+        if bf16 and not first and not xv.bf16:      # a float network input that is not first-layer shaped
+            xv = ops.cast_view(xv, torch.bfloat16)
+            input_cast = True
         cin_true = conv.weight.shape[1]
         # Winograd layers keep their transformed input for the weight gradient when a backward pass will follow
         keep = [] if (wino and self._record) else None
         rec = dict(kind="conv", ind=ind, x=xv, conv=conv, bn=bn, k=k, cout=cout, slope=slope, pool=pool, wino_v=keep,
-                   wino_tile=wino)
+                   wino_tile=wino, input_cast=input_cast)
         if bn is None and slope == 1.0 and pool == 0:
             z = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs)
             if wino:
@@ -143,8 +171,8 @@ class Network(object):
             elif first:
                 ops.conv3x3_c4(xv, conv.weight, cout, bias=conv.bias, out=z)
             else:
-                ops.conv2d(xv, wp, cout, k, bias=conv.bias, out=z, cin_true=cin_true)
-            rec.update(y=z, z=z, z_full=None)
+                self._conv_any(xv, conv, cout, k, conv.bias, z, False)
+            rec.update(x=xv, y=z, z=z, z_full=None)
             tape.append(rec)
             return z, None
         if wino:
@@ -152,10 +180,10 @@ class Network(object):
                                           bn_partial=bn is not None and training, keep_v=keep, tile=wino)
         elif first:
             y, partial = ops.conv3x3_c4(xv, conv.weight, cout, bias=None if bn is not None else conv.bias,
-                                        bn_partial=bn is not None and training)
+                                        bn_partial=bn is not None and training, out_dtype=self.act_dtype)
         else:
-            y, partial = ops.conv2d(xv, wp, cout, k, bias=None if bn is not None else conv.bias,
-                                    bn_partial=bn is not None and training, cin_true=cin_true)
+            y, partial = self._conv_any(xv, conv, cout, k, None if bn is not None else conv.bias, None,
+                                        bn is not None and training)
         scale = shift = mean = invstd = None
         if bn is not None:
             scale, shift, mean, invstd = ops.bn_finalize(partial, xv.pixels, bn, training)
@@ -166,7 +194,7 @@ class Network(object):
         OH, OW = (xv.H // 2, xv.W // 2) if pool == 1 else (xv.H, xv.W)
         z = ops.bn_act_pool(y, scale, shift, slope, pool,
                             out=self._dest(ind + 1 if pool else ind, xv.B, OH, OW, cout, dev, bufs))
-        rec.update(y=y, z=z, z_full=z_full, scale=scale, shift=shift, mean=mean, invstd=invstd,
+        rec.update(x=xv, y=y, z=z, z_full=z_full, scale=scale, shift=shift, mean=mean, invstd=invstd,
                    training=training)
         tape.append(rec)
         return z, z_full
@@ -242,6 +270,8 @@ class Network(object):
                 n_cls, o_ch = vec.shape[0], head.weight.shape[0]
                 w_op, b_eff, w_eff = ops.fold_reweight_head(head.weight.detach(), None if head.bias is None
                                                             else head.bias.detach(), vec.detach(), self.compute_dtype)
+                if self.compute_dtype == "bf16" and not (x.bf16 and x.C % 32 == 0):
+                    raise NotImplementedError("bf16 mode: the fused head needs a bf16 feature map with channels % 32 == 0")
                 y, _ = ops.conv2d(x, w_op, n_cls * o_ch, 1, bias=b_eff, nchw_out=True)
                 result = y.view(x.B * n_cls, o_ch, x.H, x.W)
                 tape.append(dict(kind="head", x=x, head=head, dyn=vec, w_eff=w_eff, n_cls=n_cls, o_ch=o_ch))

@@ -60,6 +60,16 @@ def like_view(v, C=None, ld=None, H=None, W=None):
                     dtype=v.t.dtype)
 
 
+def cast_view(v, dtype, out=None):
+    """A dense copy of `v` in another storage type (float32 <-> bfloat16, round-to-nearest-even).  Plumbing for the few
+    convolutions of non-standard cfgs whose channel counts the bf16 kernels do not take; the shipped cfgs never call it."""
+    src = v.t[:, v.c0:v.c0 + v.C]
+    if out is None:
+        return View(src.to(dtype).contiguous(), v.B, v.H, v.W, v.C)
+    out.t[:, out.c0:out.c0 + out.C].copy_(src)
+    return out
+
+
 def fill(t, value):
     check(lib().fsd_fill(t.data_ptr(), float(value), t.numel(), _stream()), "fsd_fill")
     return t

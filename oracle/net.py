@@ -173,6 +173,84 @@ def _walk(blocks, mods, x, dyn=None):
     return x
 
 
+# ---- bf16 storage mode (BASELINE configs[2] / [4]) -------------------------------------------------
+# What the product's bf16 mode is DEFINED to compute, restated with float tensors that are rounded to bfloat16 wherever
+# the product stores one: every conv output y, every activation z, the packed conv weights and the folded head weight;
+# products accumulate in fp32 and the BatchNorm statistics come from the UNROUNDED conv output.  First layers (<= 4 input
+# channels: the fp32 image / image+mask) keep fp32 operands.  Rounding is a straight-through estimator for autograd.
+
+def _q(t):
+    return t + (t.to(torch.bfloat16).float() - t).detach()
+
+
+def _conv_block_bf16(seq, x, training):
+    conv = seq[0]
+    bn = seq[1] if len(seq) > 1 and isinstance(seq[1], nn.BatchNorm2d) else None
+    act = seq[len(seq) - 1]
+    first = conv.in_channels <= 4
+    w = conv.weight if first else _q(conv.weight)
+    y32 = F.conv2d(x, w, conv.bias, conv.stride, conv.padding)
+    y16 = _q(y32)
+    if bn is not None:
+        if training:
+            mean = y32.mean(dim=(0, 2, 3))
+            var = y32.var(dim=(0, 2, 3), unbiased=False)
+            with torch.no_grad():
+                n = y32.numel() / y32.shape[1]
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                bn.running_mean.mul_(1 - mom).add_(mom * mean)
+                bn.running_var.mul_(1 - mom).add_(mom * var * (n / max(n - 1.0, 1.0)))
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        inv = torch.rsqrt(var + bn.eps)
+        t = (y16 - mean.view(1, -1, 1, 1)) * (inv * bn.weight).view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+    else:
+        t = y16
+    if isinstance(act, nn.LeakyReLU):
+        t = F.leaky_relu(t, 0.1)
+    elif isinstance(act, nn.ReLU):
+        t = F.relu(t)
+    if bn is None and act is conv:      # linear conv without BatchNorm: the stored value is the rounded conv output itself
+        return y16
+    return _q(t)
+
+
+def _walk_bf16(blocks, mods, x, dyn=None, training=True):
+    """_walk in bf16 storage mode.  The reweighting + 1x1 head pair is evaluated the way the product fuses it: the folded
+    weight W[o,c] * w[n,c] is rounded to bf16 once, the (B*N, C, H, W) tensor never exists, the head output is float."""
+    outs = {}
+    n_dyn = 0
+    layers = blocks[1:]
+    skip = -1
+    for idx, blk in enumerate(layers):
+        if idx <= skip:
+            continue
+        kind = blk["type"]
+        if kind == "route":
+            src = [int(v) if int(v) > 0 else int(v) + idx for v in blk["layers"].split(",")]
+            x = outs[src[0]] if len(src) == 1 else torch.cat([outs[s] for s in src], 1)
+        elif kind in ("region", "cost"):
+            continue
+        elif kind == "convolutional" and is_dynamic(blk):
+            head = mods[idx + 1][0]
+            vec = dyn[n_dyn]
+            n_dyn += 1
+            n_cls, o_ch, c = vec.shape[0], head.weight.shape[0], head.weight.shape[1]
+            w_eff = _q((head.weight.view(1, o_ch, c) * vec.view(n_cls, 1, c)).reshape(n_cls * o_ch, c, 1, 1))
+            bias = None if head.bias is None else head.bias.repeat(n_cls)
+            y = F.conv2d(x, w_eff, bias)
+            x = y.view(x.shape[0] * n_cls, o_ch, x.shape[2], x.shape[3])
+            skip = idx + 1
+            outs[idx + 1] = x
+            continue
+        elif kind == "convolutional":
+            x = _conv_block_bf16(mods[idx], x, training)
+        else:
+            x = mods[idx](x)          # max pools / reorg / global max commute with the rounding
+        outs[idx] = x
+    return x
+
+
 # ---- darknet weight stream (cfg.py:411-481, darknet_meta.py:355-479) -------------------------
 
 def _take(buf, pos, t):
@@ -242,6 +320,13 @@ class OracleDarknet(nn.Module):
 
     def forward(self, x, metax, mask):
         return self.detect_forward(x, self.meta_forward(metax, mask))
+
+    def forward_bf16(self, x, metax, mask):
+        """The product's bf16 storage mode (see _walk_bf16): -> (head output float, reweighting vectors)."""
+        if self.metain_type in (2, 3):
+            metax = torch.cat([metax, mask], dim=1)
+        dyn = _walk_bf16(self.learnet_blocks, self.learnet_models, metax, training=self.training)
+        return _walk_bf16(self.blocks, self.models, x, [dyn], training=self.training), dyn
 
     def load_weights(self, path):
         with open(path, "rb") as fh:

@@ -110,3 +110,169 @@ def test_wgrad_bf16_transpose_read_kernel_matches_fp64(dev, B, H, W, cin, cout, 
     ref = w.grad
     err = float((dw.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-5, err
+
+
+# ---- the HBM-bound kernels: one template, two storage types ------------------------------------------------------
+
+def _pair(dev, B, H, W, C, seed):
+    """The same bf16-representable NHWC tensor as a float view and as a bf16 view."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    t = _bf(torch.randn(B * H * W, C, generator=g)).to(dev)
+    return ops.View(t.clone(), B, H, W, C), ops.View(t.to(BF), B, H, W, C)
+
+
+@pytest.mark.parametrize("pool", [0, 1, 2])
+def test_bn_act_pool_forward_and_backward_twins(dev, pool):
+    from fewshot_detection_amd import ops
+    B, H, W, C = 3, 13, 13, 24
+    yf, yh = _pair(dev, B, H, W, C, 1)
+    g = torch.Generator().manual_seed(2)
+    scale, shift = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    mean, invstd = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    zf, zh = ops.bn_act_pool(yf, scale, shift, 0.1, pool), ops.bn_act_pool(yh, scale, shift, 0.1, pool)
+    assert zh.bf16 and torch.equal(zh.t.float(), _bf(zf.t.cpu()).to(dev))          # same float math, rounded once at the store
+    OH, OW = zf.H, zf.W
+    dzf, dzh = _pair(dev, B, OH, OW, C, 3)
+    dtf, pf = ops.bn_act_pool_bwd(dzf, None, yf, scale, shift, mean, invstd, 0.1, pool)
+    dth, ph = ops.bn_act_pool_bwd(dzh, None, yh, scale, shift, mean, invstd, 0.1, pool)
+    assert dth.bf16 and torch.equal(dth.t.float(), _bf(dtf.t.cpu()).to(dev))
+    assert torch.allclose(ph.sum(0), pf.sum(0), rtol=1e-5, atol=1e-4)              # partial sums from the float values
+    coef = (torch.rand(3, C, generator=g) + 0.5).to(dev)
+    df = ops.View(dtf.t.clone(), B, H, W, C)
+    dh = ops.View(_bf(dtf.t.cpu()).to(dev).to(BF), B, H, W, C)
+    ref_in = ops.View(dh.t.float(), B, H, W, C)
+    ops.bn_bwd_apply(ref_in, yf, coef, mean, invstd)
+    ops.bn_bwd_apply(dh, yh, coef, mean, invstd)
+    assert torch.equal(dh.t.float(), _bf(ref_in.t.cpu()).to(dev))
+    del df
+
+
+def test_layout_and_scatter_twins(dev):
+    from fewshot_detection_amd import ops
+    xf, xh = _pair(dev, 2, 8, 6, 16, 5)
+    assert torch.equal(ops.reorg(xh, 2).t.float(), ops.reorg(xf, 2).t)
+    assert torch.equal(ops.nhwc_to_nchw(xh), ops.nhwc_to_nchw(xf))
+    nchw = ops.nhwc_to_nchw(xf)
+    back = ops.nchw_to_nhwc(nchw, pad_to=64, dtype=BF)
+    assert back.bf16 and back.C == 64 and torch.equal(back.t[:, :16].float(), xf.t) and float(back.t[:, 16:].float().abs().max()) == 0
+    sf, sh = _pair(dev, 3, 6, 6, 8, 6)
+    vf, af = ops.global_maxpool(sf, True)
+    vh, ah = ops.global_maxpool(sh, True)
+    assert torch.equal(vf, vh) and torch.equal(af, ah)
+    gout = torch.randn(3, 8, device=dev)
+    assert torch.equal(ops.global_maxpool_bwd(gout, ah, sh).t.float(), _bf(ops.global_maxpool_bwd(gout, af, sf).t.cpu()).to(dev))
+    g1f, g1h = _pair(dev, 2, 4, 3, 64, 7)          # gradient of reorg(x, 2): (2, 4, 3, 64)
+    assert torch.equal(ops.reorg_bwd(g1h, xh, 2).t.float(), ops.reorg_bwd(g1f, xf, 2).t)
+    a_f, a_h = _pair(dev, 2, 5, 5, 12, 8)
+    b_f, b_h = _pair(dev, 2, 5, 5, 12, 9)
+    ops.add_inplace(a_f, b_f)
+    ops.add_inplace(a_h, b_h)
+    assert torch.equal(a_h.t.float(), _bf(a_f.t.cpu()).to(dev))
+    cs_f, cs_h = _pair(dev, 4, 13, 13, 30, 10)
+    assert torch.allclose(ops.colsum(cs_h, 30), ops.colsum(cs_f, 30), rtol=1e-6, atol=1e-5)
+
+
+# ---- the whole model ---------------------------------------------------------------------------------------------
+
+def _targets(rng, bs, cs):
+    tgt = np.zeros((bs, cs, 250), np.float64)
+    fill = np.zeros((bs, cs), np.int64)
+    for b in range(bs):
+        for _ in range(rng.randint(1, 4)):
+            n = rng.randint(0, cs)
+            w, h = rng.uniform(0.05, 0.5, 2)
+            cx = float(np.clip(rng.uniform(0.1, 0.9), w / 2, 0.999 - w / 2))
+            cy = float(np.clip(rng.uniform(0.1, 0.9), h / 2, 0.999 - h / 2))
+            t = fill[b, n]
+            tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+            fill[b, n] += 1
+    return torch.from_numpy(tgt)
+
+
+def test_full_architecture_bf16_mode_vs_oracle_emulation(dev, tmp_path):
+    """darknet_dynamic.cfg + reweighting_net.cfg (66.3 M parameters) in bf16 storage mode against the oracle's
+    restatement of that mode (oracle/net.py _walk_bf16: bf16-rounded conv outputs, activations and packed weights, fp32
+    accumulation, BatchNorm statistics from the unrounded conv output).  Agreement is at bf16 resolution: an accumulator
+    that sits on a rounding boundary may round the other way after a 1e-7 difference in summation order."""
+    from fewshot_detection_amd import cfgs
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from oracle.net import OracleDarknet
+    from oracle.region import region_loss_v2
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    torch.manual_seed(31)
+    ora = OracleDarknet(dyn_cfg, rw_cfg).train()
+    net = Darknet(dyn_cfg, rw_cfg)
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train().set_compute_dtype("bf16")
+    B, N, S = 4, 3, 416
+    g = torch.Generator().manual_seed(32)
+    x, metax = torch.rand(B, 3, S, S, generator=g), torch.rand(N, 3, S, S, generator=g)
+    mask = torch.zeros(N, 1, S, S)
+    mask[:, :, 100:300, 50:250] = 1
+    tgt = _targets(np.random.RandomState(33), B, N)
+    cfg.neg_ratio = "full"
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    region.seen = 0
+    out = net(x.to(dev), metax.to(dev), mask.to(dev))
+    assert net._det.fallback_convs == 0 and net._meta.fallback_convs == 0          # every layer on the bf16 kernels
+    loss = region(out, tgt)
+    loss.backward()
+    ref, dyn_ref = ora.forward_bf16(x, metax, mask)
+    r = region_loss_v2(ref, tgt, ora.region.anchors, seen=0)
+    r["loss"].backward()
+    o, rf = out.detach().cpu(), ref.detach()
+    rel = float((o - rf).norm() / rf.norm())
+    print("bf16 mode forward: relative L2 %.3e, max|diff| %.3e (max|out| %.2f); loss %.2f vs %.2f"
+          % (rel, float((o - rf).abs().max()), float(rf.abs().max()), float(loss.detach()), float(r["loss"].detach())))
+    assert out.shape == ref.shape and rel < 2e-2
+    assert abs(float(loss.detach()) - float(r["loss"].detach())) < 2e-2 * abs(float(r["loss"].detach()))
+    named, mine = dict(ora.named_parameters()), dict(net.named_parameters())
+    cos = []
+    for name, p in mine.items():
+        gm, gr = p.grad.cpu().double().flatten(), named[name].grad.double().flatten()
+        cos.append((float(torch.dot(gm, gr) / (gm.norm() * gr.norm() + 1e-30)), name))
+    cos.sort()
+    print("bf16 mode gradients: worst cosines", cos[:4], "median %.4f" % cos[len(cos) // 2][0])
+    assert cos[0][0] > 0.9 and cos[len(cos) // 2][0] > 0.99
+    # and against the fp32 path of the same model: close at bf16 resolution end to end
+    net32 = Darknet(dyn_cfg, rw_cfg)
+    net32.load_state_dict(ora.state_dict())       # (running statistics moved during the forwards above; train mode ignores them)
+    net32 = net32.to(dev).train()
+    with torch.no_grad():
+        o32 = net32(x.to(dev), metax.to(dev), mask.to(dev)).cpu()
+    assert float((o - o32).norm() / o32.norm()) < 5e-2
+
+
+def test_bf16_mode_trains_on_the_reduced_width_net(dev):
+    """mini_dynamic / mini_reweight (4 ... 64 channels): channel counts below the bf16 kernels' granularity go through the
+    documented fp32-kernel fallback on bf16-valued operands; the step still follows the fp32 model."""
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    torch.manual_seed(22)
+    cfgs_ = (os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+    a = Darknet(*cfgs_)
+    b = Darknet(*cfgs_)
+    b.load_state_dict(a.state_dict())
+    a, b = a.to(dev).train(), b.to(dev).train().set_compute_dtype("bf16")
+    x, metax = torch.rand(2, 3, 96, 96, device=dev), torch.rand(3, 3, 96, 96, device=dev)
+    mask = (torch.rand(3, 1, 96, 96, device=dev) > 0.5).float()
+    tgt = torch.zeros(2, 3, 250, dtype=torch.float64)
+    tgt[0, 1, :5] = torch.tensor([1, 0.5, 0.5, 0.4, 0.3])
+    tgt[1, 2, :5] = torch.tensor([2, 0.3, 0.6, 0.2, 0.5])
+    cfg.neg_ratio = "full"
+    losses, grads = [], []
+    for net in (a, b):
+        region = net.models[len(net.models) - 1]
+        region.verbose = False
+        loss = region(net(x, metax, mask), tgt)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
+    assert b._det.fallback_convs > 0
+    assert abs(losses[0] - losses[1]) < 0.05 * abs(losses[0])
+    cos = float(torch.dot(grads[0], grads[1]) / (grads[0].norm() * grads[1].norm()))
+    assert cos > 0.9, cos

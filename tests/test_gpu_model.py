@@ -93,93 +93,6 @@ def test_mini_detector_vs_oracle_odd_sizes(dev, S, Sm, B, N):
     assert float((out.cpu() - ref).abs().max()) < TOL
 
 
-def _bf16_oracle(ora):
-    """Oracle twin for the bf16 compute mode: every convolution sees bf16-ROUNDED inputs and weights and
-    accumulates in fp32 (what 'bf16 in, fp32 accumulate' means); everything else stays fp32."""
-    import torch.nn.functional as F
-
-    def hook(mod, args):
-        return (args[0].bfloat16().float(),)
-
-    for m in ora.modules():
-        if isinstance(m, torch.nn.Conv2d):
-            m.register_forward_pre_hook(hook)
-            m.weight.data = m.weight.data.bfloat16().float()
-    return ora
-
-
-def test_bf16_mode_matches_bf16_rounded_oracle(dev):
-    """BASELINE C3/C5 numerics on the reduced-width detector: HIP bf16 mode vs an oracle whose convs round their
-    operands to bf16.  The fused head rounds W*w (the folded weight) instead of W and w*x separately, so the
-    comparison feeds the oracle the same folded operand."""
-    from fewshot_detection_amd.darknet_meta import Darknet
-    from oracle.net import OracleDarknet
-    torch.manual_seed(21)
-    cfgs = (os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
-    ora = OracleDarknet(*cfgs)
-    for m in ora.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.weight.data.uniform_(0.5, 1.5)
-            m.bias.data.uniform_(-0.2, 0.2)
-    net = Darknet(*cfgs)
-    net.load_state_dict(ora.state_dict())
-    net = net.to(dev).train().set_compute_dtype("bf16")
-    B, N, S = 3, 4, 128
-    x, metax = torch.rand(B, 3, S, S), torch.rand(N, 3, S, S)
-    mask = (torch.rand(N, 1, S, S) > 0.5).float()
-    with torch.no_grad():
-        dyn = net.meta_forward(metax.to(dev), mask.to(dev))
-        feat_out = net.detect_forward(x.to(dev), dyn)
-    ora = _bf16_oracle(ora).train()
-    with torch.no_grad():
-        dyn_ref = ora.meta_forward(metax, mask)[0]
-        # model level: an activation that sits on a bf16 rounding boundary may round the other way after a
-        # 1e-7 upstream difference, so agreement is at bf16 resolution (2^-8), not fp32 (kernel-level test is 1e-4)
-        assert float((dyn[0].cpu() - dyn_ref).abs().max()) < 2e-2 * float(dyn_ref.abs().max())
-        # detector up to the dynamic conv, then the folded head exactly as the fused kernel defines it
-        blocks, mods = ora.blocks, ora.models
-        from oracle.net import _walk
-        cut = [i for i, b in enumerate(blocks[1:]) if b["type"] == "convolutional" and "dynamic" in b][0]
-        feats = _walk(blocks[:cut + 1], mods, x)                       # (B, C, G, G) before reweighting
-        head = mods[cut + 1][0]
-        w_eff = (head.weight.data.view(1, -1, feats.shape[1]) * dyn_ref.view(N, 1, -1)).reshape(-1, feats.shape[1], 1, 1)
-        ref = torch.nn.functional.conv2d(feats.bfloat16().float(), w_eff.bfloat16().float(),
-                                         head.bias.data.repeat(N)).view(B * N, -1, feats.shape[2], feats.shape[3])
-    assert feat_out.shape == ref.shape
-    err = (feat_out.cpu() - ref).abs()
-    assert float(err.max()) < 3e-2 * float(ref.abs().max()), float(err.max())
-    assert float(err.mean()) < 3e-3 * float(ref.abs().max()), float(err.mean())
-
-
-def test_bf16_mode_trains(dev):
-    """bf16 forward + data gradients (weight gradients stay fp32): loss close to the fp32 path, gradients aligned."""
-    from fewshot_detection_amd.cfg import cfg
-    from fewshot_detection_amd.darknet_meta import Darknet
-    torch.manual_seed(22)
-    cfgs = (os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
-    a = Darknet(*cfgs)
-    b = Darknet(*cfgs)
-    b.load_state_dict(a.state_dict())
-    a, b = a.to(dev).train(), b.to(dev).train().set_compute_dtype("bf16")
-    x, metax = torch.rand(2, 3, 96, 96, device=dev), torch.rand(3, 3, 96, 96, device=dev)
-    mask = (torch.rand(3, 1, 96, 96, device=dev) > 0.5).float()
-    tgt = torch.zeros(2, 3, 250, dtype=torch.float64)
-    tgt[0, 1, :5] = torch.tensor([1, 0.5, 0.5, 0.4, 0.3])
-    tgt[1, 2, :5] = torch.tensor([2, 0.3, 0.6, 0.2, 0.5])
-    cfg.neg_ratio = "full"
-    losses, grads = [], []
-    for net in (a, b):
-        region = net.models[len(net.models) - 1]
-        region.verbose = False
-        loss = region(net(x, metax, mask), tgt)
-        loss.backward()
-        losses.append(float(loss.detach()))
-        grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
-    assert abs(losses[0] - losses[1]) < 0.05 * abs(losses[0])
-    cos = float(torch.dot(grads[0], grads[1]) / (grads[0].norm() * grads[1].norm()))
-    assert cos > 0.9, cos          # bf16 operand noise on a tiny random net; fp32 weight gradients keep it aligned
-
-
 def test_load_weights_after_a_forward_invalidates_packed_weights(dev, tmp_path):
     """eval.py:118-122 pushes several checkpoints through ONE model.  The packed / Winograd weight
     copies the engine caches must not survive load_weights (its `.data.copy_` leaves torch's version counter alone)."""

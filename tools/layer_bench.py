@@ -54,6 +54,8 @@ def main():
         ops.WINOGRAD4 = False
     if os.environ.get("FSD_WINO4_MIN_CH"):
         ops.WINO4_MIN_CH = int(os.environ["FSD_WINO4_MIN_CH"])
+    if os.environ.get("FSD_LB_DTYPE") == "bf16":
+        return main_bf16(what, dev)
     for B, H, W, cin, cout, k in SHAPES:
         x = ops.nchw_to_nhwc(torch.randn(B, cin, H, W, device=dev))
         dy = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, device=dev))
@@ -77,6 +79,29 @@ def main():
             line += "  wgrad %7.3f ms %6.1f TF" % (ms, flops / ms / 1e9)
             _, cl = timed_classes(lambda: ops.conv2d_wgrad(dy, cout, x, cin, k))
             line += " (gemm %.3f xform %.3f)" % (cl.get("gemm_wgrad", 0), cl.get("wino_transform", 0))
+        print(line, flush=True)
+
+
+def main_bf16(what, dev):
+    """bf16 storage mode: DMA-staged bf16 MFMA forward / data-gradient kernel and the transpose-read weight gradient."""
+    for B, H, W, cin, cout, k in SHAPES + [(SHAPES[0][0], 13, 13, 1024, 450, 1), (SHAPES[0][0], 26, 26, 512, 256, 1)]:
+        x = ops.View(torch.randn(B * H * W, cin, device=dev).to(torch.bfloat16), B, H, W, cin)
+        dy = ops.View(torch.randn(B * H * W, (cout + 7) // 8 * 8, device=dev).to(torch.bfloat16), B, H, W, (cout + 7) // 8 * 8)
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        flops = 2.0 * k * k * cin * cout * B * H * W
+        line = "%3dx%3d %4d->%4d k%d:" % (H, W, cin, cout, k)
+        if what in ("fwd", "all"):
+            wp = ops.pack_weight(w, 0, "bf16")
+            ms = timed(lambda: ops.conv2d(x, wp, cout, k, bn_partial=True))
+            line += "  fwd %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
+            if cout % 32 == 0:
+                wp1 = ops.pack_weight(w, 1, "bf16")
+                dyc = ops.View(dy.t, B, H, W, cout)
+                ms = timed(lambda: ops.conv2d(dyc, wp1, cin, k))
+                line += "  dgrad %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
+        if what in ("wgrad", "all"):
+            ms = timed(lambda: ops.conv2d_wgrad(dy, dy.C, x, cin, k))
+            line += "  wgrad %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
         print(line, flush=True)
 
 
