@@ -283,6 +283,16 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// 128x64 tiles (4 x 1 waves) for layers with <= 64 output channels, 128x128 otherwise.  Measured on MI355X
+// (tools/layer_bench.py, B = 64): forcing 128x64 on the wide layers to fill the last round of workgroups better (13x13
+// maps: 680 tiles of 128x128 on 512 resident slots) LOSES 8-12 % -- the lower operand reuse costs more than the
+// quantisation; a 3- or 4-deep DMA ring with counted vmcnt at 1 workgroup per CU loses 15-25 % against two stages at 2
+// workgroups per CU (occupancy hides the DMA latency better than depth).
+inline bool narrow_tile(long long pixels, int cout) {
+  (void)pixels;
+  return cout <= 64;
+}
+
 }  // namespace
 
 extern "C" int fsd_conv_row_tiles_h(long long pixels) { return (int)((pixels + 127) / 128); }
@@ -311,8 +321,8 @@ extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* 
   a.cpt = cin / bk;
   a.m_tiles = (int)((pixels + 127) / 128);
   const bool nchw = out_nchw_f32 != 0;
-  if (cout <= 64 && !nchw) {
-    a.n_tiles = 1;
+  if (!nchw && narrow_tile(pixels, cout)) {
+    a.n_tiles = (cout + 63) / 64;
     return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);
   }
   a.n_tiles = (cout + 127) / 128;
@@ -510,8 +520,10 @@ __global__ __launch_bounds__(256) void wgrad_h_reduce_kernel(const float* __rest
 }
 
 inline int wgrad_h_splits(long long pixels, int tiles) {
-  int s = (2048 + tiles - 1) / tiles;                 // ~8 resident workgroups per CU
-  const long long max_s = (pixels + 511) / 512;       // at least 16 chunks per split
+  static const char* env = getenv("FSD_WGRAD_H_WGS");  // tuning aid: target number of workgroups
+  const int target = env ? atoi(env) : 1024;
+  int s = (target + tiles - 1) / tiles;               // ~4 resident workgroups per CU; every split is a workspace slice to fold
+  const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
   if (s > max_s) s = (int)max_s;
   return s < 1 ? 1 : s > 1024 ? 1024 : s;
 }
