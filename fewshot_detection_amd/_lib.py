@@ -46,8 +46,6 @@ PROTOTYPES = {
     "fsd_wino_grad_transforms": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_packed_weight_elems_bf16": (_sz, [_i, _i, _i]),
     "fsd_pack_conv_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "fsd_conv_row_tiles_bf16": (_i, [_ll]),
-    "fsd_conv2d_fwd_bf16": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_bn_finalize_workspace_bytes": (_sz, [_i]),
     "fsd_bn_finalize": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
     "fsd_bn_act_pool_fwd": (_i, [_p, _ll, _p, _p, _f, _i, _p, _ll, _i, _i, _i, _i, _p]),
@@ -60,7 +58,6 @@ PROTOTYPES = {
     "fsd_fold_reweight_head": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "fsd_conv2d_wgrad": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
-    "fsd_conv2d_wgrad_bf16": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_act_bwd_rows": (_i, [_ll]),
     "fsd_bn_act_pool_bwd_rows": (_i, [_i, _i, _i, _i]),
     "fsd_reduce_workspace_bytes": (_sz, [_i]),

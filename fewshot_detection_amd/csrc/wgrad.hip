@@ -37,22 +37,19 @@ struct WgradArgs {
   long long dy_bs, x_bs, ws_bs;   // batched (gridDim.z > 1, Winograd weight gradient): strides between batches
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 // TILE x TILE outputs per workgroup (2x2 waves), STAGES LDS buffers.
-//   BF16 = false: exact fp32 MFMA (32x32x2), LDS tiles hold floats.            TILE 64, 1 stage (17 KB, 8 WGs/CU)
-//   BF16 = true : operands rounded to bf16 (RNE) on the LDS store, 32x32x16 MFMA with fp32 accumulation
-//                 (BASELINE C3/C5); fragments need 8 consecutive PIXELS per lane, which are LDS rows here, so
-//                 they are gathered with 16-bit LDS reads (pairs land in the two halves of one VGPR).
+//   Exact fp32 MFMA (32x32x2), LDS tiles hold floats; default TILE 64, 1 stage (17 KB, 8 WGs/CU).  BF16 must be false:
+//   the bf16 storage mode has its own weight-gradient kernel (conv_bf16v2.hip, LDS transpose reads).
 //   DMA = true  : (fp32, PLAIN, 2 stages) the [row][channel] tiles go global -> LDS with global_load_lds: no staging
 //                 registers, no ds_write, no address VALU in the loop; LDS rows are unpadded (the DMA writes 1 KB per
 //                 wave instruction linearly), which is conflict-free for the 32-lane b32 fragment reads.  Needs full
 //                 tiles and full 32-row chunks: the launcher sends column remainders / the last < 32 rows elsewhere.
 template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
-  static_assert(!DMA || (!BF16 && PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
-  typedef typename std::conditional<BF16, unsigned short, float>::type lds_t;
-  constexpr int LDT = DMA ? TILE : TILE + (BF16 ? 8 : 4);   // LDS row stride in elements (keeps 16-byte alignment)
+  static_assert(!BF16, "fp32 kernel");
+  static_assert(!DMA || (PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
+  typedef float lds_t;
+  constexpr int LDT = DMA ? TILE : TILE + 4;   // LDS row stride in elements (keeps 16-byte alignment)
   constexpr int CQ = TILE / 4;                     // float4 column groups per tile row
   constexpr int RPP = kThreads / CQ;               // pixel rows staged per pass
   constexpr int PASSES = kBK / RPP;
@@ -130,17 +127,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
     }
   };
   auto put = [&](lds_t* dst, f32x4 v, bool ok) {
-    if constexpr (BF16) {
-      uint2 w = make_uint2(0u, 0u);
-      if (ok) {
-        const __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
-        w.x = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-        w.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
-      }
-      *reinterpret_cast<uint2*>(dst) = w;
-    } else {
-      *reinterpret_cast<f32x4*>(dst) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    *reinterpret_cast<f32x4*>(dst) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto sstore = [&](lds_t* st) {
 #pragma unroll
@@ -159,36 +146,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](const lds_t* st) {
-    if constexpr (BF16) {
-      // lane (m = lane & 31, h = lane >> 5) supplies pixels s*16 + h*8 .. +7 of column m
-      const unsigned short* sa = st + (lane >> 5) * 8 * LDT + wm * (T * 32) + (lane & 31);
-      const unsigned short* sb = st + kBK * LDT + (lane >> 5) * 8 * LDT + wn * (T * 32) + (lane & 31);
-#pragma unroll
-      for (int s16 = 0; s16 < kBK / 16; ++s16) {
-        bf16x8 af[T], bf[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-          unsigned short v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sa[(s16 * 16 + e) * LDT + i * 32];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) af[i][e] = __builtin_bit_cast(__bf16, v[e]);
-        }
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-          unsigned short v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sb[(s16 * 16 + e) * LDT + j * 32];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bf[j][e] = __builtin_bit_cast(__bf16, v[e]);
-        }
-#pragma unroll
-        for (int i = 0; i < T; ++i)
-#pragma unroll
-          for (int j = 0; j < T; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
+    {
       const float* sa = st + (lane >> 5) * 4 * LDT + wm * (T * 32) + (lane & 31);
       const float* sb = st + kBK * LDT + (lane >> 5) * 4 * LDT + wn * (T * 32) + (lane & 31);
       // fragments one k8-step ahead of the MFMAs (statically indexed double buffer)
@@ -482,10 +440,9 @@ inline int tile_of(int bf16) { return (bf16 || f32_variant() == 1 || f32_variant
 
 int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
   // issued MFMA work: dW[Cout][ncols] reduced over M pixel rows, per batch (grid.z)
-  fsd_prof::Scope prof(bf16 ? fsd_prof::kGemmBf16 : fsd_prof::kGemmWgrad, 2.0 * a.M * (double)a.Cout * a.ncols * grid.z, stream);
+  fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)a.Cout * a.ncols * grid.z, stream);
   if (bf16) {
-    const size_t lds = 2 * (size_t)(2 * kBK * (128 + 8)) * sizeof(unsigned short);
-    hipLaunchKernelGGL((wgrad_kernel<128, 2, true>), grid, dim3(kThreads), lds, stream, a);
+    return FSD_ERR_UNSUPPORTED;       // bf16 operands: fsd_conv2d_wgrad_h
   } else if (f32_variant() == 1) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -697,26 +654,14 @@ extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int wi
   // sized for the finer (fp32, 64x64) tiling, which needs the larger number of splits; valid for both modes
   const long long pixels = (long long)batch * height * width;
   const int ncols = ksize * ksize * round_up(cin, 4);
-  size_t best = 0;
-  for (int bf16 = 0; bf16 < 2; ++bf16) {
-    const int tile = tile_of(bf16);
-    const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
-    const size_t need = (size_t)pick_splits(pixels, tiles) * cout * ncols * sizeof(float);
-    if (need > best) best = need;
-  }
-  return best;
+  const int tile = tile_of(0);
+  const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
+  return (size_t)pick_splits(pixels, tiles) * cout * ncols * sizeof(float);
 }
 
 extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
                                 void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                 int cout, int ksize, hipStream_t stream) {
   return wgrad_impl(dy, dy_ld, x, x_ld, dw_oihw, workspace, workspace_bytes, batch, height, width, cin, cout, ksize, 0,
-                    stream);
-}
-
-extern "C" int fsd_conv2d_wgrad_bf16(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
-                                     void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
-                                     int cout, int ksize, hipStream_t stream) {
-  return wgrad_impl(dy, dy_ld, x, x_ld, dw_oihw, workspace, workspace_bytes, batch, height, width, cin, cout, ksize, 1,
                     stream);
 }

@@ -228,18 +228,16 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     else:
         y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev)
         y_ptr, y_ld = y.ptr, y.ld
-    bf16 = w_packed.dtype == torch.bfloat16          # the packed operand carries the compute mode
+    if w_packed.dtype != torch.float32:
+        raise ValueError("fp32 activations need fp32-packed weights (bf16 weights belong to bf16 activations)")
     if bn_partial:
-        tiles = (lib().fsd_conv_row_tiles_bf16(xv.pixels) if bf16
-                 else lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize))
+        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize)
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib().fsd_conv2d_fwd_bf16 if bf16 else lib().fsd_conv2d_fwd
-    check(fn(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
-             xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()),
-          "fsd_conv2d_fwd_bf16" if bf16 else "fsd_conv2d_fwd")
+    check(lib().fsd_conv2d_fwd(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+                               xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()), "fsd_conv2d_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
@@ -437,9 +435,10 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
     ws_bytes = L.fsd_conv2d_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, ksize)
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
     dw = grad_dst(param, (cout, cin, ksize, ksize), dev)
-    fn = L.fsd_conv2d_wgrad_bf16 if dtype == "bf16" else L.fsd_conv2d_wgrad
-    check(fn(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
-             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
+    if dtype != "f32":
+        raise ValueError("fp32 views take the fp32 weight-gradient kernel (bf16 mode: bf16 views)")
+    check(L.fsd_conv2d_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
+                             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
     return dw
 
 

@@ -186,18 +186,12 @@ int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const float* y, l
                              const float* mean, const float* invstd, float* v_out, float* wt_out, int batch, int height,
                              int width, int channels, int tile, hipStream_t stream);
 
-/* bf16 compute mode (BASELINE configs C3 / C5: bf16 operands, fp32 accumulate).  Same contract as
- * fsd_conv2d_fwd: activations are fp32 NHWC in HBM and are rounded to bf16 (RNE) while being staged;
- * weights are packed once as bf16 ([round_up(rows,128)][round_up(taps*round_up(red,4), 64)] bf16);
- * outputs, bias and the BatchNorm partial sums are fp32.  bn_partial has fsd_conv_row_tiles_bf16 rows. */
+/* Packed bf16 conv weights of the bf16 storage mode (operand of fsd_conv2d_fwd_h): [round_up(rows,128)]
+ * [round_up(taps*round_up(red,4), 64)] bfloat16, K-major, round-to-nearest-even; mode 0 = forward (rows = Cout, red = Cin),
+ * mode 1 = data gradient (rows = Cin, red = Cout, taps rotated 180 degrees). */
 size_t fsd_packed_weight_elems_bf16(int rows, int red, int ksize);
 int fsd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed_bf16, int cout, int cin, int ksize, int mode,
                               hipStream_t stream);
-int fsd_conv_row_tiles_bf16(long long pixels);
-int fsd_conv2d_fwd_bf16(const float* x, long long x_ld, const void* w_packed_bf16, const float* bias, float* y,
-                        long long y_ld, float* bn_partial, int batch, int height, int width, int cin,
-                        int cout, int ksize, int out_nchw, hipStream_t stream);
-
 /* ---- batch norm (training statistics) + activation + pooling ------------------------------ */
 /* Reduce the per-tile partials, produce the per-channel affine (scale = gamma*invstd,
  * shift = beta - mean*scale), save mean / invstd for the backward pass and update the running
@@ -255,11 +249,6 @@ size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int ci
 int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
                      void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                      int cout, int ksize, hipStream_t stream);
-/* bf16 compute mode of the same gradient: dy and x are rounded to bf16 (RNE) on their way into LDS,
- * products accumulate in fp32; same workspace query. */
-int fsd_conv2d_wgrad_bf16(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
-                          void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
-                          int cout, int ksize, hipStream_t stream);
 /* (The data gradient is fsd_conv2d_fwd[_bf16] on dy with weights packed in mode 1.) */
 
 /* Gradient through pool(act(y*scale+shift)): dt = d loss / d (y*scale+shift), dense (pixels, C),

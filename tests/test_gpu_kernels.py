@@ -248,38 +248,6 @@ def test_region_decode_vs_reference_golden(dev, only_obj):
         assert sum(len(bl) for bl in got) == n_ref
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout,k,bias,nchw", [
-    (2, 13, 13, 64, 128, 3, False, False),      # Cin % 64 == 0: per-tap fast path
-    (2, 20, 24, 3, 32, 3, False, False),        # first layer: Cin 3 -> 4, K = 36, one partial chunk
-    (2, 13, 13, 256, 30, 1, True, False),       # 1x1 + bias, Cout tail
-    (1, 7, 9, 1280, 200, 3, False, False),      # concat-width input
-    (1, 9, 9, 40, 64, 3, False, False),         # generic path crossing taps inside a chunk
-    (3, 5, 5, 1024, 90, 1, True, True),         # fused-head shape, NCHW store
-])
-def test_conv_bf16_matches_bf16_rounded_reference(dev, B, H, W, cin, cout, k, bias, nchw):
-    """bf16 compute mode = conv of bf16-ROUNDED operands with fp32 accumulation (BASELINE C3/C5 numerics)."""
-    from fewshot_detection_amd import ops
-    g = torch.Generator().manual_seed(B * 100 + cin)
-    x = torch.randn(B, cin, H, W, generator=g)
-    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    b = torch.randn(cout, generator=g) if bias else None
-    xr, wr = x.bfloat16().double(), w.bfloat16().double()
-    ref = F.conv2d(xr, wr, None if b is None else b.double(), 1, (k - 1) // 2).float()
-    xv = ops.nchw_to_nhwc(x.to(dev))
-    wp = ops.pack_weight(w.to(dev), 0, "bf16")
-    y, part = ops.conv2d(xv, wp, cout, k, bias=None if b is None else b.to(dev), bn_partial=not bias and not nchw,
-                         nchw_out=nchw)
-    out = y.cpu() if nchw else ops.nhwc_to_nchw(y).cpu()
-    assert torch.allclose(out, ref, rtol=1e-4, atol=2e-5), float((out - ref).abs().max())
-    fp32 = F.conv2d(x, w, b, 1, (k - 1) // 2)
-    assert float((out - fp32).abs().max()) < 0.1               # and it is a bf16-accurate conv of the unrounded data
-    if part is not None:
-        p = part.double().sum(0).cpu()
-        flat = ref.double().permute(1, 0, 2, 3).reshape(cout, -1)
-        assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-3)
-        assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
-
-
 @pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("B,H,W,cin,cout,bias", [
     (2, 13, 13, 64, 128, False),     # odd size: last tile row/column partly outside the image
