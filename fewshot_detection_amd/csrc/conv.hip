@@ -383,13 +383,14 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
   return r;
 }
 
-// Tile choice of the batched plain GEMMs (Winograd positions).  64x64 single-stage tiles win up to K = 512; for the
-// K >= 1024 GEMMs the 128x128 tile with DMA staging (global_load_lds, two stages) is ~3 % faster (measured,
-// tools/layer_bench.py).  FSD_WINO_TILE = a|c|d|e overrides.  'a' 64x64, 'c' 128x128 register-staged, 'd' 128x128 DMA,
-// 'e' 128x64.
+// Tile choice of the batched plain GEMMs (Winograd positions).  64x64 single-stage tiles win up to K = 256; from
+// K = 512 with >= 512 output channels (the 13x13 layers) the 128x128 tile with DMA staging (global_load_lds, two
+// stages) is faster: -10 % at 512 -> 1024, -8 % at 1024 / 1280 -> 1024; at 256 -> 512 @ 26x26 it loses 4 % (measured
+// round 2, tools/layer_bench.py).  FSD_WINO_TILE = a|c|d|e overrides.  'a' 64x64, 'c' 128x128 register-staged,
+// 'd' 128x128 DMA, 'e' 128x64.
 inline char batched_pick(int cin, int cout) {
   static const char* env = getenv("FSD_WINO_TILE");
-  return env ? env[0] : (cin >= 1024 && cout % 128 == 0 ? 'd' : 'a');
+  return env ? env[0] : (cin >= 512 && cout >= 512 && cout % 128 == 0 ? 'd' : 'a');
 }
 
 }  // namespace

@@ -172,12 +172,10 @@ def draw_augmentation(ow, oh, jitter=0.2, hue=0.1, saturation=1.5, exposure=1.5,
 def _nearest_table(box_w, out_w):
     """Pillow's NEAREST resize of a box_w-wide image to out_w columns: source column per output column.  The running
     sum `xo += scale` in double (Geometry.c ImagingScaleAffine) decides exact ties, so it is restated as a loop."""
-    tab = np.empty(out_w, np.int64)
     scale = float(box_w) / float(out_w)
-    xo = scale * 0.5
-    for x in range(out_w):
-        tab[x] = int(xo)
-        xo += scale
+    steps = np.full(out_w, scale, np.float64)
+    steps[0] = scale * 0.5
+    tab = np.cumsum(steps).astype(np.int64)      # cumsum adds left to right: the same doubles as the C loop `xo += scale`
     tab[tab >= box_w] = -1
     return tab
 
@@ -202,23 +200,14 @@ def index_tables(p, ow, oh, shape):
     return np.ascontiguousarray(xs, np.int32), np.ascontiguousarray(ys, np.int32)
 
 
-def _clip8(v):
-    v = int(v)                     # the reference's Pillow converted point() tables with C (int): truncation
-    return 0 if v < 0 else 255 if v > 255 else v
-
-
 def distort_luts(hue, sat, val):
     """(3, 256) uint8: the tables image.distort_image applies to the H, S, V bands (image.py:19-34)."""
-    def change_hue(x):
-        x += hue * 255
-        if x > 255:
-            x -= 255
-        if x < 0:
-            x += 255
-        return x
-    return np.array([[_clip8(change_hue(i)) for i in range(256)],
-                     [_clip8(i * sat) for i in range(256)],
-                     [_clip8(i * val) for i in range(256)]], np.uint8)
+    i = np.arange(256, dtype=np.float64)
+    h = i + hue * 255
+    h = np.where(h > 255, h - 255, h)
+    h = np.where(h < 0, h + 255, h)
+    # C (int) truncation, then clip to 0..255 -- the reference's Pillow converted point() tables that way
+    return np.clip(np.trunc(np.stack([h, i * sat, i * val])), 0, 255).astype(np.uint8)
 
 
 class DeviceAugmenter(object):

@@ -123,12 +123,13 @@ def nms(boxes, nms_thresh):
     batch = getattr(boxes, "_batch", None)
     if batch is None or boxes._n != len(boxes) or batch.boxes_dev.shape[1] > NMS_MAX_DEVICE_ROW:
         return _nms_host(boxes, nms_thresh)
+    import numpy as np
     kept = batch.kept_positions(nms_thresh)[boxes._row]
-    alive = set(int(p) for p in kept)
-    for pos, b in enumerate(boxes):
-        if pos not in alive:
-            b[4] = 0                        # the reference's in-place side effect on suppressed boxes
-    return [boxes[int(p)] for p in kept]
+    dead = np.ones(len(boxes), bool)
+    dead[kept] = False
+    for pos in np.flatnonzero(dead).tolist():
+        boxes[pos][4] = 0                   # the reference's in-place side effect on suppressed boxes
+    return [boxes[p] for p in kept.tolist()]
 
 
 def convert2cpu(gpu_matrix):
@@ -185,8 +186,10 @@ def _decode(output, rows_per_image, conf_thresh, num_classes, anchors, num_ancho
         pos = np.empty(len(order), np.int64)
         pos[order] = np.arange(len(order))
         positions.append(pos)
-        row = BoxList([float(v[1]), float(v[2]), float(v[3]), float(v[4]), float(v[5]), float(v[6]), int(v[7])]
-                      for v in b[order])
+        vals = b[order, 1:8].astype(np.float64).tolist()      # float32 -> python float (exact), nested lists built in C
+        for v in vals:
+            v[6] = int(v[6])
+        row = BoxList(vals)
         row._row, row._n = r, len(order)
         all_boxes.append(row)
     batch = _DecodedBatch(boxes, counts, n, positions)
