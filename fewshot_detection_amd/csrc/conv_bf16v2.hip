@@ -367,16 +367,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   constexpr int STAGE = 32 * (BM + BN);           // elements per LDS stage
   extern __shared__ __attribute__((aligned(16))) u16 smem_w[];
 
+  // The N dimension is the packed (tap, ci) column space of dW, ncols = taps * Cin: a 128-wide tile is one tap's slice of
+  // a wide layer, or several whole taps of a narrow one (Cin = 32: four taps per tile, so dy is re-read 3x instead of 9x).
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tap = L % p.taps;
-  const int t2 = L / p.taps;
-  const int nt = t2 % p.n_tiles, mt = t2 / p.n_tiles;
+  const int nt = L % p.n_tiles, mt = L / p.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  const int ncols = p.taps * p.Cin;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-  const int ky = tap / p.ks, kx = tap - ky * p.ks;
-  const int dyo = ky - p.pad, dxo = kx - p.pad;
-  const int shift = dyo * p.W + dxo;
   const long long pix0 = (long long)blockIdx.y * p.pix_per_split;
   long long pix_end = pix0 + p.pix_per_split;
   if (pix_end > p.M) pix_end = p.M;
@@ -385,6 +383,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   // this lane's piece of an A row: channels m0 + a_piece*8 .. +7 (logical), rows a_row + ROWS_PER_PASS * pass
   const int a_row = wave * GA::RPI + lane / GA::LPR, a_pp = lane % GA::LPR;
   const int b_row = wave * GB::RPI + lane / GB::LPR, b_pp = lane % GB::LPR;
+  // the B piece of this lane is the same in every pass (the swizzle depends on row & 3 and passes advance by >= 16 rows):
+  // its tap and channel offset are lane constants
+  const int b_piece = b_pp ^ GB::swz(b_row);
+  const int b_col = n0 + b_piece * 8;                      // column of dW = tap * Cin + ci
+  const int b_tap = b_col / p.Cin, b_ci = b_col - b_tap * p.Cin;
+  const bool b_col_ok = b_col < ncols;
+  const int ky = b_tap / p.ks, kx = b_tap - ky * p.ks;
+  const int dyo = ky - p.pad, dxo = kx - p.pad;
+  const int shift = dyo * p.W + dxo;
   // image coordinates of the B rows of this thread (they advance by 32 pixels per chunk)
   int b_y[GB::PASSES], b_x[GB::PASSES];
   const float inv_w = 1.0f / (float)p.W;
@@ -413,11 +420,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
     for (int j = 0; j < GB::PASSES; ++j) {
       const int row = b_row + GB::ROWS_PER_PASS * j;
       if (GB::ROWS_PER_PASS * j + wave * GB::RPI < 32) {
-        const int piece = b_pp ^ GB::swz(row);
         const long long pix = base + row;
-        const bool ok = row < 32 && pix < pix_end && (n0 + piece * 8) < p.Cin &&
+        const bool ok = row < 32 && pix < pix_end && b_col_ok &&
                         (unsigned)(b_y[j] + dyo) < (unsigned)p.H && (unsigned)(b_x[j] + dxo) < (unsigned)p.W;
-        const u16* src = ok ? p.x + (pix + shift) * p.x_ld + n0 + piece * 8 : g_zero_page_h;
+        const u16* src = ok ? p.x + (pix + shift) * p.x_ld + b_ci : g_zero_page_h;
         dma16(src, st + 32 * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
       }
       // advance this row's image coordinates by one chunk (32 pixels); (x + 0.5) / W is never within 1/(2W) of an integer
@@ -487,19 +493,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
       cur ^= 1;
     }
   }
-  const int ncols = p.taps * p.Cin;
   float* out = p.ws + (long long)blockIdx.y * p.Cout * ncols;
   const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + c_lane;
-    if (n >= p.Cin) continue;
+    const int n = n0 + (wn * TN + j) * 32 + c_lane;          // column of dW = tap * Cin + ci
+    if (n >= ncols) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-        if (m < p.Cout) out[(long long)m * ncols + tap * p.Cin + n] = acc[i][j][r];
+        if (m < p.Cout) out[(long long)m * ncols + n] = acc[i][j][r];
       }
   }
 }
@@ -520,17 +525,28 @@ __global__ __launch_bounds__(256) void wgrad_h_reduce_kernel(const float* __rest
 }
 
 inline int wgrad_h_splits(long long pixels, int tiles) {
-  static const char* env = getenv("FSD_WGRAD_H_WGS");  // tuning aid: target number of workgroups
-  const int target = env ? atoi(env) : 1024;
-  int s = (target + tiles - 1) / tiles;               // ~4 resident workgroups per CU; every split is a workspace slice to fold
   const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
+  int s;
+  if (tiles >= 256) {
+    // many tiles: few splits, chosen so that the last round of the 512 resident workgroups (2 per CU) is well filled;
+    // every split is one more workspace slice for the fold kernel to read (+3 % per split, measured)
+    double best = 1e30;
+    s = 1;
+    for (int c = 1; c <= 8; ++c) {
+      const double wgs = (double)tiles * c, rounds = (double)((long long)((wgs + 511) / 512));
+      const double cost = rounds / (wgs / 512.0) * (1.0 + 0.03 * c);
+      if (cost < best - 1e-9) { best = cost; s = c; }
+    }
+  } else {
+    s = (1024 + tiles - 1) / tiles;                   // few tiles: ~4 workgroups per CU
+  }
   if (s > max_s) s = (int)max_s;
   return s < 1 ? 1 : s > 1024 ? 1024 : s;
 }
 
-inline void wgrad_h_tiles(int cout, int cin, int* bm, int* bn) {
+inline void wgrad_h_tiles(int cout, int ncols, int* bm, int* bn) {
   *bm = cout <= 64 ? 64 : 128;
-  *bn = cin <= 32 ? 32 : cin <= 64 ? 64 : 128;
+  *bn = ncols <= 32 ? 32 : ncols <= 64 ? 64 : 128;     // ncols = taps * Cin: the packed column space of dW
   if (*bn == 32) *bm = 128;                            // the 32-wide variant runs 4 x 1 waves of 32 rows
 }
 
@@ -538,8 +554,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
   const size_t lds = 2 * (size_t)32 * (BM + BN) * sizeof(u16);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
-  hipLaunchKernelGGL((wgrad_bf16_tr_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles * a.taps, splits), dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL((wgrad_bf16_tr_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -547,8 +562,9 @@ int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
 
 extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
   int bm, bn;
-  wgrad_h_tiles(cout, cin, &bm, &bn);
-  const int tiles = ((cout + bm - 1) / bm) * ((cin + bn - 1) / bn) * ksize * ksize;
+  const int ncols = ksize * ksize * cin;
+  wgrad_h_tiles(cout, ncols, &bm, &bn);
+  const int tiles = ((cout + bm - 1) / bm) * ((ncols + bn - 1) / bn);
   const int splits = wgrad_h_splits((long long)batch * height * width, tiles);
   return (size_t)splits * cout * ksize * ksize * cin * sizeof(float);
 }
@@ -570,10 +586,11 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   a.dy_ld = dy_ld; a.x_ld = x_ld; a.H = height; a.W = width; a.M = (int)pixels; a.Cout = cout; a.Cin = cin;
   a.ks = ksize; a.pad = (ksize - 1) / 2; a.taps = ksize * ksize;
   int bm, bn;
-  wgrad_h_tiles(cout, cin, &bm, &bn);
+  const int ncols = a.taps * cin;
+  wgrad_h_tiles(cout, ncols, &bm, &bn);
   a.m_tiles = (cout + bm - 1) / bm;
-  a.n_tiles = (cin + bn - 1) / bn;
-  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles * a.taps);
+  a.n_tiles = (ncols + bn - 1) / bn;
+  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles);
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), 32);
   int rc;
   if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);
