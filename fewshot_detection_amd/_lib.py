@@ -46,6 +46,7 @@ PROTOTYPES = {
     "fsd_wino_grad_transforms": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_packed_weight_elems_bf16": (_sz, [_i, _i, _i]),
     "fsd_pack_conv_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "fsd_pack_conv_weight_bf16_pair": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fsd_bn_finalize_workspace_bytes": (_sz, [_i]),
     "fsd_bn_finalize": (_i, [_p, _i, _ll, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
     "fsd_bn_act_pool_fwd": (_i, [_p, _ll, _p, _p, _f, _i, _p, _ll, _i, _i, _i, _i, _p]),

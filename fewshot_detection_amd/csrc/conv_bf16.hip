@@ -34,9 +34,109 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, unsigned sh
   out[idx] = __builtin_bit_cast(unsigned short, b);
 }
 
+// Both packings of one weight tensor in a single pass: a workgroup converts a [64 cout][64 cin][taps] block of the OIHW
+// tensor (contiguous runs of 64*taps floats, float4 loads) into a bf16 LDS tile and writes it twice -- forward operand
+// out0[co][tap][ci] and data-gradient operand out1[ci][taps-1-tap][co] -- as full 128-byte lines, 16 bytes per lane.
+// Padding elements of out0 / out1 are never written: the caller zero-fills the buffers once.
+template <int TAPS>
+__global__ __launch_bounds__(1024) void pack_weight_bf16_pair_kernel(const float* __restrict__ w, unsigned short* __restrict__ out0,
+                                                                    unsigned short* __restrict__ out1, int cout, int cin,
+                                                                    int red4_0, int kpad0, int red4_1, int kpad1) {
+  constexpr int T = 64, RUN = T * TAPS;
+  constexpr int ROW = RUN + 2;         // bf16 elements per cout row; (8 * ROW / 2) % 64 == 8: the mode-1 gathers spread over banks
+  extern __shared__ unsigned short tile[];
+  const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T;
+  const int n_ci = min(T, cin - ci0), n_co = min(T, cout - co0);
+  const bool full = n_ci == T && n_co == T && (cin & 3) == 0;
+  if (full) {
+#pragma unroll 9
+    for (int e = threadIdx.x; e < T * RUN / 4; e += 1024) {
+      const int co_l = e / (RUN / 4), r = (e - co_l * (RUN / 4)) * 4;       // r = ci_l * TAPS + tap
+      const float4 v = *reinterpret_cast<const float4*>(w + ((long long)(co0 + co_l) * cin + ci0) * TAPS + r);
+      unsigned short* d = tile + co_l * ROW + r;
+      d[0] = __builtin_bit_cast(unsigned short, (__bf16)v.x);
+      d[1] = __builtin_bit_cast(unsigned short, (__bf16)v.y);
+      d[2] = __builtin_bit_cast(unsigned short, (__bf16)v.z);
+      d[3] = __builtin_bit_cast(unsigned short, (__bf16)v.w);
+    }
+  } else {
+    for (int e = threadIdx.x; e < T * RUN; e += 1024) {
+      const int co_l = e / RUN, r = e - co_l * RUN;
+      float v = 0.f;
+      if (co_l < n_co && r < n_ci * TAPS) v = w[((long long)(co0 + co_l) * cin + ci0) * TAPS + r];
+      tile[co_l * ROW + r] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+  }
+  __syncthreads();
+  // mode 0: (co, tap) rows of 64 ci = 8 lanes x 8 ci
+#pragma unroll 5
+  for (int e = threadIdx.x; e < T * TAPS * 8; e += 1024) {
+    const int c8 = (e & 7) * 8, t2 = e >> 3;
+    const int tap = t2 % TAPS, co_l = t2 / TAPS;
+    if (co_l >= n_co || c8 >= n_ci) continue;
+    const unsigned short* sp = tile + co_l * ROW + c8 * TAPS + tap;
+    unsigned short* dp = out0 + (long long)(co0 + co_l) * kpad0 + tap * red4_0 + ci0 + c8;
+    if (c8 + 8 <= n_ci && ((red4_0 | kpad0) & 7) == 0) {
+      uint4 u;
+      u.x = sp[0] | ((unsigned)sp[TAPS] << 16);
+      u.y = sp[2 * TAPS] | ((unsigned)sp[3 * TAPS] << 16);
+      u.z = sp[4 * TAPS] | ((unsigned)sp[5 * TAPS] << 16);
+      u.w = sp[6 * TAPS] | ((unsigned)sp[7 * TAPS] << 16);
+      *reinterpret_cast<uint4*>(dp) = u;
+    } else {
+      for (int q = 0; q < 8 && c8 + q < n_ci; ++q) dp[q] = sp[q * TAPS];
+    }
+  }
+  // mode 1: (ci, tap) rows of 64 co = 8 lanes x 8 co
+#pragma unroll 5
+  for (int e = threadIdx.x; e < T * TAPS * 8; e += 1024) {
+    const int r = e % RUN, o8 = (e / RUN) * 8;                  // consecutive lanes: consecutive (ci, tap), same co group
+    const int ci_l = r / TAPS, tap = r - ci_l * TAPS;
+    if (ci_l >= n_ci || o8 >= n_co) continue;
+    const unsigned short* sp = tile + o8 * ROW + r;
+    unsigned short* dp = out1 + (long long)(ci0 + ci_l) * kpad1 + (TAPS - 1 - tap) * red4_1 + co0 + o8;
+    if (o8 + 8 <= n_co && ((red4_1 | kpad1) & 7) == 0) {
+      uint4 u;
+      u.x = sp[0] | ((unsigned)sp[ROW] << 16);
+      u.y = sp[2 * ROW] | ((unsigned)sp[3 * ROW] << 16);
+      u.z = sp[4 * ROW] | ((unsigned)sp[5 * ROW] << 16);
+      u.w = sp[6 * ROW] | ((unsigned)sp[7 * ROW] << 16);
+      *reinterpret_cast<uint4*>(dp) = u;
+    } else {
+      for (int q = 0; q < 8 && o8 + q < n_co; ++q) dp[q] = sp[q * ROW];
+    }
+  }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
+
+extern "C" int fsd_pack_conv_weight_bf16_pair(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin,
+                                              int ksize, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w_oihw || !w_fwd_bf16 || !w_dgrad_bf16 || cout < 1 || cin < 1 || (ksize != 1 && ksize != 3)) return FSD_ERR_ARG;
+  const int taps = ksize * ksize;
+  const int red4_0 = round_up(cin, 4), kpad0 = round_up(taps * red4_0, kBKh);
+  const int red4_1 = round_up(cout, 4), kpad1 = round_up(taps * red4_1, kBKh);
+  const dim3 grid((cin + 63) / 64, (cout + 63) / 64);
+  if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)64 * (64 * taps + 2) * sizeof(unsigned short);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weight_bf16_pair_kernel<9>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)64 * (64 * 9 + 2) * 2));
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  unsigned short* o0 = static_cast<unsigned short*>(w_fwd_bf16);
+  unsigned short* o1 = static_cast<unsigned short*>(w_dgrad_bf16);
+  if (taps == 9)
+    hipLaunchKernelGGL(pack_weight_bf16_pair_kernel<9>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
+  else
+    hipLaunchKernelGGL(pack_weight_bf16_pair_kernel<1>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
+  return (int)hipGetLastError();
+}
 
 extern "C" size_t fsd_packed_weight_elems_bf16(int rows, int red, int ksize) {
   return (size_t)round_up(rows, 128) * (size_t)round_up(ksize * ksize * round_up(red, 4), kBKh);

@@ -509,19 +509,69 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   }
 }
 
-// ws[split][cout][tap * cin + ci] -> dW[cout][cin][taps] (OIHW), fixed summation order
-__global__ __launch_bounds__(256) void wgrad_h_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
-                                                             int cout, int cin, int taps) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over (co, tap, ci): coalesced reads
-  const long long total = (long long)cout * taps * cin;
+// Folding the split-K workspace, fixed summation order throughout.
+// (1) many splits (the layers with few tiles): slices are first summed in groups of kFoldGroup by a 2-D grid -- a
+//     single pass would leave each thread with hundreds of dependent-latency loads and a handful of workgroups;
+// (2) ws[split][cout][tap * cin + ci] -> dW[cout][cin][taps] (OIHW): one workgroup per (cout, block of CB input channels)
+//     reads TAPS runs of CB floats per slice and writes ONE contiguous run of CB * TAPS floats (the tap-major ->
+//     tap-minor transposition goes through LDS instead of 4-byte stores at a 36-byte stride).
+constexpr int kFoldGroup = 16, kFoldDirect = 24;
+
+__global__ __launch_bounds__(256) void wgrad_h_partial_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits,
+                                                              long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int ci = (int)(idx % cin);
-  const long long t = idx / cin;
-  const int tap = (int)(t % taps);
-  const int co = (int)(t / taps);
+  const int k0 = blockIdx.y * kFoldGroup, k1 = min(splits, k0 + kFoldGroup);
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += ws[(long long)k * total + idx];
-  dw[((long long)co * cin + ci) * taps + tap] = s;
+  for (int k = k0; k < k1; ++k) s += ws[(long long)k * total + idx];
+  out[(long long)blockIdx.y * total + idx] = s;
+}
+
+template <int TAPS, int CB>
+__global__ __launch_bounds__(256) void wgrad_h_fold_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                                           int cout, int cin) {
+  __shared__ float stage[CB * TAPS];
+  const int cblocks = (cin + CB - 1) / CB;
+  const int co = blockIdx.x / cblocks, c0 = (blockIdx.x - co * cblocks) * CB;
+  const int nci = min(CB, cin - c0);
+  const long long total = (long long)cout * TAPS * cin;
+  const float* base = ws + (long long)co * TAPS * cin + c0;
+  for (int e = threadIdx.x; e < CB * TAPS; e += 256) {
+    const int tap = e / CB, c = e - tap * CB;
+    if (c < nci) {
+      const float* p = base + (long long)tap * cin + c;
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += p[(long long)k * total];
+      stage[c * TAPS + tap] = s;
+    }
+  }
+  __syncthreads();
+  float* o = dw + ((long long)co * cin + c0) * TAPS;
+  for (int e = threadIdx.x; e < nci * TAPS; e += 256) o[e] = stage[e];
+}
+
+// floats of workspace the fold needs BEHIND the `splits` slices the GEMM writes
+inline long long wgrad_h_fold_extra_slices(int splits) { return splits > kFoldDirect ? (splits + kFoldGroup - 1) / kFoldGroup : 0; }
+
+int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int taps, hipStream_t stream) {
+  const long long total = (long long)cout * taps * cin;
+  float* src = ws;
+  float* dst = ws + (long long)splits * total;          // ping: behind the slices; pong: over the (consumed) first slices
+  while (splits > kFoldDirect) {
+    const int groups = (splits + kFoldGroup - 1) / kFoldGroup;
+    hipLaunchKernelGGL(wgrad_h_partial_kernel, dim3((unsigned)((total + 255) / 256), groups), dim3(256), 0, stream, src, dst,
+                       splits, total);
+    float* t = src; src = dst; dst = t;
+    splits = groups;
+  }
+  if (taps == 9) {
+    const unsigned wgs = (unsigned)cout * ((cin + 63) / 64);
+    hipLaunchKernelGGL((wgrad_h_fold_kernel<9, 64>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
+  } else {
+    const unsigned wgs = (unsigned)cout * ((cin + 255) / 256);
+    hipLaunchKernelGGL((wgrad_h_fold_kernel<1, 256>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
+  }
+  return (int)hipGetLastError();
 }
 
 inline int wgrad_h_splits(long long pixels, int tiles) {
@@ -566,7 +616,7 @@ extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int 
   wgrad_h_tiles(cout, ncols, &bm, &bn);
   const int tiles = ((cout + bm - 1) / bm) * ((ncols + bn - 1) / bn);
   const int splits = wgrad_h_splits((long long)batch * height * width, tiles);
-  return (size_t)splits * cout * ksize * ksize * cin * sizeof(float);
+  return (size_t)(splits + wgrad_h_fold_extra_slices(splits)) * cout * ksize * ksize * cin * sizeof(float);
 }
 
 extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const void* x_bf16, long long x_ld, float* dw_oihw,
@@ -599,8 +649,5 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   else if (bm == 64 && bn == 128) rc = launch_wgrad_h<64, 128, 2, 2>(a, splits, stream);
   else rc = launch_wgrad_h<64, 64, 2, 2>(a, splits, stream);
   if (rc != 0) return rc;
-  const long long total = (long long)cout * a.taps * cin;
-  hipLaunchKernelGGL(wgrad_h_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const float*>(workspace), dw_oihw, splits, cout, cin, a.taps);
-  return (int)hipGetLastError();
+  return launch_wgrad_h_fold(static_cast<float*>(workspace), dw_oihw, splits, cout, cin, a.taps, stream);
 }

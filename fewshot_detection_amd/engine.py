@@ -52,6 +52,16 @@ class _WeightCache(object):
         key = (id(w), mode, dtype)
         tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
         hit = self._store.get(key)
+        if dtype == "bf16" and (hit is None or hit[0] != tag):
+            # both bf16 operands (forward, data gradient) in ONE pass over the weight, into buffers that are kept
+            other = self._store.get((id(w), 1 - mode, dtype))
+            bufs = None
+            if hit is not None and other is not None:
+                bufs = (hit[1], other[1]) if mode == 0 else (other[1], hit[1])
+            pair = ops.pack_weight_bf16_pair(w.detach(), bufs)
+            self._store[(id(w), 0, dtype)] = (tag, pair[0])
+            self._store[(id(w), 1, dtype)] = (tag, pair[1])
+            return pair[mode]
         if hit is None or hit[0] != tag:
             if dtype in ("wino2", "wino4"):
                 packed = ops.pack_weight_wino(w.detach(), mode, int(dtype[4]))

@@ -142,6 +142,19 @@ def pack_weight(w, mode=0, dtype="f32"):
     return out
 
 
+def pack_weight_bf16_pair(w, out=None):
+    """Forward (mode 0) and data-gradient (mode 1) bf16 operands of one conv weight in a single pass.  out: a pair of
+    buffers from an earlier call (re-used: their zero padding never changes)."""
+    require_device(w)
+    cout, cin, k, _ = w.shape
+    if out is None:
+        out = (torch.zeros(lib().fsd_packed_weight_elems_bf16(cout, cin, k), dtype=torch.bfloat16, device=w.device),
+               torch.zeros(lib().fsd_packed_weight_elems_bf16(cin, cout, k), dtype=torch.bfloat16, device=w.device))
+    check(lib().fsd_pack_conv_weight_bf16_pair(w.contiguous().data_ptr(), out[0].data_ptr(), out[1].data_ptr(), cout, cin, k,
+                                               _stream()), "fsd_pack_conv_weight_bf16_pair")
+    return out
+
+
 def pack_weight_wino(w, mode=0, tile=2):
     """(Cout,Cin,3,3) -> the (tile+2)^2 transformed (G g G^T) matrices in the GEMM kernel's packed layout."""
     require_device(w)

@@ -192,6 +192,11 @@ int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const float* y, l
 size_t fsd_packed_weight_elems_bf16(int rows, int red, int ksize);
 int fsd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed_bf16, int cout, int cin, int ksize, int mode,
                               hipStream_t stream);
+/* Both packings (mode 0 and mode 1) of one weight tensor in one pass over it.  The two buffers
+ * (fsd_packed_weight_elems_bf16(cout, cin, k) and (cin, cout, k) elements) must have been zero-filled ONCE by the
+ * caller: only the non-padding elements are written. */
+int fsd_pack_conv_weight_bf16_pair(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin, int ksize,
+                                   hipStream_t stream);
 /* ---- batch norm (training statistics) + activation + pooling ------------------------------ */
 /* Reduce the per-tile partials, produce the per-channel affine (scale = gamma*invstd,
  * shift = beta - mean*scale), save mean / invstd for the backward pass and update the running

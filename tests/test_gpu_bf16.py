@@ -75,6 +75,24 @@ def test_conv_bf16_dma_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin
         assert float((e2 - gref.abs() * 2.0 ** -8).max()) < 1e-3 * max(1.0, float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("cout,cin,k", [(64, 32, 3), (128, 64, 1), (1024, 512, 3), (30, 1024, 1), (72, 200, 3), (1024, 1280, 3)])
+def test_single_pass_weight_pair_equals_the_two_single_packings(dev, cout, cin, k):
+    """fsd_pack_conv_weight_bf16_pair (one read of W) == mode 0 and mode 1 of fsd_pack_conv_weight_bf16, bit for bit,
+    and re-packing into the kept buffers leaves the zero padding intact."""
+    from fewshot_detection_amd import ops
+    torch.manual_seed(cout + cin)
+    w = torch.randn(cout, cin, k, k).to(dev)
+    pair = ops.pack_weight_bf16_pair(w)
+    for mode in (0, 1):
+        want = ops.pack_weight(w, mode, "bf16")
+        assert torch.equal(pair[mode].view(torch.int16), want.view(torch.int16)), mode
+    w2 = -2.0 * w
+    pair2 = ops.pack_weight_bf16_pair(w2, pair)
+    assert pair2[0].data_ptr() == pair[0].data_ptr()
+    for mode in (0, 1):
+        assert torch.equal(pair2[mode].view(torch.int16), ops.pack_weight(w2, mode, "bf16").view(torch.int16)), mode
+
+
 def test_conv_bf16_head_nchw_float_output(dev):
     """The fused reweighting (x) head GEMM: bf16 operands, float NCHW output (the loss input), 450 ragged channels."""
     from fewshot_detection_amd import ops
