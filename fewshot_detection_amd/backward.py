@@ -12,7 +12,7 @@ Per fused conv block (reverse of engine.Network._conv):
 """
 import torch
 
-from . import ops
+from . import ops, streams
 from .ops import View
 
 AVAILABLE = True
@@ -52,7 +52,22 @@ def _dgrad_h(net, dy, conv, xv, k):
     return ops.cast_view(dxf, torch.bfloat16)
 
 
-def _conv_backward(net, rec, grads, pgrads, first_input):
+def _off_path(ws, fn, reads):
+    """Run the weight-gradient launch `fn` on the side stream `ws` (None: inline).  It starts once the main stream has
+    produced its operands (`reads`: tensors allocated on the main stream that the side stream will still be reading
+    after the caller has dropped them) and nothing on the main stream waits for it until the end of the sweep."""
+    if ws is None:
+        return fn()
+    main = torch.cuda.current_stream()
+    ws.wait_stream(main)
+    with torch.cuda.stream(ws):
+        dw = fn()
+    streams.keep_alive(ws, *reads)
+    streams.keep_alive(main, dw)
+    return dw
+
+
+def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
     gz = grads.pop(id(rec["z"]), None)
     gzf = grads.pop(id(rec["z_full"]), None) if rec.get("z_full") is not None else None
     if gz is None and gzf is None:
@@ -82,8 +97,10 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
                 coef[1:].zero_()
             if xv is first_input and ops.c4_bnfused_eligible(xv, cout, k):
                 # first layer: no data gradient is needed, so dy is formed inside the weight-gradient kernel
-                pgrads[id(conv.weight)] = ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv,
-                                                                       cin, cout, param=conv.weight)
+                pgrads[id(conv.weight)] = _off_path(
+                    ws, lambda: ops.conv3x3_wgrad_c4_bnfused(dt, yv, coef, rec["mean"], rec["invstd"], xv, cin, cout,
+                                                             param=conv.weight),
+                    (dt.t, yv.t, coef, rec["mean"], rec["invstd"], xv.t))
                 return
             kept = rec.get("wino_v")
             if (ops.FUSE_WINO_GRAD and kept and rec.get("wino_tile") == 4 and xv is not first_input and dt.C % 4 == 0
@@ -106,11 +123,14 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
     kept = rec.get("wino_v")
     wtile = rec.get("wino_tile") or 0
     bf16 = net.compute_dtype == "bf16"
+    # the weight gradient is off the critical path of the sweep: on the "wgrad" stream it overlaps the data-gradient chain
     if bf16:
-        pgrads[id(conv.weight)] = _wgrad_h(net, dy, cout, xv, cin, k, conv.weight)
+        pgrads[id(conv.weight)] = _off_path(ws, lambda: _wgrad_h(net, dy, cout, xv, cin, k, conv.weight), (dy.t, xv.t))
     else:
-        pgrads[id(conv.weight)] = ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32", wino_v=kept[0] if kept else None,
-                                                   param=conv.weight, tile=wtile, wt_in=wt_in)
+        pgrads[id(conv.weight)] = _off_path(
+            ws, lambda: ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32", wino_v=kept[0] if kept else None,
+                                         param=conv.weight, tile=wtile, wt_in=wt_in),
+            (dy.t, xv.t, kept[0] if kept else None, wt_in))
     if xv is not first_input and not rec.get("input_cast"):
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         tile = 0 if bf16 else ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)
@@ -123,9 +143,12 @@ def _conv_backward(net, rec, grads, pgrads, first_input):
         _accumulate(grads, xv, dx)
 
 
-def run(net, tape, grad_out, params):
-    """Returns {"params": [grad or None, ... in the order of `params`], "dyn": grad of the vectors}."""
+def run(net, tape, grad_out, params, wgrad_stream=True):
+    """Returns {"params": [grad or None, ... in the order of `params`], "dyn": grad of the vectors}.
+    wgrad_stream: launch the weight gradients on the "wgrad" side stream (streams.py); the current stream waits for
+    them before this returns."""
     ops.require_device(grad_out)
+    ws = streams.side(grad_out.device, "wgrad") if (wgrad_stream and streams.ENABLED) else None
     grads = {}
     pgrads = {}
     grad_dyn = None
@@ -154,6 +177,8 @@ def run(net, tape, grad_out, params):
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach(), param=head.weight)
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn
+            if streams.ENABLED:          # the reweighting net's backward (its own stream) may start as soon as this exists
+                streams.publish(d_dyn, torch.cuda.current_stream().record_event())
             if head.bias is not None:
                 dst = ops.grad_dst(head.bias, (o_ch,), g.t.device)
                 torch.sum(ops.colsum(g, rows).view(n_cls, o_ch), dim=0, out=dst)
@@ -179,10 +204,12 @@ def run(net, tape, grad_out, params):
                 dt, _ = ops.bn_act_pool_bwd(g, None, rec["x"], None, None, None, None, 1.0, rec["pool"])
                 _accumulate(grads, rec["x"], dt)
         elif kind == "conv":
-            _conv_backward(net, rec, grads, pgrads, first_input)
+            _conv_backward(net, rec, grads, pgrads, first_input, ws)
         elif kind == "input":
             pass
         else:
             raise NotImplementedError("backward of tape record %r" % kind)
+    if ws is not None:
+        torch.cuda.current_stream().wait_stream(ws)
     # gradients the kernels wrote straight into a trainer's flat buffer are not handed to autograd again
     return {"params": [None if id(p) in ops.GRAD_SUNK else pgrads.get(id(p)) for p in params], "dyn": grad_dyn}

@@ -346,25 +346,27 @@ struct WgradHArgs {
 // 16-byte piece a lane FETCHES is permuted inside its row (XOR below) so that the transpose reads that follow are
 // bank-conflict free: a 32-lane half reads 4 consecutive pixel rows x 2 sixteen-channel blocks = 8 pieces of 32 B, which
 // must land in 8 different 32-byte bank ranges.
-template <int CH>
+template <int CH, int KC>
 struct TileGeom {
   static constexpr int LPR = CH / 8;            // lanes per pixel row
   static constexpr int RPI = 64 / LPR;          // pixel rows per wave instruction
-  static constexpr int PASSES = 32 / (4 * RPI) > 0 ? 32 / (4 * RPI) : 1;
-  static constexpr int ROWS_PER_PASS = 4 * RPI; // 16 (CH = 128), 32 (CH = 64), 64 (CH = 32: only the first 32 used)
+  static constexpr int PASSES = KC / (4 * RPI) > 0 ? KC / (4 * RPI) : 1;
+  static constexpr int ROWS_PER_PASS = 4 * RPI; // 16 (CH = 128), 32 (CH = 64), 64 (CH = 32: only the first KC used)
   __device__ static __forceinline__ int swz(int row) {      // XOR mask on the 16-byte piece index of a row
     return CH == 128 ? ((row & 3) << 2) : CH == 64 ? ((row & 2) << 1) : 0;
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// KC = pixels per k-chunk (one barrier per chunk): 32, or 64 for the 128 x 128 tile (half the barriers per MFMA).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KC>
 __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(KC == 32 || KC == 64, "k-chunk of 32 or 64 pixels");
   constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile of at least 32 x 32");
-  typedef TileGeom<BM> GA;
-  typedef TileGeom<BN> GB;
-  constexpr int STAGE = 32 * (BM + BN);           // elements per LDS stage
+  typedef TileGeom<BM, KC> GA;
+  typedef TileGeom<BN, KC> GB;
+  constexpr int STAGE = KC * (BM + BN);           // elements per LDS stage
   extern __shared__ __attribute__((aligned(16))) u16 smem_w[];
 
   // The N dimension is the packed (tap, ci) column space of dW, ncols = taps * Cin: a 128-wide tile is one tap's slice of
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   const long long pix0 = (long long)blockIdx.y * p.pix_per_split;
   long long pix_end = pix0 + p.pix_per_split;
   if (pix_end > p.M) pix_end = p.M;
-  const int nk = (int)((pix_end - pix0 + 31) / 32);
+  const int nk = (int)((pix_end - pix0 + KC - 1) / KC);
 
   // this lane's piece of an A row: channels m0 + a_piece*8 .. +7 (logical), rows a_row + ROWS_PER_PASS * pass
   const int a_row = wave * GA::RPI + lane / GA::LPR, a_pp = lane % GA::LPR;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   const int shift = dyo * p.W + dxo;
   // image coordinates of the B rows of this thread (they advance by 32 pixels per chunk)
   int b_y[GB::PASSES], b_x[GB::PASSES];
-  const float inv_w = 1.0f / (float)p.W;
+  const float inv_w = 1.0f / (float)p.W, inv_h = 1.0f / (float)p.H;
 #pragma unroll
   for (int j = 0; j < GB::PASSES; ++j) {
     const long long pp = pix0 + b_row + GB::ROWS_PER_PASS * j;
@@ -404,14 +406,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   }
 
   auto stage = [&](int kc, u16* st) {
-    const long long base = pix0 + (long long)kc * 32;
+    const long long base = pix0 + (long long)kc * KC;
 #pragma unroll
     for (int j = 0; j < GA::PASSES; ++j) {
       const int row = a_row + GA::ROWS_PER_PASS * j;
-      if (GA::ROWS_PER_PASS * j + wave * GA::RPI < 32) {            // CH = 32: 64 rows per pass, only 32 exist
+      if (GA::ROWS_PER_PASS * j + wave * GA::RPI < KC) {            // CH = 32: 64 rows per pass, only KC exist
         const int piece = a_pp ^ GA::swz(row);
         const long long pix = base + row;
-        const bool ok = row < 32 && pix < pix_end && (m0 + piece * 8) < p.Cout;
+        const bool ok = row < KC && pix < pix_end && (m0 + piece * 8) < p.Cout;
         const u16* src = ok ? p.dy + pix * p.dy_ld + m0 + piece * 8 : g_zero_page_h;
         dma16(src, st + (GA::ROWS_PER_PASS * j + wave * GA::RPI) * BM);
       }
@@ -419,21 +421,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
 #pragma unroll
     for (int j = 0; j < GB::PASSES; ++j) {
       const int row = b_row + GB::ROWS_PER_PASS * j;
-      if (GB::ROWS_PER_PASS * j + wave * GB::RPI < 32) {
+      if (GB::ROWS_PER_PASS * j + wave * GB::RPI < KC) {
         const long long pix = base + row;
-        const bool ok = row < 32 && pix < pix_end && b_col_ok &&
+        const bool ok = row < KC && pix < pix_end && b_col_ok &&
                         (unsigned)(b_y[j] + dyo) < (unsigned)p.H && (unsigned)(b_x[j] + dxo) < (unsigned)p.W;
         const u16* src = ok ? p.x + (pix + shift) * p.x_ld + b_ci : g_zero_page_h;
-        dma16(src, st + 32 * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
+        dma16(src, st + KC * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
       }
-      // advance this row's image coordinates by one chunk (32 pixels); (x + 0.5) / W is never within 1/(2W) of an integer
-      int xx = b_x[j] + 32;
+      // advance this row's image coordinates by one chunk (KC pixels).  (v + 0.5) / n is never within 1/(2n) of an
+      // integer, so the float quotients are exact; the row index wraps by the same rule (a chunk spans up to KC image
+      // rows on the 3x3 / 2x2 / 1x1 maps at the end of the reweighting net, so a fixed number of subtractions is not
+      // enough -- the version with three conditional subtractions mis-tracked every map smaller than 4x4).
+      int xx = b_x[j] + KC;
       const int q = (int)(((float)xx + 0.5f) * inv_w);
       xx -= q * p.W;
       int yy = b_y[j] + q;
-      if (yy >= p.H) yy -= p.H;
-      if (yy >= p.H) yy -= p.H;
-      if (yy >= p.H) yy -= p.H;
+      yy -= (int)(((float)yy + 0.5f) * inv_h) * p.H;
       b_x[j] = xx;
       b_y[j] = yy;
     }
@@ -463,9 +466,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
   };
   auto compute = [&](const u16* st) {
     const u16* sa = st;
-    const u16* sb = st + 32 * BM;
+    const u16* sb = st + KC * BM;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KC / 16; ++s) {
       const int krow = s * 16 + (G >> 1) * 8;
       const int row_lo = krow + (Lq >> 2);                        // the +4 rows of the second read share (row & 3)
       bf16x8 af[TM], bf[TN];
@@ -600,12 +603,27 @@ inline void wgrad_h_tiles(int cout, int ncols, int* bm, int* bn) {
   if (*bn == 32) *bm = 128;                            // the 32-wide variant runs 4 x 1 waves of 32 rows
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KC = 32>
 int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)32 * (BM + BN) * sizeof(u16);
+  const size_t lds = 2 * (size_t)KC * (BM + BN) * sizeof(u16);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
-  hipLaunchKernelGGL((wgrad_bf16_tr_kernel<BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
+  auto k = wgrad_bf16_tr_kernel<BM, BN, WM, WN, KC>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
+}
+
+// pixels per k-chunk of the 128 x 128 tile: 64 (two LDS stages of 32 KB, still two workgroups per CU, half the barriers)
+// on the large maps.  Measured at B = 64 (tools/layer_bench.py wgrad, bf16): 104x104 64->128 0.331 -> 0.280 ms, 52x52
+// 128->256 0.251 -> 0.227 ms; 26x26 and 13x13 (<= 43k pixels, few chunks per split) lose 2-4 %, so they keep 32.
+// FSD_WGRAD_H_KC=32|64 forces one (tuning aid).
+inline int wgrad_h_kc(long long pixels) {
+  static const char* env = getenv("FSD_WGRAD_H_KC");
+  if (env) return atoi(env) == 32 ? 32 : 64;
+  return pixels >= 131072 ? 64 : 32;
 }
 
 }  // namespace
@@ -641,9 +659,11 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   a.m_tiles = (cout + bm - 1) / bm;
   a.n_tiles = (ncols + bn - 1) / bn;
   const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles);
-  a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), 32);
+  const bool kc64 = bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64;
+  a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kc64 ? 64 : 32);
   int rc;
   if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);
+  else if (kc64) rc = launch_wgrad_h<128, 128, 2, 2, 64>(a, splits, stream);
   else if (bm == 128 && bn == 128) rc = launch_wgrad_h<128, 128, 2, 2>(a, splits, stream);
   else if (bm == 128 && bn == 64) rc = launch_wgrad_h<128, 64, 2, 2>(a, splits, stream);
   else if (bm == 64 && bn == 128) rc = launch_wgrad_h<64, 128, 2, 2>(a, splits, stream);

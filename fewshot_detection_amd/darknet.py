@@ -32,7 +32,7 @@ class Darknet(nn.Module):
 
     def forward(self, x):
         self.loss = None
-        return _NetFn.apply(self._net, self.training, 1, False, x, *_flat_params(self.models))
+        return _NetFn.apply(self._net, self.training, 1, False, None, False, x, *_flat_params(self.models))
 
     def print_network(self):
         print_cfg(self.blocks)

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .cfg import (cfg, load_conv, load_conv_bn, load_fc, parse_cfg, print_cfg, save_conv, save_conv_bn,
                   save_fc)
 from .dynamic_conv import dynamic_conv2d
@@ -201,13 +201,34 @@ def build_modules(blocks, region_cls):
 
 class _NetFn(torch.autograd.Function):
     """One engine.Network as a single autograd node: inputs (activations, optional reweighting
-    vectors, parameters) -> output; backward replays the tape on the HIP kernels."""
+    vectors, parameters) -> output; backward replays the tape on the HIP kernels.
+
+    side: None, or the name of the side stream this network runs on (streams.py; the reweighting net runs on
+    "meta" beside the detector).  defer: the caller guarantees that the output's first reader calls
+    streams.await_tensor (the fused head does); otherwise the current stream waits for the side stream right away."""
 
     @staticmethod
-    def forward(ctx, net, training, n_inputs, has_dyn, *tensors):
+    def forward(ctx, net, training, n_inputs, has_dyn, side, defer, *tensors):
         inputs = list(tensors[:n_inputs])
         dyn = [tensors[n_inputs]] if has_dyn else None
-        out, tape = net.forward(inputs, dyn=dyn, training=training, record=any(ctx.needs_input_grad))
+        record = any(ctx.needs_input_grad)
+        ctx.side = None
+        if side is not None and streams.ENABLED and inputs[0].is_cuda:
+            main = torch.cuda.current_stream()
+            s = streams.side(inputs[0].device, side)
+            s.wait_stream(main)               # inputs, and the weights the optimizer just updated on the main stream
+            with torch.cuda.stream(s):
+                out, tape = net.forward(inputs, dyn=dyn, training=training, record=record)
+                done = s.record_event()
+            streams.keep_alive(s, *inputs)
+            streams.keep_alive(main, out)
+            if defer:
+                streams.publish(out, done)
+            else:
+                main.wait_event(done)
+            ctx.side = side
+        else:
+            out, tape = net.forward(inputs, dyn=dyn, training=training, record=record)
         ctx.net, ctx.tape, ctx.n_inputs, ctx.has_dyn = net, tape, n_inputs, has_dyn
         ctx.params = tensors[n_inputs + (1 if has_dyn else 0):]
         return out
@@ -215,11 +236,23 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         from . import backward as bw
-        grads = bw.run(ctx.net, ctx.tape, grad_out.contiguous(), ctx.params)
+        grad_out = grad_out.contiguous()
+        if ctx.side is not None:
+            main = torch.cuda.current_stream()
+            s = streams.side(grad_out.device, ctx.side)
+            if not streams.await_tensor(grad_out, s):     # published by the head's backward: start as soon as it is there
+                s.wait_stream(main)
+            with torch.cuda.stream(s):
+                grads = bw.run(ctx.net, ctx.tape, grad_out, ctx.params, wgrad_stream=False)
+            streams.keep_alive(s, grad_out)
+            main.wait_stream(s)               # gradients (flat buffer or tensors) are complete for whatever follows
+            streams.keep_alive(main, *[g for g in grads["params"] if g is not None])
+        else:
+            grads = bw.run(ctx.net, ctx.tape, grad_out, ctx.params)
         if ops.GRAD_HOOK is not None:
             ops.GRAD_HOOK()
         head = [None] * ctx.n_inputs + ([grads["dyn"]] if ctx.has_dyn else [])
-        return (None, None, None, None) + tuple(head) + tuple(grads["params"])
+        return (None, None, None, None, None, None) + tuple(head) + tuple(grads["params"])
 
 
 class Darknet(nn.Module):
@@ -250,25 +283,28 @@ class Darknet(nn.Module):
         return self
 
     # ---- forward ---------------------------------------------------------------------------
-    def meta_forward(self, metax, mask):
-        """Support images (+ masks) -> list of reweighting vectors [(N, C, 1, 1)]."""
+    def meta_forward(self, metax, mask, _defer=False):
+        """Support images (+ masks) -> list of reweighting vectors [(N, C, 1, 1)].
+        _defer (internal, used by forward()): the vectors are still being computed on the "meta" side stream when this
+        returns and their only reader -- detect_forward's fused head -- waits for them (streams.py)."""
         if int(self.learnet_blocks[0]["feat_layer"]) != 0:
             raise NotImplementedError("feat_layer != 0 is not used by any shipped cfg")
         inputs = [metax, mask] if cfg.metain_type in (2, 3) else [metax]
         if mask is None:          # RGB + mask already interleaved per pixel (episode.DeviceAugmenter layout="nhwc4")
             inputs = [metax]
         params = _flat_params(self.learnet_models)
-        out = _NetFn.apply(self._meta, self.training, len(inputs), False, *(inputs + params))
+        out = _NetFn.apply(self._meta, self.training, len(inputs), False, "meta", bool(_defer), *(inputs + params))
         return [out]
 
     def detect_forward(self, x, dynamic_weights):
         """Query images + reweighting vectors -> (B*N, A*(5+C), G, G), rows ordered b*N+n."""
         self.loss = None       # the reference clears it here too (darknet_meta.py:134)
         params = _flat_params(self.models)
-        return _NetFn.apply(self._det, self.training, 1, True, x, dynamic_weights[0], *params)
+        return _NetFn.apply(self._det, self.training, 1, True, None, False, x, dynamic_weights[0], *params)
 
     def forward(self, x, metax, mask, ids=None):
-        return self.detect_forward(x, self.meta_forward(metax, mask))
+        # the reweighting net runs on its own stream beside the detector backbone; the two meet at the fused head
+        return self.detect_forward(x, self.meta_forward(metax, mask, _defer=True))
 
     def print_network(self):
         print_cfg(self.blocks)

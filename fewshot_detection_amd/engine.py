@@ -15,7 +15,7 @@ A forward pass records a tape (views + per-channel statistics) that `backward` r
 """
 import torch
 
-from . import ops
+from . import ops, streams
 from .ops import View
 
 
@@ -278,6 +278,7 @@ class Network(object):
                     raise ValueError("reweighting vectors %s do not match %d feature channels"
                                      % (tuple(vec.shape), x.C))
                 n_cls, o_ch = vec.shape[0], head.weight.shape[0]
+                streams.await_tensor(vec)        # vectors still in flight on the reweighting net's stream (Darknet.forward)
                 w_op, b_eff, w_eff = ops.fold_reweight_head(head.weight.detach(), None if head.bias is None
                                                             else head.bias.detach(), vec.detach(), self.compute_dtype)
                 if self.compute_dtype == "bf16" and not (x.bf16 and x.C % 32 == 0):

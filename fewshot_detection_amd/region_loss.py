@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from ._lib import check, lib
 from .cfg import cfg
 
@@ -130,11 +130,21 @@ class _RegionBase(nn.Module):
         keep_map = np.full(rows, -1, np.int32)
         keep_map[keep] = np.arange(len(keep), dtype=np.int32)
         dev = output.device
-        # Pageable host->device copies: the host blocks here until the stream has run the forward pass, then queues the
-        # loss + backward (7 ms of host work against 27 ms of GPU work, tools/enqueue_time.py).  Pinned staging through
-        # torch's caching host allocator was tried and cost 3 ms per step in allocator synchronisation.
-        target_dev = torch.from_numpy(tr).to(dev, non_blocking=True)
-        keep_dev = torch.from_numpy(keep_map).to(dev, non_blocking=True)
+        # Pageable host->device copies block the host until the stream they are queued on has drained.  On the main stream
+        # that means "until the forward pass has run" (the host then queues loss + backward against an idle GPU); on the
+        # "copy" side stream it means "until this copy is done", so the host keeps queueing the step ahead of the GPU.
+        # (Pinned staging through torch's caching host allocator was tried and cost 3 ms per step in allocator
+        # synchronisation.)
+        if streams.ENABLED and dev.type == "cuda":
+            main, cs = torch.cuda.current_stream(), streams.side(dev, "copy")
+            with torch.cuda.stream(cs):
+                target_dev = torch.from_numpy(tr).to(dev)
+                keep_dev = torch.from_numpy(keep_map).to(dev)
+            main.wait_stream(cs)
+            streams.keep_alive(main, target_dev, keep_dev)
+        else:
+            target_dev = torch.from_numpy(tr).to(dev, non_blocking=True)
+            keep_dev = torch.from_numpy(keep_map).to(dev, non_blocking=True)
         dbg = None
         if self.debug_targets:
             dbg = torch.zeros((9, rows, self.num_anchors, output.shape[2], output.shape[3]),

@@ -115,6 +115,12 @@ def test_conv_bf16_head_nchw_float_output(dev):
     (2, 13, 13, 1280, 1024, 3),     # L29
     (2, 13, 13, 1024, 512, 1),      # head shape (rows padded to 512)
     (16, 52, 52, 128, 256, 3),      # many pixels: several splits, image rows wrap inside a 32-pixel chunk
+    (20, 3, 3, 1024, 1024, 3),      # last reweighting-net layer of the metric-string episode (224x224 supports -> 3x3 maps):
+                                    # a chunk spans several whole images
+    (20, 3, 3, 64, 64, 3),          # the same on the 64 x 64 tile (32-pixel chunks)
+    (9, 2, 2, 32, 64, 3),           # 2x2 and 1x1 maps: every tap but the centre is padding for most pixels
+    (70, 1, 1, 128, 128, 3),
+    (3, 5, 4, 128, 128, 3),         # non-square map smaller than a chunk
 ])
 def test_wgrad_bf16_transpose_read_kernel_matches_fp64(dev, B, H, W, cin, cout, k):
     from fewshot_detection_amd import ops

@@ -1,0 +1,115 @@
+"""Side streams (fewshot_detection_amd/streams.py): the reweighting net beside the detector, the weight gradients beside
+the data-gradient chain, the target upload on a copy stream.  Kernels are unchanged and deterministic, so a step with
+the side streams must be BIT-identical to the same step on one stream -- any difference is a missing dependency."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cfg_paths(tmp_path_factory):
+    from fewshot_detection_amd import cfgs
+    return cfgs.write_standard_cfgs(str(tmp_path_factory.mktemp("cfgs")))
+
+
+def _episode(seed, B, N, S, Sm):
+    import bench
+    return bench.synth_episode(seed, B, N, S, Sm)
+
+
+def _run_steps(dev, cfg_paths, enabled, dtype, steps, B=8, N=5, S=224, Sm=128, neg="full"):
+    """`steps` train steps from a fixed seed -> (outputs of every step, losses, final flat parameters, flat gradient)."""
+    from fewshot_detection_amd import streams
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    old = streams.ENABLED
+    streams.ENABLED = enabled
+    cfg.neg_ratio = neg
+    try:
+        torch.manual_seed(3)
+        random.seed(3)
+        net = Darknet(cfg_paths[0], cfg_paths[1]).to(dev).train()
+        net.set_compute_dtype(dtype)
+        region = net.models[len(net.models) - 1]
+        region.verbose = False
+        opt = EpisodeTrainer(net, lr=1e-9, momentum=0.9, weight_decay=5e-4)      # random init: a real step size diverges
+        outs, losses = [], []
+        for i in range(steps):
+            x, metax, mask, target = _episode(100 + i, B, N, S, Sm)
+            out = net(x.to(dev), metax.to(dev), mask.to(dev))
+            region.seen += B
+            loss = region(out, target)
+            outs.append(out.detach().clone())
+            losses.append(loss.detach().clone())
+            opt.backward_and_step(loss)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v)) for v in losses) and bool(torch.isfinite(opt.flat).all())
+        return outs, losses, opt.flat.detach().clone(), opt.grad.detach().clone()
+    finally:
+        streams.ENABLED = old
+        cfg.neg_ratio = "full"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_train_steps_bit_identical_with_side_streams(dev, cfg_paths, dtype):
+    ref = _run_steps(dev, cfg_paths, False, dtype, 3)
+    for attempt in range(3):                      # a missing dependency is a race: give it a few chances to show
+        got = _run_steps(dev, cfg_paths, True, dtype, 3)
+        for a, b in zip(ref[0], got[0]):
+            assert torch.equal(a, b), "head output differs (attempt %d)" % attempt
+        for a, b in zip(ref[1], got[1]):
+            assert torch.equal(a, b), "loss differs (attempt %d)" % attempt
+        assert torch.equal(ref[3], got[3]), "flat gradient of the last step differs (attempt %d)" % attempt
+        assert torch.equal(ref[2], got[2]), "parameters after 3 steps differ (attempt %d)" % attempt
+
+
+def test_side_streams_with_negative_row_filter(dev, cfg_paths):
+    """neg_ratio = 1 consumes python's RNG on the host and uploads a keep map: same draw, same bits."""
+    ref = _run_steps(dev, cfg_paths, False, "f32", 2, neg=1)
+    got = _run_steps(dev, cfg_paths, True, "f32", 2, neg=1)
+    assert all(torch.equal(a, b) for a, b in zip(ref[1], got[1]))
+    assert torch.equal(ref[2], got[2])
+
+
+def test_autograd_without_trainer_and_public_meta_forward(dev, cfg_paths):
+    """Plain autograd (.grad tensors, no gradient sink) and the public meta_forward / detect_forward pair: the vectors a
+    caller receives from meta_forward are complete on the CURRENT stream (no deferred wait leaks out of the API)."""
+    from fewshot_detection_amd import streams
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.darknet_meta import Darknet
+    cfg.neg_ratio = "full"
+    res = []
+    for enabled in (False, True):
+        old = streams.ENABLED
+        streams.ENABLED = enabled
+        try:
+            torch.manual_seed(5)
+            net = Darknet(cfg_paths[0], cfg_paths[1]).to(dev).train()
+            region = net.models[len(net.models) - 1]
+            region.verbose = False
+            x, metax, mask, target = _episode(7, 4, 3, 160, 96)
+            vecs = net.meta_forward(metax.to(dev), mask.to(dev))
+            v_host = vecs[0].detach().cpu()                      # read right away on the current stream
+            out = net.detect_forward(x.to(dev), vecs)
+            loss = region(out, target)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().clone() for p in net.parameters()]
+            res.append((v_host, out.detach().clone(), grads))
+        finally:
+            streams.ENABLED = old
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
