@@ -279,7 +279,10 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
                          "the ranks, supports replicated (SURVEY 8e)")
-    ap.add_argument("--profile-steps", type=int, default=5, help="timed steps that carry the per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=4, help="timed steps that carry the per-kernel HIP events")
+    ap.add_argument("--streams", type=int, choices=[0, 1], default=None,
+                    help="side HIP streams (reweighting net, weight gradients, target upload beside the main stream); "
+                         "default: on unless FSD_STREAMS=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle comparison on the cpu_baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / other-episode timings")
@@ -315,12 +318,15 @@ def main():
     global_batch = args.batch if strong else args.batch * world
 
     from fewshot_detection_amd import backward as bw
-    from fewshot_detection_amd import cfgs, ops
+    from fewshot_detection_amd import cfgs, ops, streams
     from fewshot_detection_amd.cfg import cfg, parse_cfg
     from fewshot_detection_amd.darknet_meta import Darknet
 
     if args.mode is None:
         args.mode = "train" if getattr(bw, "AVAILABLE", False) else "forward"
+    if args.streams is not None:
+        streams.ENABLED = bool(args.streams)
+    streams_on = streams.ENABLED
     cfg.neg_ratio = args.neg if args.neg == "full" else float(args.neg)
     if isinstance(cfg.neg_ratio, float) and cfg.neg_ratio.is_integer():
         cfg.neg_ratio = int(cfg.neg_ratio)
@@ -374,21 +380,31 @@ def main():
     gc.disable()
     # Per-kernel HIP events (roofline) are recorded INSIDE the timed region, on its first `prof_steps` steps only: each
     # record is a barrier packet in the queue and a few hundred of them per step cost ~1 ms of the step.
+    # The profiled steps run on ONE stream: with the side streams a kernel shares the chip with the launches of the other
+    # strands and its duration says how the chip was shared, not how good the kernel is.  They are part of the timed
+    # region (the headline therefore includes a few un-overlapped steps); ms_per_step_unprofiled is the rest.
     prof_steps = min(args.steps, args.profile_steps) if rank == 0 else 0
     prof = []
+    t_mid = None
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == 0 and prof_steps:
             ops.PROFILE = prof
             ops.kernel_profile(True)
+            streams.ENABLED = False
         elif i == prof_steps and prof_steps:
             ops.PROFILE = None
             ops.kernel_profile(False)
+            streams.ENABLED = streams_on
+            torch.cuda.synchronize()
+            t_mid = time.perf_counter()
         loss = step()
     ops.PROFILE = None
     ops.kernel_profile(False)
+    streams.ENABLED = streams_on
     fence()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
     gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -442,8 +458,9 @@ def main():
             "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
                     "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
                     "its own duration, HIP events recorded by the library right around every launch on the launch stream "
-                    "during the first `profiled_steps` timed steps; avg_kernel_ms is what rocprofv3 --kernel-trace --stats "
-                    "shows for this kernel (profiles/)",
+                    "during the first `profiled_steps` timed steps, which run on one stream (no side-stream overlap: a "
+                    "kernel's duration in isolation); avg_kernel_ms is what rocprofv3 --kernel-trace --stats shows for this "
+                    "kernel under `bench.py --streams 0` (profiles/)",
             "profiled_steps": prof_steps,
             "traffic": (traffic or {}).get("hbm_bytes_per_launch") if is_c2 else None,
             "traffic_source": traffic_src if is_c2 else None,
@@ -493,6 +510,13 @@ def main():
                        "mode": args.mode, "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "episode_forward_gflop": full_flops / 1e9},
             "roofline": roof,
+            "streams": {"enabled": bool(streams_on),
+                        "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
+                                "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
+                        "profiled_steps_on_one_stream": prof_steps,
+                        "ms_per_step_unprofiled": ((t_end - t_mid) / (args.steps - prof_steps) * 1e3
+                                                   if t_mid is not None and args.steps > prof_steps else None),
+                        "ms_per_step_profiled": ((t_mid - t0) / prof_steps * 1e3 if t_mid is not None else None)},
         }
         if opt is not None:
             res["dp"] = {"world_size": opt.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,

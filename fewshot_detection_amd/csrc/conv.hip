@@ -57,7 +57,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int kq = tid & 7, r0 = tid >> 3;
   // GLDS: the DMA writes LDS linearly (wave base + lane*16 B); bank conflicts are avoided by
   // permuting which 16-B k-group each lane FETCHES (same 128-B line) and un-permuting on the read.
-  const int kq_src = GLDS ? (kq ^ (r0 & 7)) : kq;
+  // The XOR mask is (row >> 1) & 7: a 16-lane service group of the ds_read_b128 fragment reads covers rows
+  // {0-3, 12-15, 20-27} (+ three more such sets), i.e. all 16 values of row & 15, and with 128-byte rows the 256-byte
+  // bank row is (row & 1, 16-byte group) -- so the group must vary with bits 1..3 of the row.  (Rounds 1-2 used
+  // row & 7, which maps every pair of rows 8 apart onto one slot: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50.)
+  const int kq_src = GLDS ? (kq ^ ((r0 >> 1) & 7)) : kq;
 
   // Per-thread im2col bookkeeping.  NHWC input and output share the pixel grid (stride 1, "same"
   // padding), so the input pixel of output pixel `pix` under tap (dy, dx) is pix + dy*W + dx.
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frag_off = GLDS ? (lane & 31) * LD : (lane & 31) * LD + (lane >> 5) * 4;
-  // GLDS read-side un-swizzle: logical k-group g of row r sits at physical group g ^ (r & 7)
-  auto kofs = [&](int k8) { return GLDS ? (((k8 * 2 + (lane >> 5)) ^ (lane & 7)) * 4) : k8 * 8; };
+  // GLDS read-side un-swizzle: logical k-group g of row r sits at physical group g ^ ((r >> 1) & 7)
+  auto kofs = [&](int k8) { return GLDS ? (((k8 * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4) : k8 * 8; };
   auto compute = [&](const float* st) {
     const float* sa = st + (wm * TM * 32) * LD + frag_off;
     const float* sb = st + (BM + wn * TN * 32) * LD + frag_off;

@@ -316,7 +316,12 @@ extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* 
   a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
   a.Cout = cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.Kpad = round_up(ksize * ksize * cin, 64);                    // row stride of fsd_pack_conv_weight_bf16
-  const int bk = cin % 64 == 0 ? 64 : 32;
+  // k-chunk: 64 elements (128-byte rows) by default; 32 for Cin = 32 and for the short reductions of the 1x1 layers
+  // (K <= 512: measured 104x104 128->64 0.072 -> 0.062 ms, 26x26 512->256 0.035 -> 0.029 ms, their data gradients
+  // likewise; the 3x3 layers and the K = 1024 head lose 3-20 % with it).  FSD_CONV_H_BK=32|64 forces one (tuning aid).
+  static const char* bk_env = getenv("FSD_CONV_H_BK");
+  int bk = (cin % 64 == 0 && !(ksize == 1 && cin <= 512)) ? 64 : 32;
+  if (bk_env && cin % 64 == 0) bk = atoi(bk_env) == 32 ? 32 : 64;
   a.nk = ksize * ksize * cin / bk;
   a.cpt = cin / bk;
   a.m_tiles = (int)((pixels + 127) / 128);

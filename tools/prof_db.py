@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="training steps in the trace (totals are divided by it)")
     ap.add_argument("--csv")
     ap.add_argument("--launches", help="list every launch of kernels whose name contains this")
+    ap.add_argument("--timeline", action="store_true", help="overlap summary: wall span, union of kernel intervals, per-queue busy")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -32,6 +33,30 @@ def main():
         t = tot[short(names[kid])]
         t[0] += 1
         t[1] += (e - s) / 1e6
+    if a.timeline:
+        cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+        qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+        iv = list(c.execute("select start, end%s from %s order by start" % ((", " + qcol) if qcol else ", 0", kd)))
+        # drop the warm-up: keep the last 60 % of the trace
+        t_lo = iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
+        iv = [x for x in iv if x[0] >= t_lo]
+        span = (max(x[1] for x in iv) - iv[0][0]) / 1e6
+        union, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s_, e_, _ in iv[1:]:
+            if s_ > cur_e:
+                union += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        union += cur_e - cur_s
+        per_q = collections.defaultdict(float)
+        for s_, e_, q in iv:
+            per_q[q] += (e_ - s_) / 1e6
+        print("# timeline (last 60 %% of the trace): span %.2f ms, GPU busy (union of kernel intervals) %.2f ms = %.1f %%, "
+              "sum of kernel durations %.2f ms (x%.2f of busy: overlap)" % (span, union / 1e6, 100 * union / 1e6 / span,
+                                                                       sum(per_q.values()), sum(per_q.values()) / (union / 1e6)))
+        for q, ms in sorted(per_q.items(), key=lambda kv: -kv[1]):
+            print("#   queue %s: %.2f ms of kernels" % (q, ms))
     div = a.steps or 1
     allms = sum(v[1] for v in tot.values())
     out = ["kernel,calls%s,total_ms%s,avg_us,percent" % (("_per_step",) * 2 if a.steps else ("", ""))]
