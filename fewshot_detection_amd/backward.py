@@ -83,6 +83,19 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
     else:
         yv = rec["y"]
         pool = rec["pool"]
+        if (bn is not None and xv is first_input and gz is not None
+                and ops.first_bwd_eligible(xv, yv, cout, k, pool, gzf)):
+            # first block of a network: no data gradient, so dt is only summed -- one sweep over y, dt never written
+            def first():
+                dw, dbeta, dgamma = ops.first_layer_bwd(gz, yv, rec["scale"], rec["shift"], rec["mean"], rec["invstd"],
+                                                        rec["slope"], xv, cin, cout, bn, rec["training"], param=conv.weight)
+                pgrads[id(bn.bias)], pgrads[id(bn.weight)] = dbeta, dgamma
+                return dw
+            pgrads[id(conv.weight)] = _off_path(ws, first, (gz.t, yv.t, rec["scale"], rec["shift"], rec["mean"],
+                                                            rec["invstd"], xv.t))
+            if ws is not None:
+                streams.keep_alive(torch.cuda.current_stream(), pgrads[id(bn.bias)], pgrads[id(bn.weight)])
+            return
         if gz is None:                       # only the un-pooled tap carries gradient
             gz, gzf, pool = gzf, None, 0
         dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, rec.get("scale"), rec.get("shift"), rec.get("mean"),

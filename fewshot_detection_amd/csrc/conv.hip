@@ -402,7 +402,7 @@ inline char batched_pick(int cin, int cout) {
 int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
   const char pick = batched_pick(cin, cout);
   const int big = pick == 'c' || pick == 'd';
-  const int bm = (big || pick == 'e') ? 128 : 64, bn = big ? 128 : 64;
+  const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   if (bm_out) *bm_out = bm;
   if (bn_out) *bn_out = bn;
   if (dma_out) *dma_out = pick == 'd';
@@ -425,7 +425,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.cpt = cin / kBK;
   const char pick = batched_pick(cin, cout);
   const int big = pick == 'c' || pick == 'd';
-  const int bm = (big || pick == 'e') ? 128 : 64, bn = big ? 128 : 64;
+  const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   a.m_tiles = (int)((rows + bm - 1) / bm);
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
@@ -433,6 +433,9 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.batches = batches;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
+  if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
+  if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages
+  if (pick == 'g') return launch<64, 64, 2, 2, 3, true>(a, false, stream);       // 64x64 DMA, 3-deep ring
   if (big) return pick == 'c' ? launch<128, 128, 2, 2, 2>(a, false, stream) : launch<128, 128, 2, 2, 2, true>(a, false, stream);
   return launch<64, 64, 2, 2, 1>(a, false, stream);
 }

@@ -492,6 +492,44 @@ def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout, param=No
     return dw
 
 
+FUSE_FIRST_BWD = os.environ.get("FSD_FUSE_FIRST_BWD", "1") != "0"     # one-sweep backward of a first conv block
+
+
+def first_bwd_eligible(xv, yv, cout, ksize, pool, dz_full):
+    """A first conv block the one-sweep backward takes: NHWC4 input, 3x3, BatchNorm, 2x2/2 max pool, even extents.
+    fp32 storage only: measured on the L0 shape (B = 64, 416x416, 32 channels, tools/probes/first_bwd_time.py) the sweep
+    takes 0.97 ms against 1.31 ms for the unfused sequence in fp32, but 1.08 against 1.07 ms in bf16 mode -- it is bound by
+    its four 64-cycle fp32 MFMAs and ~60 VALU instructions per pooling cell, not by HBM, so halving the bytes buys nothing
+    and the HBM-bound unfused kernels catch up."""
+    return (FUSE_FIRST_BWD and pool == 1 and dz_full is None and c4_bnfused_eligible(xv, cout, ksize)
+            and xv.H % 2 == 0 and xv.W % 2 == 0 and yv.C == cout and not yv.bf16)
+
+
+def first_layer_bwd(dz, yv, scale, shift, mean, invstd, slope, xv, cin, cout, bn, training, param=None):
+    """-> (dW, dbeta, dgamma): the whole backward of a first conv block from dz (gradient w.r.t. its pooled output) in
+    one sweep over y; dt is never written (csrc/first_bwd.hip)."""
+    L = lib()
+    dev = xv.t.device
+    if dz.bf16 != yv.bf16:
+        raise ValueError("dz and y must share the storage type")
+    rows = L.fsd_first_layer_bwd_rows(xv.B, xv.H, xv.W)
+    ws_bytes = L.fsd_first_layer_bwd_workspace_bytes(xv.B, xv.H, xv.W, cout)
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    partial = torch.empty((rows, cout, 2), dtype=torch.float32, device=dev)
+    fn = L.fsd_first_layer_bwd_accum_h if yv.bf16 else L.fsd_first_layer_bwd_accum
+    check(fn(dz.ptr, dz.ld, yv.ptr, yv.ld, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), slope,
+             xv.ptr, xv.ld, ws.data_ptr(), ws_bytes, partial.data_ptr(), xv.B, xv.H, xv.W, cin, cout, _stream()),
+          "fsd_first_layer_bwd_accum")
+    dbeta, dgamma, coef = reduce_partials(partial, yv.pixels, cout, scale=scale, want_coef=True, param0=bn.bias,
+                                          param1=bn.weight)
+    if not training:                     # frozen statistics: dy = scale * dt
+        coef[1:].zero_()
+    dw = grad_dst(param, (cout, cin, 3, 3), dev)
+    check(L.fsd_first_layer_bwd_fold(ws.data_ptr(), ws_bytes, coef.data_ptr(), dw.data_ptr(), xv.B, xv.H, xv.W, cin, cout,
+                                     _stream()), "fsd_first_layer_bwd_fold")
+    return dw, dbeta, dgamma
+
+
 def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     """-> (dt View dense (pixels, C), partial [rows][C][2])."""
     L = lib()

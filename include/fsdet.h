@@ -152,6 +152,22 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
                                  void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                  int cout, hipStream_t stream);
 
+/* Whole backward pass of a FIRST conv block (input of <= 4 channels stored as NHWC4, 3x3, BatchNorm, leaky, 2x2 / 2
+ * max pool; height and width even, cout % 32 == 0) in one sweep over its activation: replaces fsd_bn_act_pool_bwd +
+ * fsd_conv3x3_wgrad_c4_bnfused (reference: autograd through darknet_meta.py:219-268 for block 0).  The BatchNorm backward
+ * is affine in dt, so  dW = c1 (S1 - c2 S2 - c3 S3)  with S1 = sum dt x, S2 = sum x, S3 = sum xhat x; _accum forms dt from
+ * (dz, y) on the fly (never written) and emits per-workgroup partials of S1, S2, S3 (workspace) and of (sum dt,
+ * sum dt xhat) (`partial`, [fsd_first_layer_bwd_rows][cout][2], the input of fsd_bn_bwd_finalize); _fold applies the
+ * coefficients fsd_bn_bwd_finalize returns.  dz: gradient w.r.t. the pooled block output (batch, height/2, width/2, cout). */
+int fsd_first_layer_bwd_rows(int batch, int height, int width);
+size_t fsd_first_layer_bwd_workspace_bytes(int batch, int height, int width, int cout);
+int fsd_first_layer_bwd_accum(const float* dz, long long dz_ld, const float* y, long long y_ld, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, float slope, const float* x,
+                              long long x_ld, void* workspace, size_t workspace_bytes, float* partial, int batch,
+                              int height, int width, int cin, int cout, hipStream_t stream);
+int fsd_first_layer_bwd_fold(const void* workspace, size_t workspace_bytes, const float* coef, float* dw_oihw, int batch,
+                             int height, int width, int cin, int cout, hipStream_t stream);
+
 /* Which kernel variants the Winograd entry points will launch for a shape (pure host queries; the parity tests use them
  * to prove that a test shape really exercises a given variant).
  *   fsd_wino_fwd_plan:   plan4 = {BM, BN, dma_staged(0/1), m_tiles} of the batched position GEMM of
@@ -314,6 +330,10 @@ int fsd_conv3x3_wgrad_c4_bnfused_h(const void* dt, long long dt_ld, const void* 
                                    const float* mean, const float* invstd, const float* x, long long x_ld, float* dw_oihw,
                                    void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                    int cout, hipStream_t stream);
+int fsd_first_layer_bwd_accum_h(const void* dz, long long dz_ld, const void* y, long long y_ld, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, float slope, const float* x,
+                                long long x_ld, void* workspace, size_t workspace_bytes, float* partial, int batch,
+                                int height, int width, int cin, int cout, hipStream_t stream);
 int fsd_bn_act_pool_fwd_h(const void* y, long long y_ld, const float* scale, const float* shift, float slope, int pool,
                           void* z, long long z_ld, int batch, int height, int width, int channels, hipStream_t stream);
 /* src / dst each float (flag 0) or bf16 (flag 1) */

@@ -50,6 +50,8 @@ def main():
     batch = int(os.environ.get("FSD_LB_BATCH", "64"))
     global SHAPES
     SHAPES = [(batch,) + s[1:] for s in SHAPES]
+    if os.environ.get("FSD_LB_SWAP") == "1":       # the data-gradient shapes: channel counts swapped
+        SHAPES = [(b, h, w, co, ci, k) for b, h, w, ci, co, k in SHAPES if k == 3 and ci >= 64]
     if os.environ.get("FSD_WINO4") == "0":
         ops.WINOGRAD4 = False
     if os.environ.get("FSD_WINO4_MIN_CH"):
