@@ -19,6 +19,7 @@
 // the window: two are this lane's (top / bottom of column h), two the partner lane's (lane ^ 32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fsdet.h"
 #include "profile.hpp"
 #include "ew_types.hpp"
@@ -29,7 +30,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 using fsd_ew::bf16_t;
 
-constexpr int kCPG = 4;       // cells per load group (16 pixels, 16 MFMAs)
 
 struct FirstBwdArgs {
   const void* dz; const void* y;          // float or bf16 (template parameter); leading dimensions in ELEMENTS
@@ -40,14 +40,16 @@ struct FirstBwdArgs {
   unsigned dz_ld, y_ld, x_ld;
   int H, W, OH, OW, Cout;
   long long cells;
-  int cpw;                                 // cells per wave (multiple of kCPG)
+  int cpw;                                 // cells per wave (multiple of 2 * CPG)
   float slope;
 };
 
 // SIDE = false: 3 input channels, the 27 (tap, ci) columns fit one 32-wide MFMA tile.
 // SIDE = true : 4 input channels, taps 0..7 in the tile and the ninth tap as FMA side sums per lane.
-template <bool SIDE, typename T>
+// CPG = cells per load group (one group of loads is in flight ahead of the MFMAs of the previous one).
+template <bool SIDE, typename T, int CPG>
 __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
+  constexpr int kCPG = CPG;
   constexpr unsigned ES = sizeof(T);
   __shared__ float s_out[4][32 * 36 + 36 + 64];       // per wave: a [32][36] tile, then S2[36], then BN sums [32][2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -296,11 +298,23 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   a.partial = partial;
   a.dz_ld = (unsigned)dz_ld; a.y_ld = (unsigned)y_ld; a.x_ld = (unsigned)x_ld;
   a.H = height; a.W = width; a.OH = height / 2; a.OW = width / 2; a.Cout = cout; a.cells = cells;
-  a.cpw = round_up((int)((cells + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 2 * kCPG);
+  // cells per load group: 1 (92 VGPRs, 5 waves per SIMD) measured fastest on the L0 shape -- 0.91 ms fp32 / 0.94 ms bf16
+  // against 0.92 / 1.03 (2 cells, 108-168 VGPRs) and 0.96 / 1.07 (4 cells); FSD_FB_CPG = 1|2|4 is a tuning aid
+  static const char* env = getenv("FSD_FB_CPG");
+  const int cpg = env ? atoi(env) : 1;
+  a.cpw = round_up((int)((cells + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 8);
   a.slope = slope;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (sizeof(T) * cout * 1.25 + 16.0), stream);
-  if (cin == 4) hipLaunchKernelGGL((first_bwd_kernel<true, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((first_bwd_kernel<false, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  const dim3 grid(blocks, cout / 32);
+  if (cin == 4) {
+    if (cpg == 1) hipLaunchKernelGGL((first_bwd_kernel<true, T, 1>), grid, dim3(256), 0, stream, a);
+    else if (cpg == 4) hipLaunchKernelGGL((first_bwd_kernel<true, T, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((first_bwd_kernel<true, T, 2>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (cpg == 1) hipLaunchKernelGGL((first_bwd_kernel<false, T, 1>), grid, dim3(256), 0, stream, a);
+    else if (cpg == 4) hipLaunchKernelGGL((first_bwd_kernel<false, T, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((first_bwd_kernel<false, T, 2>), grid, dim3(256), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 

@@ -497,12 +497,11 @@ FUSE_FIRST_BWD = os.environ.get("FSD_FUSE_FIRST_BWD", "1") != "0"     # one-swee
 
 def first_bwd_eligible(xv, yv, cout, ksize, pool, dz_full):
     """A first conv block the one-sweep backward takes: NHWC4 input, 3x3, BatchNorm, 2x2/2 max pool, even extents.
-    fp32 storage only: measured on the L0 shape (B = 64, 416x416, 32 channels, tools/probes/first_bwd_time.py) the sweep
-    takes 0.97 ms against 1.31 ms for the unfused sequence in fp32, but 1.08 against 1.07 ms in bf16 mode -- it is bound by
-    its four 64-cycle fp32 MFMAs and ~60 VALU instructions per pooling cell, not by HBM, so halving the bytes buys nothing
-    and the HBM-bound unfused kernels catch up."""
+    Measured on the L0 shape (B = 64, 416x416, 32 channels, tools/probes/first_bwd_time.py): 0.91 ms against 1.28 ms for
+    the unfused sequence in fp32, 0.94 against 1.07 ms in bf16 mode (the sweep is bound by its four 64-cycle fp32 MFMAs
+    and ~60 VALU instructions per pooling cell, not by HBM, so halving the bytes buys it little)."""
     return (FUSE_FIRST_BWD and pool == 1 and dz_full is None and c4_bnfused_eligible(xv, cout, ksize)
-            and xv.H % 2 == 0 and xv.W % 2 == 0 and yv.C == cout and not yv.bf16)
+            and xv.H % 2 == 0 and xv.W % 2 == 0 and yv.C == cout)
 
 
 def first_layer_bwd(dz, yv, scale, shift, mean, invstd, slope, xv, cin, cout, bn, training, param=None):
