@@ -8,6 +8,8 @@ state_dicts and darknet .weights files interchange); the arithmetic runs in engi
 the HIP kernels.  Gradients flow through two autograd nodes (reweighting net, detector) whose
 backward replays the engine tape.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -274,6 +276,13 @@ class Darknet(nn.Module):
         self.seen = 0
         self._det = Network(self.blocks, self.models)
         self._meta = Network(self.learnet_blocks, self.learnet_models)
+        # Inference at the reference's validation batch size (valid_ensemble.py: 2 images per batch) is bound by the ~100
+        # kernel launches of a forward pass, not by the GPU (1.4 ms of host enqueue per batch against 0.3 ms of kernels):
+        # with inference_graphs the eval-mode detect_forward of a (shape, vectors, weights) combination is captured once
+        # into a hipGraph and replayed.  Opt-in (or FSD_INFER_GRAPHS=1): the returned tensor is a fresh copy, but capture
+        # needs a warm-up pass and pins the activation memory of every captured shape.
+        self.inference_graphs = os.environ.get("FSD_INFER_GRAPHS", "0") == "1"
+        self._graphs = {}
 
     def set_compute_dtype(self, dtype):
         """"f32" (default, exact fp32 MFMA) or "bf16" (conv operands in bf16, fp32 accumulate: BASELINE C3/C5)."""
@@ -296,9 +305,40 @@ class Darknet(nn.Module):
         out = _NetFn.apply(self._meta, self.training, len(inputs), False, "meta", bool(_defer), *(inputs + params))
         return [out]
 
+    def _detect_graphed(self, x, vec):
+        """Eval-mode detect_forward through a captured hipGraph (one per input shape / vectors / weight state)."""
+        from .engine import _WEIGHT_EPOCH
+        versions = tuple(p._version for p in self.models.parameters()) + tuple(b._version for b in self.models.buffers())
+        key = (tuple(x.shape), x.device.index, vec.data_ptr(), vec._version, tuple(vec.shape), _WEIGHT_EPOCH[0],
+               self._det.compute_dtype, hash(versions))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 8:                 # each entry pins its activations: keep a handful of shapes
+                self._graphs.pop(next(iter(self._graphs)))
+            static_x = x.detach().clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):                     # warm-up off the capture: packs the weights, primes the allocator
+                    self._det.forward([static_x], dyn=[vec], training=False)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                static_out, _ = self._det.forward([static_x], dyn=[vec], training=False)
+            ent = (graph, static_x, static_out, vec)   # `vec` is kept alive: the graph reads its storage
+            self._graphs[key] = ent
+        graph, static_x, static_out, _ = ent
+        static_x.copy_(x)
+        graph.replay()
+        return static_out.clone()
+
     def detect_forward(self, x, dynamic_weights):
         """Query images + reweighting vectors -> (B*N, A*(5+C), G, G), rows ordered b*N+n."""
         self.loss = None       # the reference clears it here too (darknet_meta.py:134)
+        if (self.inference_graphs and not self.training and not torch.is_grad_enabled() and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 4 and not dynamic_weights[0].requires_grad):
+            return self._detect_graphed(x, dynamic_weights[0])
         params = _flat_params(self.models)
         return _NetFn.apply(self._det, self.training, 1, True, None, False, x, dynamic_weights[0], *params)
 
