@@ -241,27 +241,30 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
   }
 }
 
-// dW[co][ci][ky][kx] = c1 (sum_b S1 - c2 sum_b S2 - c3 sum_b S3): one workgroup per output channel, 4 block lanes x 64
-// column lanes (36 used), fp64 sums in a fixed order.
+// dW[co][ci][ky][kx] = c1 (sum_b S1 - c2 sum_b S2 - c3 sum_b S3): one workgroup per (output channel, 9 of the 36 columns),
+// 28 block lanes x 9 columns, fp64 sums in a fixed order.  (One workgroup per channel with 4 block lanes was a chain of
+// 512 dependent-latency iterations on 32 workgroups: 141 us for 19 MB.)
+constexpr int kFoldLanes = 28, kFoldCols = 9;
 __global__ __launch_bounds__(256) void first_bwd_fold_kernel(const float* __restrict__ ws, const float* __restrict__ ws2,
                                                             const float* __restrict__ coef, float* __restrict__ dw,
                                                             int blocks, int cout, int cin) {
-  __shared__ double s_acc[4][3][36];
-  const int co = blockIdx.x, col = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  if (col < 36) {
+  __shared__ double s_acc[kFoldLanes][3][kFoldCols];
+  const int co = blockIdx.x;
+  const int cl = threadIdx.x % kFoldCols, ry = threadIdx.x / kFoldCols;
+  const int col = blockIdx.y * kFoldCols + cl;
+  if (ry < kFoldLanes) {
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int b = ry; b < blocks; b += 4) {
+    for (int b = ry; b < blocks; b += kFoldLanes) {
       a1 += (double)ws[(((size_t)b * 2 + 0) * cout + co) * 36 + col];
       a3 += (double)ws[(((size_t)b * 2 + 1) * cout + co) * 36 + col];
       a2 += (double)ws2[(size_t)b * 36 + col];
     }
-    s_acc[ry][0][col] = a1; s_acc[ry][1][col] = a2; s_acc[ry][2][col] = a3;
+    s_acc[ry][0][cl] = a1; s_acc[ry][1][cl] = a2; s_acc[ry][2][cl] = a3;
   }
   __syncthreads();
-  if (ry == 0 && col < 36) {
+  if (ry == 0) {
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) { a1 += s_acc[l][0][col]; a2 += s_acc[l][1][col]; a3 += s_acc[l][2][col]; }
+    for (int l = 0; l < kFoldLanes; ++l) { a1 += s_acc[l][0][cl]; a2 += s_acc[l][1][cl]; a3 += s_acc[l][2][cl]; }
     const double c1 = coef[co], c2 = coef[cout + co], c3 = coef[2 * cout + co];
     const int tap = col >> 2, ci = col & 3;
     if (ci < cin) dw[((size_t)co * cin + ci) * 9 + tap] = (float)(c1 * (a1 - c2 * a2 - c3 * a3));
@@ -355,7 +358,7 @@ extern "C" int fsd_first_layer_bwd_fold(const void* workspace, size_t workspace_
   if (workspace_bytes < fsd_first_layer_bwd_workspace_bytes(batch, height, width, cout)) return FSD_ERR_WORKSPACE;
   const int blocks = fb_blocks((long long)batch * height * width / 4);
   const float* ws = reinterpret_cast<const float*>(workspace);
-  hipLaunchKernelGGL(first_bwd_fold_kernel, dim3(cout), dim3(256), 0, stream, ws, ws + (size_t)blocks * 2 * cout * 36, coef,
+  hipLaunchKernelGGL(first_bwd_fold_kernel, dim3(cout, 36 / kFoldCols), dim3(256), 0, stream, ws, ws + (size_t)blocks * 2 * cout * 36, coef,
                      dw_oihw, blocks, cout, cin);
   return (int)hipGetLastError();
 }
