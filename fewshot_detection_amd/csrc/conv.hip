@@ -49,6 +49,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     p.w = static_cast<const float*>(p.w) + (long long)blockIdx.y * p.w_bs;
     p.y += (long long)blockIdx.y * p.y_bs;
   }
+  // (An XCD remap over the flat (batch, tile) id -- each XCD walking whole positions, so that its resident workgroups
+  // share one position's V and U panels -- measured the same time as this per-batch remap on every layer, +-2 %.)
   const int L = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
   const int m0 = p.m_base + mt * BM, n0 = nt * BN;
@@ -392,15 +394,18 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
 // stages) is faster: -10 % at 512 -> 1024, -8 % at 1024 / 1280 -> 1024; at 256 -> 512 @ 26x26 it loses 4 % (measured
 // round 2, tools/layer_bench.py).  FSD_WINO_TILE = a|c|d|e overrides.  'a' 64x64, 'c' 128x128 register-staged,
 // 'd' 128x128 DMA, 'e' 128x64.
-inline char batched_pick(int cin, int cout) {
+// The 128-row tile needs rows to fill it: the reweighting net's last layers have 20-80 tile rows per position (3x3 and
+// 7x7 maps of 20 supports), where a 128-row tile is 84 % padding -- those keep the 64x64 tile (4 launches per step,
+// 75-140 us each with the 128-row tile).
+inline char batched_pick(long long rows, int cin, int cout) {
   static const char* env = getenv("FSD_WINO_TILE");
-  return env ? env[0] : (cin >= 512 && cout >= 512 && cout % 128 == 0 ? 'd' : 'a');
+  return env ? env[0] : (cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a');
 }
 
 }  // namespace
 
 int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
-  const char pick = batched_pick(cin, cout);
+  const char pick = batched_pick(rows, cin, cout);
   const int big = pick == 'c' || pick == 'd';
   const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   if (bm_out) *bm_out = bm;
@@ -423,7 +428,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.Kpad = cin;
   a.nk = cin / kBK;
   a.cpt = cin / kBK;
-  const char pick = batched_pick(cin, cout);
+  const char pick = batched_pick(rows, cin, cout);
   const int big = pick == 'c' || pick == 'd';
   const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   a.m_tiles = (int)((rows + bm - 1) / bm);
