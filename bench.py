@@ -266,7 +266,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="query images per GPU (weak) / per global episode (strong)")
     ap.add_argument("--classes", type=int, default=20, help="episode classes N = support images")
     ap.add_argument("--size", type=int, default=416)
@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
                          "the ranks, supports replicated (SURVEY 8e)")
-    ap.add_argument("--profile-steps", type=int, default=2, help="timed steps that carry the per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=1, help="timed steps that carry the per-kernel HIP events")
     ap.add_argument("--streams", type=int, choices=[0, 1], default=None,
                     help="side HIP streams (reweighting net, weight gradients, target upload beside the main stream); "
                          "default: on unless FSD_STREAMS=0")

@@ -215,7 +215,7 @@ class _NetFn(torch.autograd.Function):
         dyn = [tensors[n_inputs]] if has_dyn else None
         record = any(ctx.needs_input_grad)
         ctx.side = None
-        if side is not None and streams.ENABLED and inputs[0].is_cuda:
+        if side is not None and streams.ENABLED and streams.META and inputs[0].is_cuda:
             main = torch.cuda.current_stream()
             s = streams.side(inputs[0].device, side)
             s.wait_stream(main)               # inputs, and the weights the optimizer just updated on the main stream

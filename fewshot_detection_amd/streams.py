@@ -22,6 +22,8 @@ import os
 import torch
 
 ENABLED = os.environ.get("FSD_STREAMS", "1") != "0"
+META = os.environ.get("FSD_STREAMS_META", "1") != "0"        # the reweighting net on its own stream
+WGRAD = os.environ.get("FSD_STREAMS_WGRAD", "1") != "0"      # the detector's weight gradients on their own stream
 
 _SIDE = {}        # (device index, name) -> torch.cuda.Stream
 _READY = {}       # data_ptr -> event that fires when the tensor stored there is complete
