@@ -161,7 +161,7 @@ def run(net, tape, grad_out, params, wgrad_stream=True):
     wgrad_stream: launch the weight gradients on the "wgrad" side stream (streams.py); the current stream waits for
     them before this returns."""
     ops.require_device(grad_out)
-    ws = streams.side(grad_out.device, "wgrad") if (wgrad_stream and streams.ENABLED) else None
+    ws = streams.side(grad_out.device, "wgrad") if (wgrad_stream and streams.ENABLED and streams.WGRAD) else None
     grads = {}
     pgrads = {}
     grad_dyn = None
