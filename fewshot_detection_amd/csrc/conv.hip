@@ -436,6 +436,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.m_base = 0;
   a.part_base = 0;
   a.batches = batches;
+  a.slope = 1.f;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
@@ -471,8 +472,16 @@ extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize
 extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_packed, const float* bias,
                               float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
                               int cin, int cout, int ksize, int out_nchw, hipStream_t stream) {
+  return fsd_conv2d_fwd_act(x, x_ld, w_packed, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, ksize, out_nchw,
+                            1.f, stream);
+}
+
+extern "C" int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w_packed, const float* bias,
+                                  float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
+                                  int cin, int cout, int ksize, int out_nchw, float slope, hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !w_packed || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
+  if (slope != 1.f && (out_nchw || bn_partial)) return FSD_ERR_UNSUPPORTED;   // activation: NHWC store, no statistics
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
   if (cin < 4 || (cin & 3) || (x_ld & 3) || x_ld < cin) return FSD_ERR_ARG;
   if (!out_nchw && y_ld < cout) return FSD_ERR_ARG;
@@ -500,6 +509,7 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
   a.m_base = 0;
   a.part_base = 0;
   a.batches = 1;
+  a.slope = slope;
   a.x_bs = a.w_bs = a.y_bs = 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;

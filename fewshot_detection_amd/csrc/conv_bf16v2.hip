@@ -48,6 +48,7 @@ struct ConvHArgs {
   int cpt;             // chunks per tap (Cin / BK)
   int Kpad;            // packed weight row stride (elements)
   int m_tiles, n_tiles;
+  float slope;         // leaky slope applied to (acc + bias) before the bf16 store; 1 = linear
 };
 
 
@@ -198,8 +199,11 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-        if (n_ok && m < p.M)
-          *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(acc[i][0][r] + bv0, acc[i][1][r] + bv1);
+        if (n_ok && m < p.M) {
+          float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
+          if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
+          *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(v0, v1);
+        }
       }
     if (p.bn_partial != nullptr) {
       // per-tile column sums of the fp32 accumulators (rows past M are exact zeros: zero-page operands)
@@ -300,7 +304,15 @@ extern "C" int fsd_conv_row_tiles_h(long long pixels) { return (int)((pixels + 1
 extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
                                 long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
                                 int ksize, int out_nchw_f32, hipStream_t stream) {
+  return fsd_conv2d_fwd_act_h(x_bf16, x_ld, w_packed_bf16, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, ksize,
+                              out_nchw_f32, 1.f, stream);
+}
+
+extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
+                                    long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
+                                    int ksize, int out_nchw_f32, float slope, hipStream_t stream) {
   (void)hipGetLastError();
+  if (slope != 1.f && (out_nchw_f32 || bn_partial)) return FSD_ERR_UNSUPPORTED;
   if (!x_bf16 || !w_packed_bf16 || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
   if (cin % 32 || (x_ld & 7) || x_ld < cin) return FSD_ERR_UNSUPPORTED;      // 16-byte DMA pieces of 8 channels
@@ -313,6 +325,7 @@ extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* 
   ConvHArgs a;
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;
   a.bn_partial = bn_partial; a.x_ld = x_ld; a.y_ld = y_ld;
+  a.slope = slope;
   a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
   a.Cout = cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.Kpad = round_up(ksize * ksize * cin, 64);                    // row stride of fsd_pack_conv_weight_bf16

@@ -29,6 +29,7 @@ struct ConvArgs {
   // batched GEMMs (gridDim.y > 1, used by the Winograd path): element strides between the operands of consecutive batches
   long long x_bs, w_bs, y_bs;
   int batches;
+  float slope;   // leaky slope applied to (acc + bias) in the NHWC epilogue; 1 = linear (fsd_conv2d_fwd_act)
 };
 
 // fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)
@@ -61,7 +62,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-          if (n_ok && m < p.M) p.y[(long long)m * p.y_ld + n] = acc[i][j][r] + bv;
+          if (n_ok && m < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (p.slope != 1.f) v = v > 0.f ? v : v * p.slope;      // inference: BatchNorm folded into w / bias, leaky here
+            p.y[(long long)m * p.y_ld + n] = v;
+          }
         }
       }
     }

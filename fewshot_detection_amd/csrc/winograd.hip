@@ -70,10 +70,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
+// leaky activation of (output + bias) for the inference entry point (slope 1 = linear)
+__device__ __forceinline__ f32x4 act4(f32x4 v, float slope) {
+  if (slope != 1.f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * slope;
+  }
+  return v;
+}
+
 // One block: 64 channel groups x 4 tile lanes over `tpb` tiles; writes y and the BN partial sums.
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                          float* __restrict__ y, long long y_ld, float* __restrict__ partial,
-                                                         int H, int W, int TH, int TW, int C, long long T, int tpb) {
+                                                         int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
   __shared__ float s_red[4][64][8];
   const int gl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int g = blockIdx.y * 64 + gl;
@@ -114,11 +123,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         const f32x4 o1 = s[i][1] - s[i][2] - s[i][3];
         const int ox = 2 * tx;
         float* dst = y + ((b * H + oy) * (long long)W + ox) * y_ld + g * 4;
-        st4(dst, o0 + bv);
+        st4(dst, act4(o0 + bv, slope));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s1[k] += o0[k]; s2[k] += o0[k] * o0[k]; }
         if (ox + 1 < W) {
-          st4(dst + y_ld, o1 + bv);
+          st4(dst + y_ld, act4(o1 + bv, slope));
 #pragma unroll
           for (int k = 0; k < 4; ++k) { s1[k] += o1[k]; s2[k] += o1[k] * o1[k]; }
         }
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
 template <int GL>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                           float* __restrict__ y, long long y_ld, float* __restrict__ partial,
-                                                          int H, int W, int TH, int TW, int C, long long T, int tpb) {
+                                                          int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
   constexpr int NPL = 256 / GL;
   __shared__ float s_red[NPL][GL][4];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
@@ -566,7 +575,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (4 * tx + j >= W) continue;
-          st2(dst + j * y_ld, o[i][j] + bv);
+          f32x2 v = o[i][j] + bv;
+          if (slope != 1.f) { v[0] = v[0] > 0.f ? v[0] : v[0] * slope; v[1] = v[1] > 0.f ? v[1] : v[1] * slope; }
+          st2(dst + j * y_ld, v);
           s1 += o[i][j];
           s2 += o[i][j] * o[i][j];
         }
@@ -721,7 +732,16 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
                                     long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
                                     float* v_keep, const float* v_in, int batch, int height, int width, int cin,
                                     int cout, int tile, hipStream_t stream) {
+  return fsd_wino_conv3x3_fwd_act(x, x_ld, u_packed, bias, y, y_ld, bn_partial, workspace, workspace_bytes, v_keep, v_in,
+                                  batch, height, width, cin, cout, tile, 1.f, stream);
+}
+
+extern "C" int fsd_wino_conv3x3_fwd_act(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                                        long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
+                                        float* v_keep, const float* v_in, int batch, int height, int width, int cin,
+                                        int cout, int tile, float slope, hipStream_t stream) {
   (void)hipGetLastError();
+  if (slope != 1.f && bn_partial) return FSD_ERR_UNSUPPORTED;       // statistics are taken from the linear output
   if ((!x && !v_in) || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile))
     return FSD_ERR_ARG;
   if (cin % 32 || (cout & 3) || (y_ld & 3) || y_ld < cout) return FSD_ERR_UNSUPPORTED;
@@ -755,15 +775,15 @@ extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float*
   fsd_prof::Scope prof_out(fsd_prof::kWinoXform, 4.0 * cout * ((double)batch * height * width + (double)P * T), stream);
   if (tile == 2) {
     hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cout / 4 + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                       bn_partial, height, width, TH, TW, cout, T, tpb);
+                       bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
     if (cg <= 32)
       hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb);
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope);
     else
       hipLaunchKernelGGL(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb);
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   }
   return (int)hipGetLastError();
 }

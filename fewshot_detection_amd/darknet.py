@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .cfg import load_conv, load_conv_bn, parse_cfg, print_cfg, save_conv, save_conv_bn
-from .darknet_meta import _NetFn, _flat_params, build_modules
+from .darknet_meta import _apply_net, _flat_params, build_modules
 from .engine import Network
 from .region_loss import RegionLoss
 
@@ -32,7 +32,7 @@ class Darknet(nn.Module):
 
     def forward(self, x):
         self.loss = None
-        return _NetFn.apply(self._net, self.training, 1, False, None, False, x, *_flat_params(self.models))
+        return _apply_net(self._net, self.training, 1, False, None, False, x, *_flat_params(self.models))
 
     def print_network(self):
         print_cfg(self.blocks)

@@ -201,6 +201,14 @@ def build_modules(blocks, region_cls):
 
 
 
+_GRAD_MODE = [True]      # torch.is_grad_enabled() of the caller of _NetFn.apply (set by _apply_net)
+
+
+def _apply_net(*args):
+    _GRAD_MODE[0] = torch.is_grad_enabled()
+    return _NetFn.apply(*args)
+
+
 class _NetFn(torch.autograd.Function):
     """One engine.Network as a single autograd node: inputs (activations, optional reweighting
     vectors, parameters) -> output; backward replays the tape on the HIP kernels.
@@ -213,7 +221,9 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, net, training, n_inputs, has_dyn, side, defer, *tensors):
         inputs = list(tensors[:n_inputs])
         dyn = [tensors[n_inputs]] if has_dyn else None
-        record = any(ctx.needs_input_grad)
+        # a backward pass can only follow if the caller runs with autograd on (inside forward() grad mode is always off,
+        # and under torch.no_grad() needs_input_grad still reports the parameters)
+        record = any(ctx.needs_input_grad) and _GRAD_MODE[0]
         ctx.side = None
         if side is not None and streams.ENABLED and streams.META and inputs[0].is_cuda:
             main = torch.cuda.current_stream()
@@ -302,7 +312,7 @@ class Darknet(nn.Module):
         if mask is None:          # RGB + mask already interleaved per pixel (episode.DeviceAugmenter layout="nhwc4")
             inputs = [metax]
         params = _flat_params(self.learnet_models)
-        out = _NetFn.apply(self._meta, self.training, len(inputs), False, "meta", bool(_defer), *(inputs + params))
+        out = _apply_net(self._meta, self.training, len(inputs), False, "meta", bool(_defer), *(inputs + params))
         return [out]
 
     def _detect_graphed(self, x, vec):
@@ -340,7 +350,7 @@ class Darknet(nn.Module):
                 and x.dtype == torch.float32 and x.dim() == 4 and not dynamic_weights[0].requires_grad):
             return self._detect_graphed(x, dynamic_weights[0])
         params = _flat_params(self.models)
-        return _NetFn.apply(self._det, self.training, 1, True, None, False, x, dynamic_weights[0], *params)
+        return _apply_net(self._det, self.training, 1, True, None, False, x, dynamic_weights[0], *params)
 
     def forward(self, x, metax, mask, ids=None):
         # the reweighting net runs on its own stream beside the detector backbone; the two meet at the fused head

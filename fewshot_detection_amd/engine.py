@@ -72,6 +72,9 @@ class _WeightCache(object):
         return hit[1]
 
 
+FOLD_EVAL_BN = True     # inference: BatchNorm folded into the conv operands, leaky in the conv epilogue (Network._conv_eval)
+
+
 class Network(object):
     """One cfg network (detector or reweighting net) bound to its nn.ModuleList of parameters."""
 
@@ -80,6 +83,7 @@ class Network(object):
         self.models = models
         self.layers = blocks[1:]
         self.cache = _WeightCache()
+        self._folded = {}             # id(conv.weight) -> (tag, folded weight, folded bias): eval-mode BatchNorm folds
         # "f32": exact fp32 MFMA, fp32 activations.  "bf16" (BASELINE configs[2] / [4]): activations and their gradients are
         # STORED in HBM as bfloat16, convolutions run bf16 x bf16 -> fp32 on the bf16 matrix cores, BatchNorm statistics come
         # from the fp32 accumulators; loss, parameter gradients, master weights and the optimizer stay fp32.
@@ -147,6 +151,60 @@ class Network(object):
         y = ops.cast_view(yf, torch.bfloat16, out=out)
         return y, partial
 
+    def _fold_bn(self, conv, bn):
+        """Eval-mode BatchNorm as part of the convolution: w' = w * gamma / sqrt(var + eps) per output channel,
+        bias' = beta - mean * gamma / sqrt(var + eps) (+ the conv's own bias scaled).  Rebuilt when any of the five
+        tensors changes (versions / the weight epoch of raw-pointer updates)."""
+        tag = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
+            (conv.weight.data_ptr(), _WEIGHT_EPOCH[0])
+        hit = self._folded.get(id(conv.weight))
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+                wf = (conv.weight.detach() * scale.view(-1, 1, 1, 1)).contiguous()
+                bf = bn.bias.detach() - bn.running_mean.detach() * scale
+                if conv.bias is not None:
+                    bf = bf + conv.bias.detach() * scale
+                bf = bf.contiguous()
+            if hit is not None:          # keep the tensor objects (the packed-operand cache is keyed by them)
+                hit[1].copy_(wf)
+                hit[2].copy_(bf)
+                wf, bf = hit[1], hit[2]
+            hit = (tag, wf, bf)
+            self._folded[id(conv.weight)] = hit
+        return hit[1], hit[2]
+
+    def _conv_eval(self, ind, xv, conv, bn, k, cout, slope, pool, wino, first, bufs, tape):
+        """Inference form of a conv + BatchNorm + leaky (+ max pool) block: one launch without a pool (the activation is
+        in the conv epilogue), two with one -- instead of conv, statistics -> scale / shift, affine + leaky + pool."""
+        dev = xv.t.device
+        wf, bf = self._fold_bn(conv, bn)
+        tapped = pool and ind in self.tapped
+        full = self._dest(ind, xv.B, xv.H, xv.W, cout, dev, bufs) if (not pool or tapped) else None
+        if first:
+            # first-layer kernel: linear output, the (always present) pool pass applies the leaky
+            y, _ = ops.conv3x3_c4(xv, wf, cout, bias=bf, out_dtype=self.act_dtype)
+            act = ops.bn_act_pool(y, None, None, slope, 0, out=full) if full is not None else None
+            z = ops.bn_act_pool(y, None, None, slope, pool, out=self._dest(ind + 1, xv.B, xv.H // 2 if pool == 1 else xv.H,
+                                                                            xv.W // 2 if pool == 1 else xv.W, cout, dev, bufs)) \
+                if pool else act
+        else:
+            if wino:
+                act, _ = ops.conv3x3_wino(xv, self.cache.get(wf, 0, "wino%d" % wino), cout, bias=bf, out=full, tile=wino,
+                                          slope=slope)
+            elif self.compute_dtype == "bf16":
+                act, _ = ops.conv2d(xv, self.cache.get(wf, 0, "bf16"), cout, k, bias=bf, out=full, slope=slope)
+            else:
+                act, _ = ops.conv2d(xv, self.cache.get(wf, 0, "f32"), cout, k, bias=bf, out=full, slope=slope,
+                                    cin_true=conv.weight.shape[1])
+            if pool:                     # leaky is monotonic: max pool of the activated tensor = activated max pool
+                OH, OW = (xv.H // 2, xv.W // 2) if pool == 1 else (xv.H, xv.W)
+                z = ops.bn_act_pool(act, None, None, 1.0, pool, out=self._dest(ind + 1, xv.B, OH, OW, cout, dev, bufs))
+            else:
+                z = act
+        tape.append(dict(kind="conv_eval", ind=ind))
+        return z, (act if tapped else None)
+
     def _conv(self, ind, blk, xv, training, pool, bufs, tape):
         seq = self.models[ind]
         conv = seq[0]
@@ -163,6 +221,9 @@ class Network(object):
         bf16 = self.compute_dtype == "bf16"
         wino = 0 if bf16 else ops.wino_tile(xv.C, cout, k, xv.H, xv.W)
         first = not wino and not xv.bf16 and ops.c4_bnfused_eligible(xv, cout, k)   # NHWC4 input: direct-operand first-layer kernel
+        if (FOLD_EVAL_BN and bn is not None and not training and not self._record
+                and (not bf16 or (xv.bf16 and xv.C % 32 == 0 and cout % 2 == 0 and xv.c0 % 8 == 0) or first)):
+            return self._conv_eval(ind, xv, conv, bn, k, cout, slope, pool, wino, first, bufs, tape)
         wp = self.cache.get(conv.weight, 0, "wino%d" % wino) if wino else None
         dev = xv.t.device
         input_cast = False

@@ -167,8 +167,9 @@ def pack_weight_wino(w, mode=0, tile=2):
     return out
 
 
-def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None, tile=2, v_in=None):
+def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep_v=None, tile=2, v_in=None, slope=1.0):
     """Winograd F(tile x tile, 3x3) convolution of an NHWC view; same results/contract as conv2d(ksize=3).
+    slope != 1: y = leaky(conv + bias) (inference form, no statistics).
     keep_v: a list; the transformed input is appended to it (kept for the weight gradient).
     v_in: an already transformed input (wino_grad_transforms); xv then only supplies the geometry."""
     L = lib()
@@ -187,9 +188,9 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     if keep_v is not None:
         v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C, tile), dtype=torch.float32, device=dev)
         keep_v.append(v)
-    check(L.fsd_wino_conv3x3_fwd(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                                 ws.data_ptr(), ws_bytes, _ptr(v), _ptr(v_in), xv.B, xv.H, xv.W, xv.C, cout, tile,
-                                 _stream()), "fsd_wino_conv3x3_fwd")
+    check(L.fsd_wino_conv3x3_fwd_act(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+                                     ws.data_ptr(), ws_bytes, _ptr(v), _ptr(v_in), xv.B, xv.H, xv.W, xv.C, cout, tile,
+                                     float(slope), _stream()), "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
@@ -229,12 +230,13 @@ PROFILE = None      # bench.py sets this to a list, one entry per conv launch (f
                     # Per-KERNEL timing is the library's job (fsd_profile_enable / fsd_profile_collect).
 
 
-def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None):
-    """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out)."""
+def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None, slope=1.0):
+    """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out).
+    slope != 1: y = leaky(conv + bias) (inference form: NHWC store, no statistics)."""
     dev = xv.t.device
     partial = None
     if xv.bf16:
-        return _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out)
+        return _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope)
     if nchw_out:
         y = torch.empty((xv.B, cout, xv.H, xv.W), dtype=torch.float32, device=dev)
         y_ptr, y_ld = y.data_ptr(), 0
@@ -249,8 +251,9 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().fsd_conv2d_fwd(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
-                               xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, _stream()), "fsd_conv2d_fwd")
+    check(lib().fsd_conv2d_fwd_act(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+                                   xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()),
+          "fsd_conv2d_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
@@ -258,7 +261,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     return y, partial
 
 
-def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out):
+def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=1.0):
     """bf16 storage mode: bf16 NHWC activations x packed bf16 weights -> bf16 NHWC (or float NCHW for the head)."""
     L = lib()
     dev = xv.t.device
@@ -278,8 +281,8 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.fsd_conv2d_fwd_h(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial), xv.B, xv.H, xv.W,
-                             xv.C, cout, ksize, 1 if nchw_out else 0, _stream()), "fsd_conv2d_fwd_h")
+    check(L.fsd_conv2d_fwd_act_h(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial), xv.B, xv.H, xv.W,
+                                 xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()), "fsd_conv2d_fwd_h")
     if PROFILE is not None:
         e1.record()
         fl = 2.0 * ksize * ksize * xv.C * cout * xv.pixels

@@ -152,6 +152,21 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
                                  void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
                                  int cout, hipStream_t stream);
 
+/* Inference forms of the three convolution entry points: y = leaky_slope(conv(x) + bias), NHWC store, no BatchNorm
+ * statistics.  With eval-mode BatchNorm folded into the operands (w * scale per output channel, bias = shift) one launch
+ * replaces conv + fsd_bn_finalize + fsd_bn_act_pool_fwd of a block without max pool (reference: conv / BatchNorm2d(eval) /
+ * LeakyReLU modules, darknet_meta.py:236-256).  slope = 1 is exactly the plain entry point. */
+int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w_packed, const float* bias, float* y, long long y_ld,
+                       float* bn_partial, int batch, int height, int width, int cin, int cout, int ksize, int out_nchw,
+                       float slope, hipStream_t stream);
+int fsd_wino_conv3x3_fwd_act(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                             long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
+                             const float* v_in, int batch, int height, int width, int cin, int cout, int tile, float slope,
+                             hipStream_t stream);
+int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
+                         long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout, int ksize,
+                         int out_nchw_f32, float slope, hipStream_t stream);
+
 /* Whole backward pass of a FIRST conv block (input of <= 4 channels stored as NHWC4, 3x3, BatchNorm, leaky, 2x2 / 2
  * max pool; height and width even, cout % 32 == 0) in one sweep over its activation: replaces fsd_bn_act_pool_bwd +
  * fsd_conv3x3_wgrad_c4_bnfused (reference: autograd through darknet_meta.py:219-268 for block 0).  The BatchNorm backward

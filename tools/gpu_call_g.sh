@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-for v in 0 1 0 1 0 1; do FSD_WINO_DY_ON_SIDE=$v timeout 300 python bench.py --steps 20 --warmup 8 --profile-steps 0 --no-cpu-baseline --no-extras --no-parity 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('f32 dy_on_side=$v', d['ms_per_step'])"; done
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_inference.py tests/test_gpu_graphs.py tests/test_gpu_kernels.py tests/test_gpu_bf16.py -q -p no:cacheprovider -x 2>&1 | tail -12
+timeout 300 python tools/probes/inference_time.py 2>&1 | grep -v "amdgpu.ids\|class_scale"
