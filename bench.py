@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
                          "the ranks, supports replicated (SURVEY 8e)")
-    ap.add_argument("--profile-steps", type=int, default=1, help="timed steps that carry the per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=2, help="timed steps that carry the per-kernel HIP events")
     ap.add_argument("--streams", type=int, choices=[0, 1], default=None,
                     help="side HIP streams (reweighting net, weight gradients, target upload beside the main stream); "
                          "default: on unless FSD_STREAMS=0")
@@ -382,28 +382,36 @@ def main():
     # record is a barrier packet in the queue and a few hundred of them per step cost ~1 ms of the step.
     # The profiled steps run on ONE stream: with the side streams a kernel shares the chip with the launches of the other
     # strands and its duration says how the chip was shared, not how good the kernel is.  They are part of the timed
-    # region (the headline therefore includes a few un-overlapped steps); ms_per_step_unprofiled is the rest.
+    # region (the headline therefore includes a few un-overlapped steps); ms_per_step_unprofiled is the rest ...
     prof_steps = min(args.steps, args.profile_steps) if rank == 0 else 0
+    # ... and they sit in the MIDDLE of the timed region: the first step after the fence runs at ramping clocks (its
+    # kernels measured 6-8 % slower than the same kernels a few steps later)
+    prof_lo = (args.steps - prof_steps) // 2
+    prof_hi = prof_lo + prof_steps
     prof = []
-    t_mid = None
+    t_a = t_b = None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == 0 and prof_steps:
+        if i == prof_lo and prof_steps:
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
             ops.PROFILE = prof
             ops.kernel_profile(True)
             streams.ENABLED = False
-        elif i == prof_steps and prof_steps:
+        elif i == prof_hi and prof_steps:
             ops.PROFILE = None
             ops.kernel_profile(False)
             streams.ENABLED = streams_on
             torch.cuda.synchronize()
-            t_mid = time.perf_counter()
+            t_b = time.perf_counter()
         loss = step()
     ops.PROFILE = None
     ops.kernel_profile(False)
     streams.ENABLED = streams_on
     fence()
     t_end = time.perf_counter()
+    if prof_steps and t_b is None:           # the profiled steps were the last ones
+        t_b = t_end
     elapsed = t_end - t0
     gc.enable()
     if dist is not None:
@@ -458,7 +466,7 @@ def main():
             "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
                     "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
                     "its own duration, HIP events recorded by the library right around every launch on the launch stream "
-                    "during the first `profiled_steps` timed steps, which run on one stream (no side-stream overlap: a "
+                    "during `profiled_steps` steps in the middle of the timed region, which run on one stream (no side-stream overlap: a "
                     "kernel's duration in isolation); avg_kernel_ms is what rocprofv3 --kernel-trace --stats shows for this "
                     "kernel under `bench.py --streams 0` (profiles/)",
             "profiled_steps": prof_steps,
@@ -514,9 +522,10 @@ def main():
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
                                 "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
                         "profiled_steps_on_one_stream": prof_steps,
-                        "ms_per_step_unprofiled": ((t_end - t_mid) / (args.steps - prof_steps) * 1e3
-                                                   if t_mid is not None and args.steps > prof_steps else None),
-                        "ms_per_step_profiled": ((t_mid - t0) / prof_steps * 1e3 if t_mid is not None else None)},
+                        "profiled_step_index": [prof_lo, prof_hi] if prof_steps else None,
+                        "ms_per_step_unprofiled": (((t_a - t0) + (t_end - t_b)) / (args.steps - prof_steps) * 1e3
+                                                   if t_a is not None and args.steps > prof_steps else None),
+                        "ms_per_step_profiled": ((t_b - t_a) / prof_steps * 1e3 if t_a is not None else None)},
         }
         if opt is not None:
             res["dp"] = {"world_size": opt.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
