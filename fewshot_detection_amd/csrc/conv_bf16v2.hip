@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
   static_assert(BK == 64 || BK == 32, "k-chunk of 64 or 32 bf16");
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
-  static_assert(TN == 2, "a wave owns one even/odd pair of 32-channel accumulators");
+  static_assert(TN == 2 || (TN == 1 && WAVES_N == 1 && !NCHW_F32_OUT),
+                "a wave owns one even/odd pair of 32-channel accumulators, or (32-channel outputs) a single one");
   constexpr int LPR = BK / 8;                 // lanes (16-byte groups) per tile row
   constexpr int RPP = 256 / LPR;              // tile rows staged per pass of the workgroup
   constexpr int RPW = 64 / LPR;               // ... per wave instruction
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
 #pragma unroll
   for (int j = 0; j < B_PER_T; ++j) {
     const int r = r0 + RPP * j;
-    const int ch = (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1);
+    const int ch = TN == 2 ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;      // TN = 1: rows in channel order
     wrow[j] = p.w + (long long)(n0 + ch) * p.Kpad + g_src * 8;
   }
   const unsigned x_ld = (unsigned)p.x_ld;
@@ -187,7 +188,28 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
 
   // ---- epilogue ----
   const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
-  if constexpr (!NCHW_F32_OUT) {
+  if constexpr (!NCHW_F32_OUT && TN == 1) {
+    // 32 output channels (the data gradient of a 32-channel layer): lane l holds channel l of 16 pixel rows.  Lane pairs
+    // swap one value per register pair so that the even lane stores channels (l, l+1) of row R(r) and the odd lane
+    // channels (l-1, l) of row R(r+1): 4-byte stores, 64 contiguous bytes per pixel row, no statistics (launcher).
+    const int n = n0 + c_lane;
+    const bool odd = lane & 1;
+    const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+    u16* yb = static_cast<u16*>(p.y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float a = acc[i][0][r] + bv, b = acc[i][0][r + 1] + bv;
+        if (p.slope != 1.f) { a = a > 0.f ? a : a * p.slope; b = b > 0.f ? b : b * p.slope; }
+        const float got = __shfl_xor(odd ? a : b, 1, 64);
+        const int rr = odd ? r + 1 : r;
+        const int m = m0 + (wm * TM + i) * 32 + (rr & 3) + 8 * (rr >> 2) + r_lane;
+        const int nn = odd ? n - 1 : n;
+        if (nn < p.Cout && m < p.M)                                       // Cout is even (launcher)
+          *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + nn) = odd ? pack2(got, b) : pack2(a, got);
+      }
+  } else if constexpr (!NCHW_F32_OUT) {
     // lane l holds channels 2l (accumulator 0) and 2l+1 (accumulator 1) of its wave's 64-channel block
     const int n = n0 + wn * 64 + 2 * c_lane;
     const bool n_ok = n < p.Cout;                                   // Cout is even (launcher)
@@ -272,10 +294,14 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
   const dim3 grid(a.m_tiles * a.n_tiles), block(256);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.nk * BK), stream);
   if (nchw) {
-    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+    if constexpr (BN >= 64) {
+      auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+    } else {
+      return FSD_ERR_UNSUPPORTED;
+    }
   } else {
     auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -339,6 +365,12 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   a.cpt = cin / bk;
   a.m_tiles = (int)((pixels + 127) / 128);
   const bool nchw = out_nchw_f32 != 0;
+  static const char* n32_env = getenv("FSD_CONV_H_N32");          // tuning aid: 0 disables the 32-channel tile
+  if (!nchw && cout <= 32 && !bn_partial && bk == 64 && !(n32_env && n32_env[0] == '0')) {
+    // 32 output channels (data gradient of the 32 -> 64 layer at 208x208): a 64-wide tile would issue twice the MFMAs
+    a.n_tiles = 1;
+    return launch_conv<128, 32, 64, 4, 1>(a, false, stream);
+  }
   if (!nchw && narrow_tile(pixels, cout)) {
     a.n_tiles = (cout + 63) / 64;
     return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);

@@ -43,6 +43,9 @@ def _nchw(v):
     (3, 9, 7, 96, 36, 3, True),          # Cin = 96 -> BK = 32; ragged M (189 rows) and N (36 channels)
     (2, 13, 13, 1280, 1024, 3, False),   # L29: 8 column tiles, K = 11520
     (5, 6, 6, 1024, 1024, 3, False),     # the 6x6 support maps
+    (2, 26, 20, 64, 32, 3, False),       # 32 output channels: the 128x32 tile (data gradient of the 32 -> 64 layer)
+    (3, 9, 7, 128, 30, 1, True),         # ... ragged: 30 channels, 189 rows, bias
+    (1, 16, 16, 64, 32, 3, True),
 ])
 def test_conv_bf16_dma_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin, cout, k, bias):
     from fewshot_detection_amd import ops
