@@ -630,14 +630,19 @@ int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int
 inline int wgrad_h_splits(long long pixels, int tiles) {
   const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
   int s;
-  if (tiles >= 256) {
+  static const char* env = getenv("FSD_WGRAD_H_SPLITS");          // tuning aid: force the split count of the many-tile case
+  if (tiles >= 256 && env && atoi(env) > 0) {
+    s = atoi(env);
+  } else if (tiles >= 256) {
     // many tiles: few splits, chosen so that the last round of the 512 resident workgroups (2 per CU) is well filled;
-    // every split is one more workspace slice for the fold kernel to read (+3 % per split, measured)
+    // every split is one more workspace slice for the fold kernel to read.  The weight per split is fitted to the sweep of
+    // round 2 (tools/layer_bench.py wgrad, bf16, FSD_WGRAD_H_SPLITS): with 0.03 the 576-tile layers (1024 -> 1024) took 6
+    // splits and 0.423 ms; 0.06 gives them 4 (0.340 ms) and leaves 288 tiles at 5 (0.190 ms) and 720 tiles at 2 (0.41 ms).
     double best = 1e30;
     s = 1;
     for (int c = 1; c <= 8; ++c) {
       const double wgs = (double)tiles * c, rounds = (double)((long long)((wgs + 511) / 512));
-      const double cost = rounds / (wgs / 512.0) * (1.0 + 0.03 * c);
+      const double cost = rounds / (wgs / 512.0) * (1.0 + 0.06 * c);
       if (cost < best - 1e-9) { best = cost; s = c; }
     }
   } else {
