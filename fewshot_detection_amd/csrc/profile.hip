@@ -64,3 +64,45 @@ extern "C" int fsd_profile_collect(double* ms, double* work, long long* launches
   }
   return rc;
 }
+
+// ---- clock probe: the shader clock the chip sustains under matrix-core load, from a dependent MFMA chain ------------
+// One wave per SIMD issues `iters` x 16 dependent v_mfma_f32_32x32x2_f32 (64 cycles each, MI355X_MICROARCH.md): the chain
+// takes iters * 16 * 64 cycles whatever the memory system does, so cycles / elapsed time is the clock.  bench.py records
+// it next to the roofline (the fp32 MFMA peak of 157.3 TFLOP/s is quoted at 2.4 GHz; under sustained fp32 MFMA load the
+// chip runs at 2.0-2.3 GHz) and uses it to notice a throttled GPU before it times anything.
+namespace {
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void clock_probe_kernel(float* out, int iters) {
+  f32x16p acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float a = 1.0f + 1e-6f * threadIdx.x, b = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  float v = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v += acc[r];
+  if (v == 123.456f) out[0] = v;          // never true: keeps the chain alive
+}
+}  // namespace
+
+extern "C" int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!scratch || !mhz_out || iters < 1) return FSD_ERR_ARG;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FSD_ERR_ARG;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1024), dim3(64), 0, stream, scratch, 64);        // warm the clocks up
+  (void)hipEventRecord(e0, stream);
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1024), dim3(64), 0, stream, scratch, iters);
+  (void)hipEventRecord(e1, stream);
+  float ms = 0.f;
+  int rc = (int)hipGetLastError();
+  if (rc == 0 && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = FSD_ERR_ARG;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != 0 || ms <= 0.f) return rc ? rc : FSD_ERR_ARG;
+  *mhz_out = (double)iters * 16.0 * 64.0 / (ms * 1e-3) / 1e6;
+  return 0;
+}

@@ -632,3 +632,12 @@ def kernel_profile_collect():
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
     check(lib().fsd_profile_collect(ms, work, cnt, n), "fsd_profile_collect")
     return {PROFILE_CLASSES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n)}
+
+
+def clock_probe_mhz(device, iters=2000):
+    """Shader clock (MHz) the GPU sustains under matrix-core load (a dependent-MFMA chain on every SIMD, ~1 ms)."""
+    import ctypes as C
+    scratch = torch.zeros(4, dtype=torch.float32, device=device)
+    mhz = C.c_double(0.0)
+    check(lib().fsd_clock_probe(scratch.data_ptr(), int(iters), C.byref(mhz), _stream()), "fsd_clock_probe")
+    return float(mhz.value)

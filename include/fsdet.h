@@ -407,6 +407,9 @@ int fsd_augment_batch(const unsigned char* src, const long long* img_off, const 
 void fsd_profile_enable(int on);
 int fsd_profile_num_classes(void);
 int fsd_profile_collect(double* ms, double* work, long long* launches, int n_classes);
+/* Shader clock (MHz) sustained under matrix-core load: one wave per SIMD runs iters x 16 dependent 64-cycle fp32 MFMAs;
+ * synchronises.  scratch: any device buffer of >= 4 bytes (never written). */
+int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stream);
 
 const char* fsd_version(void);
 

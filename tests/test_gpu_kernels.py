@@ -436,3 +436,11 @@ def test_plain_decode_vs_reference_golden(dev, k):
     assert flat.shape == ref.shape
     assert np.array_equal(flat[:, 0], ref[:, 0]) and np.array_equal(flat[:, 7], ref[:, 7])
     assert np.allclose(flat[:, 1:7], ref[:, 1:7], rtol=1e-5, atol=1e-6)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(dev):
+    """fsd_clock_probe: a dependent fp32-MFMA chain of known length (64 cycles per instruction) timed with HIP events."""
+    from fewshot_detection_amd import ops
+    mhz = [ops.clock_probe_mhz(dev) for _ in range(3)]
+    assert all(500.0 < v < 3000.0 for v in mhz), mhz
+    assert max(mhz) / min(mhz) < 1.5, mhz
