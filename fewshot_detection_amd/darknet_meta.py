@@ -316,30 +316,32 @@ class Darknet(nn.Module):
         return [out]
 
     def _detect_graphed(self, x, vec):
-        """Eval-mode detect_forward through a captured hipGraph (one per input shape / vectors / weight state)."""
+        """Eval-mode detect_forward through a captured hipGraph (one per input shape / vector count / weight state).
+        The graph reads its images and its reweighting vectors from static buffers that every call refreshes, so callers
+        may pass new tensors each time (valid_ensemble.py re-uses one set of averaged vectors, others recompute them)."""
         from .engine import _WEIGHT_EPOCH
         versions = tuple(p._version for p in self.models.parameters()) + tuple(b._version for b in self.models.buffers())
-        key = (tuple(x.shape), x.device.index, vec.data_ptr(), vec._version, tuple(vec.shape), _WEIGHT_EPOCH[0],
-               self._det.compute_dtype, hash(versions))
+        key = (tuple(x.shape), x.device.index, tuple(vec.shape), _WEIGHT_EPOCH[0], self._det.compute_dtype, hash(versions))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 8:                 # each entry pins its activations: keep a handful of shapes
                 self._graphs.pop(next(iter(self._graphs)))
-            static_x = x.detach().clone()
+            static_x, static_vec = x.detach().clone(), vec.detach().clone()
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(2):                     # warm-up off the capture: packs the weights, primes the allocator
-                    self._det.forward([static_x], dyn=[vec], training=False)
+                    self._det.forward([static_x], dyn=[static_vec], training=False)
             cur.wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), torch.no_grad():
-                static_out, _ = self._det.forward([static_x], dyn=[vec], training=False)
-            ent = (graph, static_x, static_out, vec)   # `vec` is kept alive: the graph reads its storage
+                static_out, _ = self._det.forward([static_x], dyn=[static_vec], training=False)
+            ent = (graph, static_x, static_vec, static_out)
             self._graphs[key] = ent
-        graph, static_x, static_out, _ = ent
+        graph, static_x, static_vec, static_out = ent
         static_x.copy_(x)
+        static_vec.copy_(vec.detach())
         graph.replay()
         return static_out.clone()
 

@@ -28,12 +28,14 @@ def test_graphed_inference_equals_eager(dev, tmp_path, dtype):
                 out = net.detect_forward(x, vecs)
                 assert torch.equal(out, ref)
         assert len(net._graphs) == 2               # one per input shape
-        # new vectors, and new weights after load_weights-style in-place updates: fresh captures, fresh results
+        # new vectors re-use the captured graph (it reads a static copy); new weights after load_weights-style in-place
+        # updates need a fresh capture: fresh results either way
         vecs2 = [torch.rand(5, 1024, 1, 1, device=dev)]
         net.inference_graphs = False
         ref2 = net.detect_forward(xs[0], vecs2).clone()
         net.inference_graphs = True
         assert torch.equal(net.detect_forward(xs[0], vecs2), ref2)
+        assert len(net._graphs) == 2
         conv0 = net.models[0][0]
         conv0.weight.mul_(1.5)                     # bumps the parameter's version
         net.inference_graphs = False
