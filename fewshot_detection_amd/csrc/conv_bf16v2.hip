@@ -627,7 +627,11 @@ int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int
   return (int)hipGetLastError();
 }
 
-inline int wgrad_h_splits(long long pixels, int tiles) {
+inline int wgrad_h_kc(long long pixels);
+// workgroups of the weight-gradient kernel resident on the chip at a time, for the tile wgrad_h_tiles picks
+inline int wgrad_h_resident(int bm, int bn, long long pixels) { return (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64) ? 512 : 1536; }
+
+inline int wgrad_h_splits(long long pixels, int tiles, int resident) {
   const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
   int s;
   static const char* env = getenv("FSD_WGRAD_H_SPLITS");          // tuning aid: force the split count of the many-tile case
@@ -646,7 +650,14 @@ inline int wgrad_h_splits(long long pixels, int tiles) {
       if (cost < best - 1e-9) { best = cost; s = c; }
     }
   } else {
-    s = (1024 + tiles - 1) / tiles;                   // few tiles: ~4 workgroups per CU
+    // few tiles: exactly ONE round of co-resident workgroups (`resident`: 512 for the 64-pixel-chunk 128x128 kernel with its
+    // 64 KB of LDS, 1536 for the others), rounded DOWN so that no handful of workgroups spills into a second round.
+    // Sweep of round 2 (tools/layer_bench.py wgrad, bf16, FSD_WGRAD_H_TARGET = 512 / 1024 / 1536, repeatable to 1 %):
+    //   104x104 64->128 0.229 / 0.277 / 0.303 ms    52x52 128->256 0.192 / 0.211 / 0.219 ms       (64-pixel chunks)
+    //   26x26 256->512  0.210 / 0.233 / 0.193 ms    208x208 32->64 0.481 / 0.325 / 0.311 ms       (32-pixel chunks)
+    static const char* env_t = getenv("FSD_WGRAD_H_TARGET");      // tuning aid
+    const int target = env_t && atoi(env_t) > 0 ? atoi(env_t) : resident;
+    s = target / tiles;
   }
   if (s > max_s) s = (int)max_s;
   return s < 1 ? 1 : s > 1024 ? 1024 : s;
@@ -688,7 +699,7 @@ extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int 
   const int ncols = ksize * ksize * cin;
   wgrad_h_tiles(cout, ncols, &bm, &bn);
   const int tiles = ((cout + bm - 1) / bm) * ((ncols + bn - 1) / bn);
-  const int splits = wgrad_h_splits((long long)batch * height * width, tiles);
+  const int splits = wgrad_h_splits((long long)batch * height * width, tiles, wgrad_h_resident(bm, bn, (long long)batch * height * width));
   return (size_t)(splits + wgrad_h_fold_extra_slices(splits)) * cout * ksize * ksize * cin * sizeof(float);
 }
 
@@ -713,7 +724,7 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   wgrad_h_tiles(cout, ncols, &bm, &bn);
   a.m_tiles = (cout + bm - 1) / bm;
   a.n_tiles = (ncols + bn - 1) / bn;
-  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles);
+  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles, wgrad_h_resident(bm, bn, pixels));
   const bool kc64 = bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64;
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kc64 ? 64 : 32);
   int rc;
