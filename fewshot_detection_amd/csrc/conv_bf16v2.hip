@@ -684,12 +684,12 @@ int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
 
 // pixels per k-chunk of the 128 x 128 tile: 64 (two LDS stages of 32 KB, still two workgroups per CU, half the barriers)
 // on the large maps.  Measured at B = 64 (tools/layer_bench.py wgrad, bf16): 104x104 64->128 0.331 -> 0.280 ms, 52x52
-// 128->256 0.251 -> 0.227 ms; 26x26 and 13x13 (<= 43k pixels, few chunks per split) lose 2-4 %, so they keep 32.
+// 128->256 0.251 -> 0.227 ms; 13x13 (11 k pixels, few chunks per split) loses 4-7 %, so it keeps 32.
 // FSD_WGRAD_H_KC=32|64 forces one (tuning aid).
 inline int wgrad_h_kc(long long pixels) {
   static const char* env = getenv("FSD_WGRAD_H_KC");
   if (env) return atoi(env) == 32 ? 32 : 64;
-  return pixels >= 131072 ? 64 : 32;
+  return pixels >= 32768 ? 64 : 32;       // with the one-round split rule 26x26 (43 k pixels) gains too: 0.207 -> 0.189 ms
 }
 
 }  // namespace
