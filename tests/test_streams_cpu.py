@@ -1,0 +1,57 @@
+"""Host-side bookkeeping of fewshot_detection_amd/streams.py (no GPU): who waits for what."""
+import types
+
+import torch
+
+from fewshot_detection_amd import streams
+
+
+class _FakeStream(object):
+    def __init__(self):
+        self.waited = []
+
+    def wait_event(self, ev):
+        self.waited.append(ev)
+
+
+def test_publish_then_await_makes_the_reader_wait_exactly_once(monkeypatch):
+    cur = _FakeStream()
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: cur)
+    streams._READY.clear()
+    t = torch.zeros(4)
+    ev = object()
+    streams.publish(t, ev)
+    view = t[:2]                                   # same storage address: the reader may hold a view
+    assert streams.await_tensor(view) is True and cur.waited == [ev]
+    assert streams.await_tensor(t) is False and cur.waited == [ev]          # consumed: nothing left to wait for
+    other = _FakeStream()
+    streams.publish(t, ev)
+    assert streams.await_tensor(t, other) is True and other.waited == [ev] and cur.waited == [ev]
+
+
+def test_unclaimed_events_do_not_pile_up():
+    streams._READY.clear()
+    keep = [torch.zeros(1) for _ in range(200)]
+    for t in keep:
+        streams.publish(t, object())
+    assert len(streams._READY) <= 65
+
+
+def test_keep_alive_ignores_host_tensors_and_none():
+    rec = types.SimpleNamespace(calls=0)
+    streams.keep_alive(rec, None, torch.zeros(2))              # CPU tensors have no stream to record: no call, no error
+    assert rec.calls == 0
+
+
+def test_switches_follow_the_environment(monkeypatch):
+    import importlib
+    monkeypatch.setenv("FSD_STREAMS", "0")
+    monkeypatch.setenv("FSD_STREAMS_WGRAD", "0")
+    mod = importlib.reload(streams)
+    try:
+        assert mod.ENABLED is False and mod.WGRAD is False and mod.META is True
+    finally:
+        monkeypatch.delenv("FSD_STREAMS")
+        monkeypatch.delenv("FSD_STREAMS_WGRAD")
+        importlib.reload(streams)
+    assert streams.ENABLED is True and streams.WGRAD is True
