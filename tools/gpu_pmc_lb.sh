@@ -5,7 +5,7 @@ R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r02p"; mkdir -p "$O"; export TMPDIR=/tmp;
 what=${1:-fwd}
 pmc() { local name=$1; local ctr=$2
   rm -rf "$O/$name"
-  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/$name" -o run -- python "$R/tools/layer_bench.py" $what > "$O/$name.log" 2>&1
+  timeout 90 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/$name" -o run -- python "$R/tools/layer_bench.py" $what > "$O/$name.log" 2>&1
   echo "$name rc=$?"; }
 pmc p1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"
 pmc p2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES"

@@ -46,7 +46,7 @@ def main():
                 keys.append(k)
     print(",".join(keys))
     for r in rows[:40]:
-        print(",".join(("%.4g" % r[k]) if isinstance(r.get(k), float) else str(r.get(k, "")) for k in keys))
+        print(",".join(("%.4g" % r[k]) if isinstance(r.get(k), float) else '"%s"' % r.get(k, "") for k in keys))
 
 
 if __name__ == "__main__":
