@@ -421,10 +421,12 @@ inline int first_blocks(long long pixels) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 inline int pick_splits(long long pixels, int tiles) {
+  // Two rounds of the 1536 co-resident 64x64 workgroups (6 per CU), rounded DOWN so that the launch does not spill a few
+  // workgroups into a third round.  Measured round 2 (tools/layer_bench.py wgrad; 2048 rounded up -> 3072 rounded down):
+  // 208x208 32->64 1.487 -> 1.403 ms, 104x104 0.671 -> 0.663, 52x52 0.425 -> 0.423, 26x26 0.382 -> 0.375.
   static const char* env = getenv("FSD_WGRAD_TARGET");          // tuning aid: target number of 64x64 workgroups
-  // 2048 (measured round 2: within 1 % of 4096 / 8192 on the 3x3 layers, 13 % faster on the short 1x1 reductions)
-  const int target = env && atoi(env) > 0 ? atoi(env) : 2048;
-  int s = (target + tiles - 1) / tiles;
+  const int target = env && atoi(env) > 0 ? atoi(env) : 3072;
+  int s = target / tiles;
   const long long max_s = (pixels + 255) / 256;      // at least 8 k-chunks per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
