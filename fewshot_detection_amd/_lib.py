@@ -22,6 +22,7 @@ PROTOTYPES = {
     "fsd_region_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "fsd_region_loss_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p,
                                      _f, _f, _f, _f, _f, _ll, _i, _i, _i, _p, _p]),
+    "fsd_region_build_targets": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _f, _f, _ll, _i, _p]),
     "fsd_region_decode": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _f, _i, _i, _i, _p]),
     "fsd_region_nms": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "fsd_packed_weight_elems": (_sz, [_i, _i, _i]),

@@ -190,7 +190,9 @@ def run(net, tape, grad_out, params, wgrad_stream=True):
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach(), param=head.weight)
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn
-            if streams.ENABLED:          # the reweighting net's backward (its own stream) may start as soon as this exists
+            # the reweighting net's backward (its own stream) may start as soon as this exists; published only when the
+            # vectors really came from a network that ran on a side stream (otherwise nobody would ever claim the event)
+            if streams.ENABLED and streams.META and streams.from_side(dyn):
                 streams.publish(d_dyn, torch.cuda.current_stream().record_event())
             if head.bias is not None:
                 dst = ops.grad_dst(head.bias, (o_ch,), g.t.device)

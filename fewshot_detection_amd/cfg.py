@@ -163,6 +163,22 @@ cfg.config_meta = _configure_meta
 cfg.config_net = _configure_net
 
 
+def load_classes(data="voc"):
+    """Class names of a dataset (reference cfg.py:11-17 reads data/<name>.names next to the module; the two lists the
+    reference ships are built in here, any other name is looked up as a .names file in the working directory's data/)."""
+    if data in ("voc", "coco"):
+        return list(cfg[data + "_classes"])
+    with open(path.join("data", "{}.names".format(data))) as fh:
+        return [ln.strip() for ln in fh.readlines()]
+
+
+# the reference's module-level helper names (cfg.py:7, 41-68)
+__C = cfg
+get_novels = _novel_classes
+get_ids = _few_shot_ids
+add_backup = _suffix_first
+
+
 def parse_cfg(cfgfile):
     """Darknet .cfg -> list of blocks (dicts of strings); see reference cfg.py:198-228."""
     blocks, cur = [], None
@@ -256,6 +272,21 @@ def load_conv(buf, start, conv_model):
     if conv_model.bias is not None:
         start = _pull(buf, start, conv_model.bias)
     return _pull(buf, start, conv_model.weight)
+
+
+def load_convfromcoco(buf, start, conv_model):
+    """Initialise a 20-class VOC head (5 anchors x 25) from the 80-class COCO head stored in the stream (5 x 85 rows
+    of 1024 weights): the box/objectness rows and the VOC classes' rows of every anchor (reference cfg.py:419-435)."""
+    rows = np.concatenate([np.arange(5), np.asarray(cfg.vocids_in_coco) + 5])
+    rows = np.concatenate([rows + a * 85 for a in range(5)])
+    if conv_model.bias is not None:
+        conv_model.bias.data.copy_(torch.from_numpy(buf[start:start + 425][rows].copy()))
+        start += 425
+    w = buf[start:start + 425 * 1024].reshape(425, 1024, 1, 1)[rows]
+    conv_model.weight.data.copy_(torch.from_numpy(w.copy()))
+    from .engine import bump_weight_epoch
+    bump_weight_epoch()
+    return start + 425 * 1024
 
 
 def save_conv(fp, conv_model):

@@ -24,6 +24,7 @@ struct RegionArgs {
   int* img_count;          // (images, A, H, W) how many kept rows claim the cell
   float* img_tcls;         // (images, A, H, W) sum of their class targets
   float* dbg;              // optional 9 x (kept, A, H, W): coord,conf,cls masks, tx,ty,tw,th,tconf,tcls
+  const float* pred;       // kFromPred only: decoded boxes (rows*A*H*W, 4) = [x, y, w, h] in grid cells
   long long dbg_stride;
   int rows, rows_per_image, A, C, H, W, L, max_boxes;
   int early;               // seen < 12800
@@ -68,7 +69,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// One workgroup per (image, class) row.
+// One workgroup per (image, class) row.  kFromPred: the standalone build_targets (region_loss.py:37-132) -- boxes come
+// decoded from the caller, only the nine target tensors and nGT / nCorrect are produced (no loss, no gradient).
+template <bool kFromPred>
 __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HW = p.H * p.W;
@@ -82,11 +85,12 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
   const long long row_off = (long long)row * p.A * chans * HW;
-  const float* o = p.out + row_off;
-  float* g = p.grad + row_off;
-  const int kept = p.keep[row];
+  const float* o = kFromPred ? nullptr : p.out + row_off;
+  float* g = kFromPred ? nullptr : p.grad + row_off;
+  const int kept = kFromPred ? row : p.keep[row];
+  const float* pr = kFromPred ? p.pred + (long long)row * cells * 4 : nullptr;
 
-  if (kept < 0) {                 // dropped by neg_filter: no box/objectness gradient
+  if (!kFromPred && kept < 0) {   // dropped by neg_filter: no box/objectness gradient
     for (int c = tid; c < cells; c += kThreads) {
       int a = c / HW, hw = c - a * HW;
       float* ga = g + (long long)a * chans * HW + hw;
@@ -130,11 +134,17 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
     } else {
       const int cell = best_n * HW + gj * p.W + gi;
       atomicMax(&s_owner[cell], tid);
-      const float* oc = o + (long long)best_n * chans * HW + gj * p.W + gi;
-      const double px = (double)(sigmoidf_(oc[0]) + (float)gi);
-      const double py = (double)(sigmoidf_(oc[HW]) + (float)gj);
-      const double pw = (double)(expf(oc[2 * HW]) * (float)p.aw[best_n]);
-      const double ph = (double)(expf(oc[3 * HW]) * (float)p.ah[best_n]);
+      double px, py, pw, ph;
+      if (kFromPred) {
+        const float* pc = pr + (long long)cell * 4;
+        px = (double)pc[0]; py = (double)pc[1]; pw = (double)pc[2]; ph = (double)pc[3];
+      } else {
+        const float* oc = o + (long long)best_n * chans * HW + gj * p.W + gi;
+        px = (double)(sigmoidf_(oc[0]) + (float)gi);
+        py = (double)(sigmoidf_(oc[HW]) + (float)gj);
+        pw = (double)(expf(oc[2 * HW]) * (float)p.aw[best_n]);
+        ph = (double)(expf(oc[3 * HW]) * (float)p.ah[best_n]);
+      }
       if (iou_f64(gx, gy, gw, gh, px, py, pw, ph) > 0.5) acc[7] += 1.0;
     }
     acc[6] += 1.0;
@@ -148,12 +158,19 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
   for (int c = tid; c < cells; c += kThreads) {
     const int a = c / HW, hw = c - a * HW;
     const int j = hw / p.W, i = hw - j * p.W;
-    const float* oc = o + (long long)a * chans * HW + hw;
-    float* gc = g + (long long)a * chans * HW + hw;
-    const float ox = oc[0], oy = oc[HW], ow = oc[2 * HW], oh = oc[3 * HW], ocf = oc[4 * HW];
-    const float x = sigmoidf_(ox), y = sigmoidf_(oy), conf = sigmoidf_(ocf);
-    const float px = x + (float)i, py = y + (float)j;
-    const float pw = expf(ow) * (float)p.aw[a], ph = expf(oh) * (float)p.ah[a];
+    float ow = 0.f, oh = 0.f, x = 0.f, y = 0.f, conf = 0.f, px, py, pw, ph;
+    float* gc = nullptr;
+    if (kFromPred) {
+      const float* pc = pr + (long long)c * 4;
+      px = pc[0]; py = pc[1]; pw = pc[2]; ph = pc[3];
+    } else {
+      const float* oc = o + (long long)a * chans * HW + hw;
+      gc = g + (long long)a * chans * HW + hw;
+      ow = oc[2 * HW]; oh = oc[3 * HW];
+      x = sigmoidf_(oc[0]); y = sigmoidf_(oc[HW]); conf = sigmoidf_(oc[4 * HW]);
+      px = x + (float)i; py = y + (float)j;
+      pw = expf(ow) * (float)p.aw[a]; ph = expf(oh) * (float)p.ah[a];
+    }
 
     float best = 0.0f;
     for (int t = 0; t < n_sil; ++t) {
@@ -178,10 +195,13 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
       th = (float)log(gh / p.ah[a]);
       tconf = (float)iou_f64(gx, gy, gw, gh, (double)px, (double)py, (double)pw, (double)ph);
       tcls = p.zero_tcls ? 0.0f : (float)s_gt[t * 5];
-      atomicAdd(&p.img_count[(long long)img * cells + c], 1);
-      atomicAdd(&p.img_tcls[(long long)img * cells + c], tcls);
+      if (!kFromPred) {
+        atomicAdd(&p.img_count[(long long)img * cells + c], 1);
+        atomicAdd(&p.img_tcls[(long long)img * cells + c], tcls);
+      }
     }
 
+    if (!kFromPred) {
     // 0.5 * sum((pred*mask - target*mask)^2), written like the reference's MSELoss operands
     const float dx = x * coord_mask - tx * coord_mask;
     const float dy = y * coord_mask - ty * coord_mask;
@@ -198,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void region_rows_kernel(RegionArgs p) {
     gc[2 * HW] = p.coord_scale * dw * coord_mask;
     gc[3 * HW] = p.coord_scale * dh * coord_mask;
     gc[4 * HW] = dc * sq * (conf * (1.0f - conf));
+    }
 
     if (dbg) {
       dbg[c] = coord_mask;                    dbg[p.dbg_stride + c] = conf_mask;
@@ -342,7 +363,7 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
   // algorithmic bytes of the loss: head output read once, its gradient written once, the float64 targets read once
   const double io_bytes = 2.0 * 4.0 * rows * (double)num_anchors * (5 + num_classes) * height * width + 8.0 * rows * (double)target_len;
   fsd_prof::Scope prof(fsd_prof::kRegion, io_bytes, stream);
-  hipLaunchKernelGGL(region_rows_kernel, dim3(rows), dim3(kThreads), lds, stream, p);
+  hipLaunchKernelGGL(region_rows_kernel<false>, dim3(rows), dim3(kThreads), lds, stream, p);
 
   int groups, n_logits;
   long long stride;
@@ -356,6 +377,34 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
   hipLaunchKernelGGL(region_class_kernel, dim3((groups + kThreads - 1) / kThreads), dim3(kThreads), 0,
                      stream, p, groups, n_logits, stride);
   hipLaunchKernelGGL(region_finalize_kernel, dim3(1), dim3(1), 0, stream, p.stats, loss_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_region_build_targets(const float* pred_boxes, const double* target, float* targets_out,
+                                        double* stats, int rows, int num_anchors, int height, int width,
+                                        int target_len, const double* anchors_host, float noobject_scale,
+                                        float object_scale, float thresh, long long seen, int max_boxes,
+                                        hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!pred_boxes || !target || !targets_out || !stats || !anchors_host) return FSD_ERR_ARG;
+  if (num_anchors < 1 || num_anchors > kMaxAnchors || rows < 1) return FSD_ERR_ARG;
+  RegionArgs p = {};
+  p.pred = pred_boxes; p.target = target; p.dbg = targets_out; p.stats = stats;
+  const int cells = num_anchors * height * width;
+  p.rows = rows; p.rows_per_image = 1; p.A = num_anchors; p.C = 0; p.H = height; p.W = width; p.L = target_len;
+  p.max_boxes = max_boxes < kMaxGT ? max_boxes : kMaxGT;
+  p.early = seen < 12800 ? 1 : 0;
+  p.coord_scale = 1.f; p.noobject_scale = noobject_scale; p.object_scale = object_scale; p.class_scale = 1.f;
+  p.thresh = thresh;
+  for (int a = 0; a < num_anchors; ++a) { p.aw[a] = anchors_host[2 * a]; p.ah[a] = anchors_host[2 * a + 1]; }
+  p.dbg_stride = (long long)rows * cells;
+  hipError_t e = hipMemsetAsync(stats, 0, FSD_REGION_STATS * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  size_t lds = kMaxGT * 5 * sizeof(double) + (size_t)cells * sizeof(int) + 4 * sizeof(int) +
+               9 * (kThreads / 64) * sizeof(double);
+  lds = (lds + 15) & ~(size_t)15;
+  if (lds > 64 * 1024) return FSD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(region_rows_kernel<true>, dim3(rows), dim3(kThreads), lds, stream, p);
   return (int)hipGetLastError();
 }
 

@@ -5,8 +5,10 @@ import torch
 import torch.nn as nn
 
 from .cfg import load_conv, load_conv_bn, parse_cfg, print_cfg, save_conv, save_conv_bn
-from .darknet_meta import _apply_net, _flat_params, build_modules
+from .darknet_meta import (EmptyModule, MaxPoolStride1, Reorg, _apply_net, _flat_params,  # noqa: F401  (the reference's
+                           build_modules)                                                 # darknet.py defines them too)
 from .engine import Network
+from .pooling import GlobalAvgPool2d  # noqa: F401
 from .region_loss import RegionLoss
 
 

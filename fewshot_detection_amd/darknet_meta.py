@@ -103,6 +103,17 @@ class EmptyModule(nn.Module):
         return x
 
 
+class Reshape(nn.Module):
+    """View (B, ...) as (B, *shape) (darknet_meta.py:38-44; no shipped cfg instantiates it)."""
+
+    def __init__(self, *args):
+        super(Reshape, self).__init__()
+        self.shape = args
+
+    def forward(self, x):
+        return x.view(x.size(0), *self.shape)
+
+
 def maybe_repeat(x1, x2):
     """Batch-align two tensors by repeating the smaller one per class (darknet_meta.py:16-35)."""
     n1, n2 = x1.size(0), x2.size(0)
@@ -234,6 +245,7 @@ class _NetFn(torch.autograd.Function):
                 done = s.record_event()
             streams.keep_alive(s, *inputs)
             streams.keep_alive(main, out)
+            streams.mark_side_output(out)
             if defer:
                 streams.publish(out, done)
             else:
@@ -319,9 +331,13 @@ class Darknet(nn.Module):
         """Eval-mode detect_forward through a captured hipGraph (one per input shape / vector count / weight state).
         The graph reads its images and its reweighting vectors from static buffers that every call refreshes, so callers
         may pass new tensors each time (valid_ensemble.py re-uses one set of averaged vectors, others recompute them)."""
-        from .engine import _WEIGHT_EPOCH
+        from .engine import _STATS_EPOCH, _WEIGHT_EPOCH
+        # the vectors may still be in flight on the "meta" side stream (forward() defers the wait to the first reader,
+        # which on the eager path is the fused head): every read below is on the current stream, so wait here
+        streams.await_tensor(vec)
         versions = tuple(p._version for p in self.models.parameters()) + tuple(b._version for b in self.models.buffers())
-        key = (tuple(x.shape), x.device.index, tuple(vec.shape), _WEIGHT_EPOCH[0], self._det.compute_dtype, hash(versions))
+        key = (tuple(x.shape), x.device.index, tuple(vec.shape), _WEIGHT_EPOCH[0], _STATS_EPOCH[0], self._det.compute_dtype,
+               hash(versions))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 8:                 # each entry pins its activations: keep a handful of shapes

@@ -12,25 +12,50 @@ from torch.nn.modules.utils import _pair
 from . import ops
 
 
+class _ConvNd(nn.Module):
+    """Parameter-free convolution base with torch's conv attributes and repr (dynamic_conv.py:10-76): the kernel of a
+    dynamic convolution arrives with the input, so `weight` / `bias` are registered as None."""
+
+    partial = None
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, transposed, output_padding,
+                 groups, bias):
+        super(_ConvNd, self).__init__()
+        if in_channels % groups != 0:
+            raise ValueError("in_channels must be divisible by groups")
+        if out_channels % groups != 0:
+            raise ValueError("out_channels must be divisible by groups")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.transposed, self.output_padding, self.groups = transposed, output_padding, groups
+        self.register_parameter("weight", None)
+        self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        pass
+
+    def extra_repr(self):
+        s = "{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}"
+        if self.padding != (0,) * len(self.padding):
+            s += ", padding={padding}"
+        if self.dilation != (1,) * len(self.dilation):
+            s += ", dilation={dilation}"
+        if self.groups != 1:
+            s += ", groups={groups}"
+        return s.format(**self.__dict__) + ", bias=False"
+
+
 def dynamic_conv2d(is_first, partial=None):
     if partial is not None:
         raise NotImplementedError("partial dynamic convolution is not used by any shipped cfg")
     if not is_first:
         raise NotImplementedError("only the first dynamic convolution of a network is supported")
 
-    class DynamicConv2d(nn.Module):
+    class DynamicConv2d(_ConvNd):
         def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
                      groups=1, bias=False):
-            super(DynamicConv2d, self).__init__()
-            self.in_channels = in_channels
-            self.out_channels = out_channels
-            self.kernel_size = _pair(kernel_size)
-            self.stride = _pair(stride)
-            self.padding = _pair(padding)
-            self.dilation = _pair(dilation)
-            self.groups = groups
-            self.register_parameter("weight", None)     # parameter-free, like the reference
-            self.register_parameter("bias", None)
+            super(DynamicConv2d, self).__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
+                                                _pair(padding), _pair(dilation), False, _pair(0), groups, bias)
 
         def forward(self, inputs):
             x, w = inputs

@@ -42,6 +42,15 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+_STATS_EPOCH = [0]
+
+
+def bump_stats_epoch():
+    """A training-mode BatchNorm finalize rewrote running_mean / running_var through raw pointers (no version bump):
+    eval-mode folds of those statistics (and hipGraphs captured over them) must be rebuilt."""
+    _STATS_EPOCH[0] += 1
+
+
 class _WeightCache(object):
     """Packed (K-major) copies of conv weights, refreshed when the parameter changes."""
 
@@ -156,7 +165,7 @@ class Network(object):
         bias' = beta - mean * gamma / sqrt(var + eps) (+ the conv's own bias scaled).  Rebuilt when any of the five
         tensors changes (versions / the weight epoch of raw-pointer updates)."""
         tag = tuple(t._version for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + \
-            (conv.weight.data_ptr(), _WEIGHT_EPOCH[0])
+            (conv.weight.data_ptr(), _WEIGHT_EPOCH[0], _STATS_EPOCH[0])
         hit = self._folded.get(id(conv.weight))
         if hit is None or hit[0] != tag:
             with torch.no_grad():

@@ -327,6 +327,9 @@ def bn_finalize(partial, count, bn, training):
                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), momentum, bn.eps,
                                 1 if training else 0, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(),
                                 buf[3].data_ptr(), _ptr(ws), _stream()), "fsd_bn_finalize")
+    if training:
+        from .engine import bump_stats_epoch
+        bump_stats_epoch()               # running statistics changed behind torch's version counters
     return buf[0], buf[1], buf[2], buf[3]
 
 

@@ -36,6 +36,58 @@ def neg_filter_indices(target_rows):
     return [i for i, p in enumerate(pos) if p or not (random() > ratio)]
 
 
+def neg_filter(pred_boxes, target, withids=False):
+    """The reference's function (region_loss.py:15-34) on tensors: drop negative (image, class) rows with probability
+    1 - neg_ratio * n_pos / n_neg.  `pred_boxes` / `target`: tensors with one leading row per (image, class)."""
+    assert pred_boxes.size(0) == target.size(0)
+    t = target.detach()
+    inds = neg_filter_indices(t.reshape(t.size(0), -1).cpu().numpy())
+    if len(inds) != target.size(0):
+        idx = torch.as_tensor(inds, dtype=torch.long)
+        pred_boxes, target = pred_boxes[idx.to(pred_boxes.device)], target[idx.to(target.device)]
+    return (pred_boxes, target, inds) if withids else (pred_boxes, target)
+
+
+def build_targets(pred_boxes, target, anchors, num_anchors, num_classes, nH, nW, noobject_scale, object_scale,
+                  sil_thresh, seen):
+    """The reference's function (region_loss.py:37-132) on the device: decoded boxes (rows*A*H*W, 4) in grid cells +
+    float64 targets (rows, 250) -> nGT, nCorrect, coord_mask, conf_mask, cls_mask, tx, ty, tw, th, tconf, tcls, each
+    (rows, A, H, W) float32 on the boxes' device.  RegionLoss[V2].forward does not call it (the fused loss kernel builds
+    the same targets from the raw head output); it exists for callers that used the function directly."""
+    ops.require_device(pred_boxes)
+    rows = target.size(0)
+    if pred_boxes.shape != (rows * num_anchors * nH * nW, 4):
+        raise ValueError("pred_boxes must be (rows*A*H*W, 4)")
+    if len(anchors) // num_anchors != 2:
+        raise NotImplementedError("anchor_step != 2 is not used by any shipped cfg")
+    tr = np.ascontiguousarray(target.detach().cpu().reshape(rows, -1).numpy(), dtype=np.float64)
+    _validate_targets(tr)
+    dev = pred_boxes.device
+    pb = pred_boxes.detach().contiguous().float()
+    tgt = torch.from_numpy(tr).to(dev)
+    out = torch.empty((9, rows, num_anchors, nH, nW), dtype=torch.float32, device=dev)
+    stats = torch.empty(16, dtype=torch.float64, device=dev)
+    anc = np.ctypeslib.as_ctypes(np.asarray(anchors, dtype=np.float64)[:2 * num_anchors].copy())
+    check(lib().fsd_region_build_targets(pb.data_ptr(), tgt.data_ptr(), out.data_ptr(), stats.data_ptr(), rows,
+                                         num_anchors, nH, nW, tr.shape[1], anc, float(noobject_scale),
+                                         float(object_scale), float(sil_thresh), int(seen), int(cfg.max_boxes),
+                                         torch.cuda.current_stream().cuda_stream), "fsd_region_build_targets")
+    s = stats.tolist()
+    if s[9] > 0:
+        raise ValueError("build_targets: %d ground-truth entries had no matching anchor or left the grid" % int(s[9]))
+    return (int(s[6]), int(s[7])) + tuple(out[k] for k in range(9))
+
+
+def select_classes(pred, tgt, ids):
+    """Rows of `pred` whose label is one of `ids` (not the first), restricted to those columns, with the labels
+    renumbered by position in `ids` (region_loss.py:369-378; only referenced from commented-out code there)."""
+    t = tgt.detach().cpu().numpy()
+    new_tgt = np.max(np.stack([(t == d) * i for i, d in enumerate(ids)]), axis=0)
+    idx = np.argwhere(new_tgt > 0).reshape(-1)
+    sel = torch.as_tensor(idx, dtype=torch.long, device=pred.device)
+    return pred[sel][:, list(ids)], new_tgt[idx]
+
+
 def _validate_targets(rows, n_labels=None):
     """The reference raises (math.log domain error / bad index) on these; say why instead.
     n_labels: number of valid class ids (rows per image for the meta loss, num_classes for v1); a label outside

@@ -18,6 +18,7 @@ stream are handed to the caching allocator with record_stream so their memory is
 FSD_STREAMS=0 (or streams.ENABLED = False) runs everything on the current stream.
 """
 import os
+import threading
 
 import torch
 
@@ -26,7 +27,9 @@ META = os.environ.get("FSD_STREAMS_META", "1") != "0"        # the reweighting n
 WGRAD = os.environ.get("FSD_STREAMS_WGRAD", "1") != "0"      # the detector's weight gradients on their own stream
 
 _SIDE = {}        # (device index, name) -> torch.cuda.Stream
-_READY = {}       # data_ptr -> event that fires when the tensor stored there is complete
+_READY = {}       # (device index, data_ptr) -> event that fires when the tensor stored there is complete (insertion-ordered)
+_LOCK = threading.Lock()
+_MAX_READY = 64
 
 
 def side(device, name):
@@ -39,20 +42,47 @@ def side(device, name):
     return s
 
 
+def _key(t):
+    return (t.device.index if t.is_cuda else -1, t.data_ptr())
+
+
 def publish(t, event):
     """`t` was produced on another stream; whoever reads it first calls await_tensor(t)."""
-    if len(_READY) > 64:          # entries nobody claimed (an exception between publish and use): drop them
-        _READY.clear()
-    _READY[t.data_ptr()] = event
+    with _LOCK:
+        _READY.pop(_key(t), None)
+        _READY[_key(t)] = event
+        # entries nobody claimed (an exception between publish and use, a consumer that never ran): evict the OLDEST
+        # ones only -- a blanket clear could drop another thread's live entry and turn its wait into a silent race
+        while len(_READY) > _MAX_READY:
+            _READY.pop(next(iter(_READY)))
 
 
 def await_tensor(t, stream=None):
     """Make `stream` (default: the current one) wait for the producer of `t`, if one was published.  -> bool."""
-    ev = _READY.pop(t.data_ptr(), None)
+    with _LOCK:
+        ev = _READY.pop(_key(t), None)
     if ev is None:
         return False
     (stream or torch.cuda.current_stream()).wait_event(ev)
     return True
+
+
+_FROM_SIDE = {}   # (device index, data_ptr) of the latest outputs computed on a side stream (bounded, insertion-ordered)
+
+
+def mark_side_output(t):
+    """Remember that `t` came out of a network that ran on a side stream (its backward will run there too and can
+    start as soon as d(t) exists: backward.py publishes d(t) only for such tensors)."""
+    with _LOCK:
+        _FROM_SIDE.pop(_key(t), None)
+        _FROM_SIDE[_key(t)] = True
+        while len(_FROM_SIDE) > 16:
+            _FROM_SIDE.pop(next(iter(_FROM_SIDE)))
+
+
+def from_side(t):
+    with _LOCK:
+        return _key(t) in _FROM_SIDE
 
 
 def keep_alive(stream, *tensors):

@@ -71,6 +71,17 @@ int fsd_region_loss_fwd_bwd(const float* output, const double* target, const int
                             float class_scale, float thresh, long long seen, int max_boxes,
                             int softmax_over_rows, int zero_tcls, float* dbg_targets, hipStream_t stream);
 
+/* Standalone build_targets (region_loss.py:37-132) for callers that hold DECODED boxes, as the reference's public
+ * function does: IoU silence in float32, anchor matching and tconf in double, "later box wins" per cell.
+ *   pred_boxes  (rows*A*H*W, 4) fp32: [x, y, w, h] in grid cells, cell order (row, anchor, y, x)
+ *   target      (rows, target_len) float64, zero-terminated on cx
+ *   targets_out 9 planes of (rows, A, H, W) floats: coord_mask, conf_mask, cls_mask, tx, ty, tw, th, tconf, tcls
+ *   stats       FSD_REGION_STATS doubles (device): [FSD_STAT_NGT], [FSD_STAT_NCORRECT], [FSD_STAT_BAD_TARGET] */
+int fsd_region_build_targets(const float* pred_boxes, const double* target, float* targets_out, double* stats,
+                             int rows, int num_anchors, int height, int width, int target_len,
+                             const double* anchors_host, float noobject_scale, float object_scale, float thresh,
+                             long long seen, int max_boxes, hipStream_t stream);
+
 /* Inference-side decode = utils.get_region_boxes_v2 (utils.py:195-290; softmax_over_rows = 1) or
  * utils.get_region_boxes (softmax_over_rows = 0): per (row, anchor, cell) sigmoid/exp decode, class
  * confidence, threshold, and compaction of the survivors on the device.

@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE: the two reference drivers the north star names, spelled for python 3 / torch 2 and written against
+the BARE module names (`from darknet_meta import Darknet`, `from utils import *`, `from cfg import parse_cfg, cfg`), i.e.
+what a maintainer's train_meta.py / valid_ensemble.py look like after the py2 idioms are modernised and
+fewshot_detection_amd/compat is put on PYTHONPATH.  The statement order follows the reference:
+
+  train()  <- train_meta.py:26-64 (options), :85-99 (model, loss, seen), :123-163 (lr factor, SGD, adjust_learning_rate),
+              :165-226 (per-epoch loaders, the loop body: forward, `region_loss.seen += B`, loss, backward, step)
+  valid()  <- valid_ensemble.py:13-178 (support-set ensembling :76-100, detect_forward :137-146, decode :148,
+              per-image NMS + result lines :156-178)
+
+The data side (`dataset.listDataset` / `dataset.MetaDataset`) is a parameter: the reference's dataset.py / image.py are
+not on the GPU box, so tests/test_gpu_drivers.py passes loaders that replay the batches the reference's own loaders
+produced when tests/golden/drivers_golden.py ran the ORIGINAL driver sources (the results of that run are the goldens
+this file's output is compared with).  Nothing here is shipped.
+"""
+import os
+
+import torch
+import torch.optim as optim
+
+from cfg import cfg, parse_cfg                       # noqa: E402  (bare names: resolved through compat/)
+from darknet_meta import Darknet                     # noqa: E402
+from utils import *                                  # noqa: E402,F401,F403
+
+
+def train(datacfg, darknetcfg, learnetcfg, weightfile, make_loaders, device, max_epochs=None):
+    """Returns (model, region_loss, optimizer, losses, lrs).  make_loaders(epoch, model) -> (train_loader, metaloader)."""
+    darknetcfg, learnetcfg = parse_cfg(darknetcfg), parse_cfg(learnetcfg)
+    data_options = read_data_cfg(datacfg)            # noqa: F405
+    net_options, meta_options = darknetcfg[0], learnetcfg[0]
+    cfg.config_data(data_options)
+    cfg.config_meta(meta_options)
+    cfg.config_net(net_options)
+    batch_size = int(net_options["batch"])
+    max_batches = int(net_options["max_batches"])
+    learning_rate = float(net_options["learning_rate"])
+    momentum, decay = float(net_options["momentum"]), float(net_options["decay"])
+    steps = [float(s) for s in net_options["steps"].split(",")]
+    scales = [float(s) for s in net_options["scales"].split(",")]
+
+    torch.manual_seed(1234)
+    model = Darknet(darknetcfg, learnetcfg)
+    region_loss = model.loss
+    model.load_weights(weightfile)
+    region_loss.seen = model.seen
+    processed_batches = 0 if cfg.tuning else int(model.seen) // batch_size
+
+    factor = {"full": 15.0, 1: 3.0, 0: 1.5, 5: 8.0}.get(cfg.neg_ratio, float(len(cfg.base_classes)))
+    learning_rate /= factor
+    model = model.to(device)
+    optimizer = optim.SGD(model.parameters(), lr=learning_rate / batch_size, momentum=momentum, dampening=0,
+                          weight_decay=decay * batch_size * factor)
+
+    def adjust_learning_rate(optimizer, batch):
+        lr = learning_rate
+        for i in range(len(steps)):
+            scale = scales[i] if i < len(scales) else 1
+            if batch >= steps[i]:
+                lr = lr * scale
+                if batch == steps[i]:
+                    break
+            else:
+                break
+        for group in optimizer.param_groups:
+            group["lr"] = lr / batch_size
+        return lr
+
+    losses, lrs = [], []
+    epoch = 0
+    while max_epochs is None or epoch < max_epochs:
+        loaders = make_loaders(epoch, model)
+        if loaders is None:
+            break
+        train_loader, metaloader = loaders
+        metaloader = iter(metaloader)
+        adjust_learning_rate(optimizer, processed_batches)
+        model.train()
+        for batch_idx, (data, target) in enumerate(train_loader):
+            metax, mask = next(metaloader)
+            lrs.append(adjust_learning_rate(optimizer, processed_batches))
+            processed_batches += 1
+            data, metax, mask = data.to(device), metax.to(device), mask.to(device)       # target stays on the host
+            optimizer.zero_grad()
+            output = model(data, metax, mask)
+            region_loss.seen = region_loss.seen + data.size(0)
+            loss = region_loss(output, target)
+            loss.backward()
+            optimizer.step()
+            losses.append(float(loss))
+        epoch += 1
+        if epoch % cfg.save_interval == 0:
+            model.seen = epoch * len(train_loader.dataset)
+    return dict(model=model, region_loss=region_loss, optimizer=optimizer, losses=losses, lrs=lrs,
+                adjust_learning_rate=adjust_learning_rate, processed_batches=processed_batches)
+
+
+def valid(datacfg, darknetcfg, learnetcfg, weightfile, outfile, dataset, device, result_root="results"):
+    """`dataset`: a module-like object with listDataset(...) / MetaDataset(...) like the reference's dataset.py."""
+    options = read_data_cfg(datacfg)                 # noqa: F405
+    valid_images, metadict = options["valid"], options["meta"]
+    ckpt = weightfile.split("/")[-1].split(".")[0]
+    backup = weightfile.split("/")[-2]
+    prefix = os.path.join(result_root, backup.split("/")[-1] + "/ene" + ckpt)
+
+    m = Darknet(darknetcfg, learnetcfg)
+    m.load_weights(weightfile)
+    m.to(device)
+    m.eval()
+
+    valid_dataset = dataset.listDataset(valid_images, shape=(m.width, m.height), shuffle=False)
+    valid_loader = torch.utils.data.DataLoader(valid_dataset, batch_size=2, shuffle=False, num_workers=0)
+    metaset = dataset.MetaDataset(metafiles=metadict, train=False, ensemble=True, with_ids=True)
+    metaloader = torch.utils.data.DataLoader(metaset, batch_size=64, shuffle=False, num_workers=0)
+    n_cls = len(metaset.classes)
+
+    with torch.no_grad():
+        enews, cnt = [0.0] * n_cls, [0.0] * n_cls
+        for metax, mask, clsids in metaloader:
+            dw = m.meta_forward(metax.to(device), mask.to(device))[0]
+            for ci, c in enumerate(clsids):
+                c = int(c)
+                enews[c] = enews[c] * cnt[c] / (cnt[c] + 1) + dw[ci] / (cnt[c] + 1)
+                cnt[c] += 1
+        dynamic_weights = [torch.stack(enews)]
+
+        os.makedirs(prefix, exist_ok=True)
+        fps = [open("%s/%s%s.txt" % (prefix, outfile, name), "w") for name in metaset.classes]
+        line_id = -1
+        conf_thresh, nms_thresh = 0.005, 0.45
+        for data, _target in valid_loader:
+            output = m.detect_forward(data.to(device), dynamic_weights)
+            batch_boxes = get_region_boxes_v2(output, n_cls, conf_thresh, m.num_classes, m.anchors, m.num_anchors, 0, 1)  # noqa: F405
+            assert output.size(0) % n_cls == 0
+            for b in range(output.size(0) // n_cls):
+                line_id += 1
+                imgpath = valid_dataset.lines[line_id].rstrip()
+                imgid = os.path.basename(imgpath).split(".")[0]
+                width, height = get_image_size(imgpath)                                   # noqa: F405
+                for i in range(n_cls):
+                    boxes = nms(batch_boxes[b * n_cls + i], nms_thresh)                   # noqa: F405
+                    for box in boxes:
+                        x1, y1 = (box[0] - box[2] / 2.0) * width, (box[1] - box[3] / 2.0) * height
+                        x2, y2 = (box[0] + box[2] / 2.0) * width, (box[1] + box[3] / 2.0) * height
+                        for j in range((len(box) - 5) // 2):
+                            fps[i].write("%s %f %f %f %f %f\n" % (imgid, box[4] * box[5 + 2 * j], x1, y1, x2, y2))
+        for fp in fps:
+            fp.close()
+    return prefix, dynamic_weights

@@ -19,8 +19,13 @@ Outputs (committed, small):
                          support batches -> detect_forward -> decode -> NMS
 
     augment.npz          image.data_augmentation (jitter crop, NEAREST resize, flip, HSV distortion) on synthetic images
+    utils_host.npz       utils.read_truths(_args) / load_class_names / image2torch / scale_bboxes / is_dict / file_lines /
+                         get_image_size / softmax on stored input files
+    region_fns.npz       region_loss.build_targets called directly on decoded boxes; region_loss.neg_filter with seeded RNG
+    drivers.npz          (drivers_golden.py) the loop body of train_meta.py:201-226 and valid_ensemble.valid() run from the
+                         reference's own source on a synthetic tmp dataset
 
-`python make_golden.py NAME...` regenerates only the named fixtures (decode_valid, ensemble, augment); no argument = all.
+`python make_golden.py NAME...` regenerates only the named fixtures (decode_valid, ensemble, augment, utils_host, region_fns, drivers); no argument = all.
 
 The GPU box has no /root/reference; tests there read only these files.
 """
@@ -393,6 +398,127 @@ def gold_episode(im):
     np.savez_compressed(os.path.join(HERE, "episode.npz"), **cases)
 
 
+def gold_public_fns(rl, cfgmod):
+    """The module-level functions of region_loss.py called on their own: build_targets (:37-132) on decoded boxes, and
+    neg_filter (:15-34) with python's seeded RNG."""
+    rng = np.random.RandomState(21)
+    out = {}
+    for k, (rows, g, seen) in enumerate([(6, 13, 0), (6, 13, 20000), (4, 19, 20000), (3, 7, 20000)]):
+        tgt = synth_targets(rng, rows, 1)[:, 0]                     # (rows, 250)
+        cells = 5 * g * g
+        pb = np.zeros((rows * cells, 4), np.float32)
+        ii = np.tile(np.arange(g), g * 5 * rows)
+        jj = np.tile(np.repeat(np.arange(g), g), 5 * rows)
+        pb[:, 0] = ii + rng.uniform(0, 1, rows * cells)
+        pb[:, 1] = jj + rng.uniform(0, 1, rows * cells)
+        aw = np.tile(np.repeat(np.array(ANCH[0::2]), g * g), rows)
+        ah = np.tile(np.repeat(np.array(ANCH[1::2]), g * g), rows)
+        pb[:, 2] = aw * np.exp(rng.normal(0, 0.4, rows * cells))
+        pb[:, 3] = ah * np.exp(rng.normal(0, 0.4, rows * cells))
+        # plant near-perfect predictions on some ground truths so silence / nCorrect fire
+        for b in range(rows):
+            for t in range(3):
+                if tgt[b, t * 5 + 1] == 0:
+                    break
+                gx, gy, gw, gh = tgt[b, t * 5 + 1] * g, tgt[b, t * 5 + 2] * g, tgt[b, t * 5 + 3] * g, tgt[b, t * 5 + 4] * g
+                for a in range(5):
+                    if rng.rand() < 0.5:
+                        pb[b * cells + a * g * g + int(gy) * g + int(gx)] = [gx, gy, gw * rng.uniform(0.8, 1.2), gh]
+        res = rl.build_targets(torch.from_numpy(pb), rl._PyFloatRows(torch.from_numpy(tgt)), ANCH, 5, 1, g, g, 1, 5, 0.6, seen)
+        names = ["nGT", "nCorrect", "coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"]
+        out.update({"bt%d_pred" % k: pb, "bt%d_target" % k: tgt, "bt%d_cfg" % k: np.array([rows, g, seen])})
+        for n, v in zip(names, res):
+            out["bt%d_%s" % (k, n)] = v.numpy() if torch.is_tensor(v) else np.int64(v)
+    out["bt_n"] = 4
+    # neg_filter: (rows, 4) dummy predictions, targets with a few positive rows
+    k = 0
+    for neg in ["full", 0, 1, 2, 5]:
+        for npos in [2, 9]:
+            rows = 30
+            tgt = np.zeros((rows, 250))
+            pos = np.random.RandomState(100 + k).choice(rows, npos, replace=False)
+            tgt[pos, 1] = 0.5
+            tgt[pos, 2] = 0.5
+            tgt[pos, 3] = 0.2
+            tgt[pos, 4] = 0.2
+            pred = torch.arange(rows * 4, dtype=torch.float32).view(rows, 4)
+            cfgmod.cfg.neg_ratio = neg
+            random.seed(500 + k)
+            p2, t2, inds = rl.neg_filter(pred, torch.from_numpy(tgt), withids=True)
+            nxt = random.random()
+            out.update({"nf%d_target" % k: tgt, "nf%d_neg" % k: str(neg), "nf%d_inds" % k: np.asarray(inds).reshape(-1),
+                        "nf%d_pred" % k: p2.numpy(), "nf%d_next_random" % k: nxt})
+            k += 1
+    out["nf_n"] = k
+    cfgmod.cfg.neg_ratio = "full"
+    np.savez_compressed(os.path.join(HERE, "region_fns.npz"), **out)
+
+
+def gold_utils_host(u):
+    """The host helpers of utils.py that dataset.py / valid_ensemble.py import: read_truths(_args) (:373-390),
+    load_class_names (:392-399), image2torch (:401-408), scale_bboxes (:477-485), is_dict / file_lines (:488-523),
+    get_image_size (:536-569), softmax (:16-19).  The input FILES are stored as byte arrays so the test can recreate
+    them where the reference is absent."""
+    import io
+    import tempfile
+    from PIL import Image
+    rng = np.random.RandomState(31)
+    tmp = tempfile.mkdtemp(prefix="fsdgold_")
+    out = {}
+    files = {}
+
+    def put(name, data):
+        files[name] = np.frombuffer(data, dtype=np.uint8)
+        with open(os.path.join(tmp, name), "wb") as fh:
+            fh.write(data)
+        return os.path.join(tmp, name)
+
+    # label files: empty, one row (loadtxt gives 1-D), many rows with narrow boxes
+    labs = {"empty.txt": np.zeros((0, 5)), "one.txt": np.array([[3, .5, .4, .2, .1]]),
+            "many.txt": np.column_stack([rng.randint(0, 20, 12), rng.uniform(0, 1, (12, 2)), rng.uniform(0.0005, 0.3, (12, 2))])}
+    for name, rows in labs.items():
+        buf = io.StringIO()
+        if len(rows):
+            np.savetxt(buf, rows, fmt="%.17g")
+        path = put(name, buf.getvalue().encode())
+        out["truths_" + name] = np.asarray(u.read_truths(path), np.float64)
+        out["truths_args_" + name] = np.asarray(u.read_truths_args(path, 0.05), np.float64)
+    out["truths_missing"] = np.asarray(u.read_truths(os.path.join(tmp, "nope.txt")), np.float64)
+    # names file with trailing blanks and an empty line
+    path = put("x.names", b"aeroplane\nbicycle  \n\npotted plant\t\nlast")
+    out["names"] = np.array(u.load_class_names(path))
+    # list files: plain list and "dict" (two fields per line) pointing at lists that share a line
+    l1 = put("list1.txt", b"/a/images/1.jpg\n/a/images/2.jpg\n/a/images/3.jpg\n")
+    l2 = put("list2.txt", b"/a/images/3.jpg\n/a/images/4.jpg\n")
+    dct = put("dict.txt", ("bird %s\ncat %s\n" % ("@TMP@/list1.txt", "@TMP@/list2.txt")).encode())
+    with open(dct, "w") as fh:                      # the stored bytes keep the placeholder, the live file has real paths
+        fh.write("bird %s\ncat %s\n" % (l1, l2))
+    out["is_dict"] = np.array([u.is_dict(l1), u.is_dict(dct)])
+    out["file_lines"] = np.array([u.file_lines(l1), u.file_lines(l2), u.file_lines(dct), u._file_lines(dct)])
+    # images: PNG, GIF, JPEG (baseline and progressive), a truncated file and a text file
+    arr = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    sizes = []
+    for name, fmt, kw in [("a.png", "PNG", {}), ("b.gif", "GIF", {}), ("c.jpg", "JPEG", {}),
+                          ("d.jpg", "JPEG", {"progressive": True, "quality": 60})]:
+        bio = io.BytesIO()
+        Image.fromarray(arr[:, : 53 - 7 * len(sizes)]).save(bio, fmt, **kw)
+        sizes.append(u.get_image_size(put(name, bio.getvalue())))
+    out["image_sizes"] = np.array(sizes)
+    out["image_size_short"] = np.array([u.get_image_size(put("short.png", b"\x89PNG\r\n")) is None,
+                                        u.get_image_size(put("text.jpg", b"this is not an image, just thirty bytes")) is None])
+    img = Image.fromarray(arr)
+    out["image2torch_in"] = arr
+    out["image2torch"] = u.image2torch(img).numpy()
+    boxes = [[.5, .25, .1, .2, .9, .8, 3], [.1, .9, .3, .4, .5, .6, 1]]
+    out["scale_bboxes"] = np.array(u.scale_bboxes(boxes, 640, 480), np.float64)
+    out["scale_bboxes_in"] = np.array(boxes, np.float64)
+    x = torch.from_numpy(rng.normal(0, 3, (4, 5)).astype(np.float32))
+    out["softmax_in"], out["softmax"] = x.numpy(), u.softmax(x).numpy()
+    for name, data in files.items():
+        out["file_" + name] = data
+    np.savez_compressed(os.path.join(HERE, "utils_host.npz"), **out)
+
+
 def main():
     assert ref_shim.available(), "needs /root/reference"
     only = set(sys.argv[1:])
@@ -404,6 +530,13 @@ def main():
             gold_ensemble(ref_shim.load("darknet_meta"), u)
         if "augment" in only:
             gold_augment(ref_shim.load("image"))
+        if "utils_host" in only:
+            gold_utils_host(u)
+        if "region_fns" in only:
+            gold_public_fns(ref_shim.load("region_loss"), ref_shim.load("cfg"))
+        if "drivers" in only:
+            import drivers_golden
+            drivers_golden.mint()
         print("golden vectors written to", HERE, sorted(only))
         return
     u = ref_shim.load("utils")
@@ -424,6 +557,10 @@ def main():
     gold_ensemble(dm, u)
     gold_episode(ref_shim.load("image"))
     gold_augment(ref_shim.load("image"))
+    gold_utils_host(u)
+    gold_public_fns(rl, cfgmod)
+    import drivers_golden
+    drivers_golden.mint()
     print("golden vectors written to", HERE)
 
 

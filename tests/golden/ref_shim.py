@@ -20,6 +20,9 @@ own (python-2, CUDA) execution:
   * `easydict` (absent) -> a 10-line attribute dict
   * image.py: `resize(shape)` -> `resize(shape, Image.NEAREST)` and `point(f)` -> `point(int(f))`: the defaults of the
     reference's Pillow (< 7.0: NEAREST resize; <= 8: C-int truncation of point() tables), which newer Pillow changed
+  * utils.read_truths `truths.size/5` -> `//`; utils._file_lines `buffer.count('\\n')` on a binary file -> `b'\\n'`
+  * dataset.py: `np.int` -> `int` (alias removed from numpy); `torchvision.transforms` (not installed) -> a stand-in with
+    Compose and ToTensor (HWC uint8 -> CHW float / 255)
   * `torch.sort(det_confs)` in utils.nms -> `stable=True` (tie order of equal float32 keys is unspecified in torch and
     version dependent; pinned to the visiting order)
 
@@ -98,6 +101,9 @@ _SUBS = {
         # CPU implementation differs between torch versions).  The fixtures pin ties to the boxes' visiting order, the
         # only order that is a property of the algorithm rather than of one library build.
         ("_,sortIds = torch.sort(det_confs)", "_,sortIds = torch.sort(det_confs, stable=True)"),
+        # py2 integer division / py2 str-is-bytes in the file helpers
+        ("truths.reshape(truths.size/5, 5)", "truths.reshape(truths.size//5, 5)"),
+        ("count += buffer.count('\\n')", "count += buffer.count(b'\\n')"),
     ],
     "cfg": [],
     "image": [
@@ -110,6 +116,8 @@ _SUBS = {
         ("cs[0] = cs[0].point(change_hue)", "cs[0] = cs[0].point(lambda i: int(change_hue(i)))"),
     ],
     "dynamic_conv": [("import pdb", "pdb = None")],
+    # numpy >= 1.24 dropped the `np.int` alias of the builtin
+    "dataset": [(".astype(np.int)", ".astype(int)")],
     "pooling": [],
 }
 
@@ -129,6 +137,32 @@ _PRELUDE = {
 _loaded = {}
 
 
+def _torchvision_stub():
+    """dataset.py imports `torchvision.transforms` for Compose / ToTensor only; torchvision is not installed here."""
+    if "torchvision" in sys.modules:
+        return
+    import numpy as np
+    import torch
+    tv, tr = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+
+    class Compose(object):
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor(object):          # torchvision's: HWC uint8 -> CHW float / 255
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img).transpose(2, 0, 1).copy()).float().div(255)
+
+    tr.Compose, tr.ToTensor = Compose, ToTensor
+    tv.transforms, tv.datasets = tr, types.ModuleType("torchvision.datasets")
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.datasets": tv.datasets})
+
+
 def load(name):
     """Return the reference module `name` (cfg, utils, region_loss, darknet_meta, ...)."""
     if name in _loaded:
@@ -146,7 +180,10 @@ def load(name):
     saved = {}
     deps = {"cfg": ["utils"], "region_loss": ["utils", "cfg"],
             "darknet_meta": ["utils", "cfg", "region_loss", "dynamic_conv", "pooling"],
-            "darknet": ["utils", "cfg", "region_loss"], "image": ["cfg"]}.get(name, [])
+            "darknet": ["utils", "cfg", "region_loss"], "image": ["cfg"],
+            "dataset": ["utils", "image", "cfg"]}.get(name, [])
+    if name == "dataset":
+        _torchvision_stub()
     for d in deps:
         saved[d] = sys.modules.get(d)
         sys.modules[d] = load(d)

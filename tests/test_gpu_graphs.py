@@ -47,3 +47,56 @@ def test_graphed_inference_equals_eager(dev, tmp_path, dtype):
     net.train()
     out = net.detect_forward(xs[0], vecs)
     assert out.requires_grad
+
+
+def test_graphed_forward_waits_for_vectors_still_on_the_meta_stream(dev, tmp_path):
+    """model(x, metax, mask) in eval mode under no_grad -- the shape of train_meta.py's test() call --
+    defers the wait for the reweighting vectors to their first reader; with inference_graphs that reader is the copy into
+    the graph's static buffer, which has to wait for the "meta" side stream first."""
+    from fewshot_detection_amd import cfgs, streams
+    from fewshot_detection_amd.darknet_meta import Darknet
+    assert streams.ENABLED and streams.META
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    torch.manual_seed(3)
+    net = Darknet(dyn_cfg, rw_cfg).to(dev).eval()
+    x = torch.rand(2, 3, 160, 160, device=dev)
+    # large supports: the reweighting net is still running on its stream when the head wants the vectors
+    metas = [(torch.rand(8, 3, 416, 416, device=dev), (torch.rand(8, 1, 416, 416, device=dev) > 0.5).float()) for _ in range(4)]
+    with torch.no_grad():
+        eager = [net(x, mx, mk).clone() for mx, mk in metas]
+        net.inference_graphs = True
+        for rep in range(2):
+            for (mx, mk), ref in zip(metas, eager):
+                assert torch.equal(net(x, mx, mk), ref)
+
+
+def test_eval_fold_is_rebuilt_after_a_training_forward_moved_the_running_statistics(dev, tmp_path):
+    """eval -> train-mode forward (no optimizer step) -> eval.  The training pass rewrites running_mean /
+    running_var through raw pointers; the folded eval weights (and captured graphs) must not be served stale."""
+    from fewshot_detection_amd import cfgs, engine
+    from fewshot_detection_amd.darknet_meta import Darknet
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    torch.manual_seed(4)
+    net = Darknet(dyn_cfg, rw_cfg).to(dev)
+    x = torch.rand(2, 3, 96, 96, device=dev)
+    vecs = [torch.rand(3, 1024, 1, 1, device=dev)]
+    for graphs in (False, True):
+        net.inference_graphs = graphs
+        net.eval()
+        with torch.no_grad():
+            before = net.detect_forward(x, vecs).clone()
+        net.train()
+        with torch.no_grad():
+            net.detect_forward(torch.rand(4, 3, 96, 96, device=dev) * 3.0, vecs)      # moves every running statistic
+        net.eval()
+        with torch.no_grad():
+            after = net.detect_forward(x, vecs).clone()
+            old = engine.FOLD_EVAL_BN
+            engine.FOLD_EVAL_BN = False
+            net.inference_graphs = False
+            try:
+                unfolded = net.detect_forward(x, vecs).clone()
+            finally:
+                engine.FOLD_EVAL_BN = old
+        assert not torch.equal(after, before)
+        assert float((after - unfolded).norm() / unfolded.norm()) < 2e-4
