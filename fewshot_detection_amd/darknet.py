@@ -4,6 +4,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from .cfg import load_conv, load_conv_bn, parse_cfg, print_cfg, save_conv, save_conv_bn
 from .darknet_meta import (EmptyModule, MaxPoolStride1, Reorg, _apply_net, _flat_params,  # noqa: F401  (the reference's
                            build_modules)                                                 # darknet.py defines them too)
@@ -35,6 +36,10 @@ class Darknet(nn.Module):
     def forward(self, x):
         self.loss = None
         return _apply_net(self._net, self.training, 1, False, None, False, x, *_flat_params(self.models))
+
+    def state_dict(self, *args, **kwargs):
+        ops.flush_bn_counters(self)        # BatchNorm batch counters are kept on the host between looks
+        return super(Darknet, self).state_dict(*args, **kwargs)
 
     def print_network(self):
         print_cfg(self.blocks)

@@ -374,6 +374,10 @@ class Darknet(nn.Module):
         # the reweighting net runs on its own stream beside the detector backbone; the two meet at the fused head
         return self.detect_forward(x, self.meta_forward(metax, mask, _defer=True))
 
+    def state_dict(self, *args, **kwargs):
+        ops.flush_bn_counters(self)        # BatchNorm batch counters are kept on the host between looks
+        return super(Darknet, self).state_dict(*args, **kwargs)
+
     def print_network(self):
         print_cfg(self.blocks)
         print("---------------------------------------------------------------------")

@@ -330,7 +330,19 @@ def bn_finalize(partial, count, bn, training):
     if training:
         from .engine import bump_stats_epoch
         bump_stats_epoch()               # running statistics changed behind torch's version counters
+        # nn.BatchNorm2d counts its training batches in a device buffer (torch >= 0.4; only read when momentum is None):
+        # counted on the host here and written back when someone looks (flush_bn_counters, called by state_dict())
+        bn._fsd_pending_batches = getattr(bn, "_fsd_pending_batches", 0) + 1
     return buf[0], buf[1], buf[2], buf[3]
+
+
+def flush_bn_counters(module):
+    """Bring every BatchNorm's `num_batches_tracked` up to date with the training batches the HIP path ran."""
+    for m in module.modules():
+        n = getattr(m, "_fsd_pending_batches", 0)
+        if n and getattr(m, "num_batches_tracked", None) is not None:
+            m.num_batches_tracked += n
+            m._fsd_pending_batches = 0
 
 
 def bn_act_pool(yv, scale, shift, slope, pool, out=None):

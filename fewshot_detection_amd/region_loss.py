@@ -210,7 +210,7 @@ class _RegionBase(nn.Module):
             s = self.stats()
             print("%d: nGT %d, recall %d, proposals %d, loss: x %f, y %f, w %f, h %f, conf %f, cls %f, total %f" % (
                 self.seen, s["nGT"], s["nCorrect"], s["nProposals"], s["loss_x"], s["loss_y"], s["loss_w"],
-                s["loss_h"], s["loss_conf"], s["loss_cls"], float(loss)))
+                s["loss_h"], s["loss_conf"], s["loss_cls"], float(loss.detach())))
         return loss
 
 

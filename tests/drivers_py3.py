@@ -86,7 +86,7 @@ def train(datacfg, darknetcfg, learnetcfg, weightfile, make_loaders, device, max
             loss = region_loss(output, target)
             loss.backward()
             optimizer.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         epoch += 1
         if epoch % cfg.save_interval == 0:
             model.seen = epoch * len(train_loader.dataset)

@@ -118,11 +118,11 @@ def build_dataset(root, n_images=10, seed=3):
         fh.write(common + "neg = 1\nbackup = backup/metayolo\n")
     with open(os.path.join(root, "tune.data"), "w") as fh:
         fh.write(common + "neg = 0\ntuning = 1\nmax_epoch = 2\nrepeat = 1\ndynamic = 0\nbackup = backup/metatune\n")
-    # a net cfg that trains for two epochs of two batches
+    # a net cfg that trains for two epochs of two batches; mini.weights carries seen = 4242 -> 1060 processed batches
     src = open(os.path.join(HERE, "mini_dynamic.cfg")).read()
     assert "batch=4" in src
     with open(os.path.join(root, "net.cfg"), "w") as fh:
-        fh.write(src.replace("momentum=0.9", "momentum=0.9\nmax_batches=2\nsteps=-1,1,3\nscales=.1,10,.1"))
+        fh.write(src.replace("momentum=0.9", "momentum=0.9\nmax_batches=1062\nsteps=-1,1061,1063\nscales=.1,10,.1"))
     shutil.copy(os.path.join(HERE, "mini_reweight.cfg"), os.path.join(root, "learnet.cfg"))
     os.makedirs(os.path.join(root, "backup", "w"))
     shutil.copy(os.path.join(HERE, "mini.weights"), os.path.join(root, "backup", "w", "mini.weights"))
@@ -209,7 +209,7 @@ def mint():
                 out["train%d_%s" % (i, k)] = np.asarray(v)
         opt = ns["optimizer"].param_groups[0]
         out["train_hparams"] = np.array([opt["lr"], opt["momentum"], opt["weight_decay"], ns["batch_size"], ns["learning_rate"]])
-        out["train_lrs"] = np.array([ns["adjust_learning_rate"](ns["optimizer"], b) for b in range(5)])
+        out["train_lrs"] = np.array([ns["adjust_learning_rate"](ns["optimizer"], b) for b in range(1059, 1066)])
         out["train_processed_batches"] = ns["processed_batches"]
         for k, v in model.state_dict().items():
             out["train_final/" + k] = v.numpy().copy()

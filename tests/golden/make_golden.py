@@ -287,6 +287,8 @@ def _load_stream(net, path):
     into a 4-D parameter, cfg.py:455, which torch 0.3.1 allowed and current torch refuses; the field order below is
     the one its save_conv_bn / save_conv wrote the file in, cfg.py:457-481.)"""
     buf = np.fromfile(path, dtype=np.float32)[4:]
+    net.header = torch.from_numpy(np.fromfile(path, count=4, dtype=np.int32))     # darknet_meta.py:355-359
+    net.seen = net.header[3]
     pos = 0
 
     def pull(t):
