@@ -99,56 +99,18 @@ def episode_flops(blocks, lblocks, B, N, S, Sm):
     return B * conv_flops_per_image(blocks, S) + N * conv_flops_per_image(lblocks, Sm) + head * N * B - B * head
 
 
-def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev):
-    """The oracle (PyTorch-CPU fp32 restatement of the reference) timed on this host on a bounded sample of the same
-    workload -- a smaller query batch, scaled to the full episode by conv FLOPs; median of 3 repetitions after one
-    warm-up.  The oracle's outputs on that sample are then the checker for the HIP path on the same
-    weights and inputs: BASELINE.json's metric names "RegionLoss max|delta| vs ref"."""
-    from oracle.net import OracleDarknet
+
+
+def _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora):
+    """The HIP path on the oracle's weights and inputs: forward, end-to-end loss, and RegionLoss on IDENTICAL inputs."""
     from oracle.region import region_loss_v2
-    from fewshot_detection_amd.cfg import cfg, parse_cfg
+    from fewshot_detection_amd.cfg import cfg
     from fewshot_detection_amd.darknet_meta import Darknet
-    cores = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(cores)
-    Bs, Ns = min(args.batch, 32), args.classes          # about 7 s of CPU work per repetition on a 64-core host
-    torch.manual_seed(4242)
-    ora = OracleDarknet(dyn_cfg, rw_cfg).train()
-    x, metax, mask, tgt = synth_episode(123, Bs, Ns, args.size, args.support)
-    blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
-    sample_flops = episode_flops(blocks, lblocks, Bs, Ns, args.size, args.support)
-    state = {k: v.clone() for k, v in ora.state_dict().items()}        # before train-mode forwards move the BN statistics
-
-    def once():
-        ora.zero_grad()
-        t0 = time.time()
-        out = ora(x, metax, mask)            # the CPU baseline is the reference's arithmetic: fp32
-        r = region_loss_v2(out, tgt, ora.region.anchors, seen=0)
-        if args.mode == "train":
-            r["loss"].backward()
-        return time.time() - t0, out, r
-
-    once()
-    reps = []
-    for _ in range(3):
-        ora.load_state_dict(state)
-        t, out, r = once()
-        reps.append(t)
-    t = sorted(reps)[1]
-    eps = 1.0 / (t * full_flops / sample_flops)
-    base = {"value": eps, "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": "oracle (PyTorch-CPU fp32) %s of B=%d queries %dx%d + N=%d supports %dx%d: median of 3 repetitions "
-                      "after 1 warm-up = %.2f s (%s), scaled by conv FLOPs (%.1f -> %.1f GFLOP forward) to the full episode"
-                      % (args.mode, Bs, args.size, args.size, Ns, args.support, args.support, t,
-                         ", ".join("%.2f" % v for v in reps), sample_flops / 1e9, full_flops / 1e9)}
-    if args.no_parity:
-        return base, None
-
-    # ---- parity of the HIP path on the very same sample, weights and (for the loss) inputs --------------------------
-    import contextlib
+    x, metax, mask, tgt = sample
     with contextlib.redirect_stdout(sys.stderr):
         net2 = Darknet(dyn_cfg, rw_cfg)
     net2.load_state_dict(state)
-    net2 = net2.to(dev).train().set_compute_dtype(args.dtype)
+    net2 = net2.to(dev).train().set_compute_dtype(dtype)
     region2 = net2.models[len(net2.models) - 1]
     region2.verbose = False
     region2.seen = 0
@@ -168,17 +130,11 @@ def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev):
         st = region2.stats()
     finally:
         cfg.neg_ratio = keep_neg
-    if args.dtype == "bf16":                 # the checker of the bf16 mode is the oracle's restatement of that mode
-        ora.load_state_dict(state)
-        with torch.no_grad():
-            out, _ = ora.forward_bf16(x, metax, mask)
-        r = region_loss_v2(out, tgt, ora.region.anchors, seen=0)
-    ref_out = out.detach()
-    ref_loss = float(r["loss"].detach())
+    B, N, S, Sm = x.shape[0], metax.shape[0], x.shape[2], metax.shape[2]
     parity = {
         "config": "B=%d queries %dx%d + N=%d supports %dx%d, train-mode BatchNorm, neg_ratio=full, seen=0, fp32 oracle "
-                  "weights loaded into the HIP model (%s compute)" % (Bs, args.size, args.size, Ns, args.support,
-                                                                      args.support, args.dtype),
+                  "weights loaded into the HIP model (%s compute; checker = the oracle's %s)"
+                  % (B, S, S, N, Sm, Sm, dtype, "fp32 forward" if dtype == "f32" else "restatement of the bf16 storage mode"),
         "forward_max_abs_delta": float((hip_out_cpu - ref_out).abs().max()),
         "forward_max_abs": float(ref_out.abs().max()),
         "forward_rel_l2": float((hip_out_cpu - ref_out).norm() / ref_out.norm()),
@@ -195,15 +151,75 @@ def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev):
     }
     # bf16 mode: both runs round at the same points; a rounding-boundary flip in layer 0 (2.7e-5) is amplified ~1.35x per
     # layer by this randomly initialised net (tests/test_gpu_bf16.py pins every layer to 1e-4 on identical inputs)
-    parity["ok"] = bool((parity["forward_max_abs_delta"] < 1e-3 if args.dtype == "f32" else parity["forward_rel_l2"] < 0.2)
+    parity["ok"] = bool((parity["forward_max_abs_delta"] < 1e-3 if dtype == "f32" else parity["forward_rel_l2"] < 0.2)
                         and parity["region_loss_max_abs_delta"] < 1e-3 and parity["anchor_assignment_equal"]
                         and parity["region_loss_abs_delta"] < 1e-3 * max(1.0, abs(ref_loss)))
     del net2
     torch.cuda.empty_cache()
+    return parity
+
+
+def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes):
+    """The oracle (PyTorch-CPU fp32 restatement of the reference) timed on this host on a bounded sample of the same
+    workload, then used as the checker of the HIP path on the same weights and inputs (BASELINE.json's metric names
+    "RegionLoss max|delta| vs ref").  On a host with >= 32 cores the sample is the timed query batch itself (B = 64: one
+    small warm-up + 2 repetitions, ~25 s of CPU work); smaller hosts time B = 32 and scale by conv FLOPs.
+    -> (cpu_baseline, {dtype: parity})"""
+    from oracle.net import OracleDarknet
+    from oracle.region import region_loss_v2
+    from fewshot_detection_amd.cfg import parse_cfg
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    Bs, Ns = (args.batch if cores >= 32 else min(args.batch, 32)), args.classes
+    torch.manual_seed(4242)
+    ora = OracleDarknet(dyn_cfg, rw_cfg).train()
+    sample = synth_episode(123, Bs, Ns, args.size, args.support)
+    x, metax, mask, tgt = sample
+    blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
+    sample_flops = episode_flops(blocks, lblocks, Bs, Ns, args.size, args.support)
+    state = {k: v.clone() for k, v in ora.state_dict().items()}        # before train-mode forwards move the BN statistics
+
+    def once(xx, tt):
+        ora.zero_grad()
+        t0 = time.time()
+        out = ora(xx, metax, mask)           # the CPU baseline is the reference's arithmetic: fp32
+        r = region_loss_v2(out, tt, ora.region.anchors, seen=0)
+        if args.mode == "train":
+            r["loss"].backward()
+        return time.time() - t0, out, r
+
+    once(x[:8], tgt[:8])                     # warm-up (thread pool, allocator, oneDNN primitives) on a slice
+    reps = []
+    for _ in range(2):
+        ora.load_state_dict(state)
+        t, out, r = once(x, tgt)
+        reps.append(t)
+    t = min(reps)
+    eps = 1.0 / (t * full_flops / sample_flops)
+    base = {"value": eps, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32) %s of B=%d queries %dx%d + N=%d supports %dx%d: best of 2 repetitions "
+                      "after a B=8 warm-up = %.2f s (%s)%s"
+                      % (args.mode, Bs, args.size, args.size, Ns, args.support, args.support, t,
+                         ", ".join("%.2f" % v for v in reps),
+                         "" if Bs == args.batch else ", scaled by conv FLOPs (%.1f -> %.1f GFLOP forward) to the full episode"
+                         % (sample_flops / 1e9, full_flops / 1e9))}
+    if args.no_parity:
+        return base, {}
+    parity = {}
+    ref_out, ref_loss = out.detach(), float(r["loss"].detach())
+    for dtype in dtypes:
+        if dtype == "bf16":                  # the checker of the bf16 mode is the oracle's restatement of that mode
+            ora.load_state_dict(state)
+            with torch.no_grad():
+                out_h, _ = ora.forward_bf16(x, metax, mask)
+            r_h = region_loss_v2(out_h, tgt, ora.region.anchors, seen=0)
+            parity[dtype] = _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, out_h.detach(), float(r_h["loss"].detach()), ora)
+        else:
+            parity[dtype] = _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora)
     return base, parity
 
 
-def timed(fn, n=5, w=2):
+def timed(fn, n=5, w=1):
     for _ in range(w):
         fn()
     torch.cuda.synchronize()
@@ -214,52 +230,296 @@ def timed(fn, n=5, w=2):
     return (time.perf_counter() - t0) / n
 
 
-def extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, blocks, lblocks):
-    """More timings of the same model on the same device (N=1 only, ~2 s): the forward pass alone (north_star:
-    ">= 0.6x MFMA roofline on the Darknet-19 forward") and BASELINE configs[1] exactly as the cfg files spell it
-    (15 base classes, supports 416x416) -- or the metric-string episode when configs[1] is the headline."""
-    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-    out = {}
+def newest_profile(name):
+    """The newest committed rocprofv3 PMC summary profiles/rNN*_<name> (tools/pmc_traffic.py over separate FETCH_SIZE /
+    WRITE_SIZE passes of this very command).  Counters cannot be read live; (None, None) if no summary is committed."""
+    import glob
+    import re
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(p))
+        if m:
+            key = (int(m.group(1)), m.group(2))
+            if best is None or key > best[0]:
+                best = (key, p)
+    if best is None:
+        return None, None
+    try:
+        return json.load(open(best[1])), "profiles/%s (offline rocprofv3 PMC passes of this command)" % os.path.basename(best[1])
+    except Exception:
+        return None, None
 
-    def fwd():
-        with torch.no_grad():
-            region(net(x, metax, mask), target)
 
-    t = timed(fwd)
-    out["forward_only"] = {"what": "forward (train-mode BN) + RegionLoss forward/grad kernel, no backward, same episode",
-                           "ms": t * 1e3, "episodes_per_s": 1.0 / t, "algorithmic_tflops": full_flops / t / 1e12,
-                           "frac_of_mfma_peak_algorithmic": full_flops / t / 1e12 / peak}
-    if args.mode == "train" and opt is not None:
-        other = (15, 416) if (args.classes, args.support) != (15, 416) else (20, 224)
-        x2, metax2, mask2, target2 = synth_episode(2000, args.batch, other[0], args.size, other[1])
-        metax2, mask2 = metax2.to(dev), mask2.to(dev)
+class Leg(object):
+    """One model replica in one storage mode (+ its trainer), and what bench.py measures on it."""
 
-        def train_other():
-            region.seen += args.batch
-            opt.backward_and_step(region(net(x, metax2, mask2), target2))
+    def __init__(self, dyn_cfg, rw_cfg, dtype, dev, dist, global_batch, mode):
+        from fewshot_detection_amd.darknet_meta import Darknet
+        self.dtype, self.dev, self.dist, self.global_batch = dtype, dev, dist, global_batch
+        torch.manual_seed(0)
+        random.seed(0)
+        with contextlib.redirect_stdout(sys.stderr):  # the constructor prints like the reference; stdout carries ONE JSON line
+            self.net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(dtype)
+        self.region = self.net.models[len(self.net.models) - 1]
+        self.region.verbose = False
+        self.opt = None
+        if mode == "train":
+            from fewshot_detection_amd.dp import EpisodeTrainer
+            # train_meta.py:123-147: lr = 0.001/factor/global_batch, wd = decay*global_batch*factor (factor 3 for
+            # neg=1).  From RANDOM init (no pretrained darknet19 weights here) that step size diverges within
+            # two steps, so the bench shrinks lr by 1e-4; the work per step is unchanged.
+            self.opt = EpisodeTrainer(self.net, lr=1e-4 * 0.001 / 3 / global_batch, momentum=0.9,
+                                      weight_decay=0.0005 * global_batch * 3, process_group=dist,
+                                      grad_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+            self.opt.time_allreduce = dist is not None
 
-        t = timed(train_other)
-        fl = episode_flops(blocks, lblocks, args.batch, other[0], args.size, other[1])
-        key = "configs1_cfg_episode" if other == (15, 416) else "metric_string_episode"
-        out[key] = {"what": "train step on B=%d queries %dx%d + %d supports %dx%d (%s)"
-                            % (args.batch, args.size, args.size, other[0], other[1], other[1],
-                               "BASELINE configs[1] with the cfg's own support size and 15 base classes" if other == (15, 416)
-                               else "the shape in BASELINE.json's metric string"),
-                    "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t, "img_per_s": args.batch / t,
-                    "episode_forward_gflop": fl / 1e9, "dtype": args.dtype}
+    def stepper(self, x, metax, mask, target, batch=None):
+        net, region, opt, gb = self.net, self.region, self.opt, (batch or self.global_batch)
+
+        def step():
+            region.seen += gb
+            loss = region(net(x, metax, mask), target)
+            if opt is not None:
+                opt.backward_and_step(loss)
+            return loss
+        return step
+
+    def fence(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup, prof_steps, streams_on):
+        """`warmup` untimed steps, then EXACTLY `steps` timed steps between two fences.  `prof_steps` of the timed steps --
+        in the middle of the region, on EVERY rank -- run on one stream with the library's per-kernel HIP events on: with
+        the side streams a kernel shares the chip with the launches of the other strands and its duration says how the
+        chip was shared, not how good the kernel is.  They are part of the timed region (the headline therefore includes
+        a few un-overlapped steps); ms_unprofiled is the rest.  The first step after a fence runs at ramping clocks (its
+        kernels measured 6-8 % slower than the same kernels a few steps later), hence the middle."""
+        from fewshot_detection_amd import ops, streams
+        for _ in range(warmup):
+            step()
+        self.fence()
+        if self.opt is not None:
+            self.opt.allreduce_wait_ms = [0.0] * len(self.opt.buckets)
+        prof_steps = min(steps, prof_steps)
+        lo = (steps - prof_steps) // 2
+        hi = lo + prof_steps
+        prof = []
+        t_a = t_b = None
+        ops.kernel_profile_collect()          # drop whatever an earlier leg left
+        # the per-launch event records create python objects: keep the cyclic collector from stopping the host for a
+        # full-heap pass in the middle of the timed region
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i == lo and prof_steps:
+                torch.cuda.synchronize()
+                t_a = time.perf_counter()
+                ops.PROFILE = prof
+                ops.kernel_profile(True)
+                streams.ENABLED = False
+            elif i == hi and prof_steps:
+                ops.PROFILE = None
+                ops.kernel_profile(False)
+                streams.ENABLED = streams_on
+                torch.cuda.synchronize()
+                t_b = time.perf_counter()
+            loss = step()
+        ops.PROFILE = None
+        ops.kernel_profile(False)
+        streams.ENABLED = streams_on
+        self.fence()
+        t_end = time.perf_counter()
+        gc.enable()
+        if prof_steps and t_b is None:        # the profiled steps were the last ones
+            t_b = t_end
+        elapsed = t_end - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        loss_val = float(loss.detach())
+        assert np.isfinite(loss_val), "non-finite loss"
+        return {"elapsed": elapsed, "steps": steps, "loss": loss_val, "prof": prof, "prof_steps": prof_steps,
+                "prof_index": [lo, hi] if prof_steps else None, "kp": ops.kernel_profile_collect(),
+                "ms_unprofiled": (((t_a - t0) + (t_end - t_b)) / (steps - prof_steps) * 1e3
+                                  if t_a is not None and steps > prof_steps else None),
+                "ms_profiled": ((t_b - t_a) / prof_steps * 1e3 if t_a is not None else None)}
+
+
+def roofline_block(r, dtype, ms):
+    """`roofline` of the bench line from the per-kernel-class HIP events of the profiled steps (r = Leg.run(...))."""
+    kp, prof, per = r["kp"], r["prof"], max(1, r["prof_steps"])
+    peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+
+    def mfma(cls):
+        k = kp[cls]
+        pk = PEAK_BF16_MFMA_TFLOPS if cls == "gemm_bf16" else PEAK_FP32_MFMA_TFLOPS
+        tf = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        return {"achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk,
+                "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
+                "avg_kernel_ms": k["ms"] / max(1, k["launches"]), "issued_gflop_per_step": k["work"] / per / 1e9}
+
+    def hbm(cls):
+        k = kp[cls]
+        gbs = k["work"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+        return {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
+                "algorithmic_mb_per_step": k["work"] / per / 1e6}
+
+    conv_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
+    conv_flops = sum(e[2] for e in prof)
+    algorithmic = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    dom = "gemm_fwd" if dtype == "f32" or kp["gemm_bf16"]["ms"] < kp["gemm_fwd"]["ms"] else "gemm_bf16"
+    roof = mfma(dom)
+    roof.update({
+        "bound": "mfma",
+        "kernel": ("conv_gemm_kernel: the fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernel behind the direct "
+                   "3x3/1x1 convolutions, the data gradients and the 36 / 16 position GEMMs of the Winograd layers"
+                   if dom == "gemm_fwd" else
+                   "conv_bf16_*_kernel + wgrad_bf16_tr_kernel: the bf16-operand MFMA (v_mfma_f32_32x32x16_bf16) implicit-GEMM "
+                   "kernels of the bf16 storage mode (forward, data gradient, weight gradient)"),
+        "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
+                "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
+                "its own duration, HIP events recorded by the library right around every launch on the launch stream "
+                "during `profiled_steps` steps in the middle of the timed region, which run on one stream (no side-stream "
+                "overlap: a kernel's duration in isolation); avg_kernel_ms is what rocprofv3 --kernel-trace --stats shows "
+                "for this kernel under `bench.py --streams 0` (profiles/)",
+        "profiled_steps": r["prof_steps"],
+        "algorithmic_speedup": {
+            "what": "direct-convolution FLOPs (2*k*k*Cin*Cout*pixels, SURVEY 8d) of the forward + data-gradient conv "
+                    "launches / the HIP-event time of those launches (transforms included)",
+            "algorithmic_tflops": algorithmic, "x_mfma_peak": algorithmic / peak,
+            "conv_launch_ms_per_step": conv_ms / per, "launches_per_step": len(prof) // per},
+        "hbm_other": {"bn_leaky_pool_backward": hbm("act_bwd"), "bn_leaky_pool_forward": hbm("act_fwd"),
+                      "region_loss": hbm("region"), "sgd": hbm("sgd"), "first_layer": hbm("first_layer")},
+    })
+    if dtype == "f32":
+        roof["wgrad_kernel"] = dict(mfma("gemm_wgrad"), kernel="wgrad_kernel: fp32 MFMA weight-gradient reduction GEMMs "
+                                                                "(direct layers and the F(3x3,4x4) Winograd batches)")
+        roof["hbm"] = dict(hbm("wino_transform"), bound="hbm",
+                           kernel="Winograd input / output / gradient transform kernels (wino4_input, wino4_output, wino4_dy, ...)",
+                           note="achieved = algorithmic bytes (activation once + transformed positions once, per launch) / "
+                                "kernel duration")
+    if kp["gemm_bf16"]["launches"] and dom != "gemm_bf16":
+        roof["bf16_kernels"] = mfma("gemm_bf16")
+    mf = kp["gemm_fwd"]["ms"] + kp["gemm_wgrad"]["ms"] + kp["gemm_bf16"]["ms"]
+    mw = kp["gemm_fwd"]["work"] + kp["gemm_wgrad"]["work"] + kp["gemm_bf16"]["work"]
+    roof["mfma_all"] = {"issued_tflops": mw / (mf * 1e-3) / 1e12 if mf > 0 else 0.0, "kernel_ms_per_step": mf / per,
+                        "issued_gflop_per_step": mw / per / 1e9, "frac_of_step_time": (mf / per) / ms if ms > 0 else 0.0,
+                        "whole_step_issued_tflops": (mw / per) / (ms * 1e-3) / 1e12}
+    roof["timed_kernel_ms_per_step"] = sum(v["ms"] for v in kp.values()) / per
+    return roof
+
+
+def backbone_forward(dyn_cfg, dtype, dev, B, S):
+    """north_star's literal target: the Darknet-19 backbone (layers 0-22 of darknet_dynamic.cfg, 18.906 GFLOP / image,
+    BASELINE.md) forward at B=64, 416x416 on one MI355X, as the training forward runs it (train-mode BatchNorm from the
+    conv epilogue's partial sums, fused BN + leaky + pool passes) and in its inference form (BatchNorm folded)."""
+    from fewshot_detection_amd import ops, streams
+    from fewshot_detection_amd.cfg import parse_cfg
+    from fewshot_detection_amd.darknet import Darknet as PlainDarknet
+    blocks = parse_cfg(dyn_cfg)[:24]                       # [net] + layers 0..22
+    assert blocks[-1]["type"] == "convolutional" and int(blocks[-1]["filters"]) == 1024
+    algorithmic = B * conv_flops_per_image(blocks, S)
+    peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(sys.stderr):
+        net = PlainDarknet(blocks).to(dev).train()
+    net._net.compute_dtype = dtype
+    x = torch.rand(B, 3, S, S, device=dev)
+    out = {"what": "Darknet-19 backbone = layers 0-22 of darknet_dynamic.cfg, forward only, B=%d %dx%d, %s"
+                   % (B, S, S, "fp32" if dtype == "f32" else "bf16 storage mode"),
+           "algorithmic_gflop": algorithmic / 1e9, "mfma_peak_tflops": peak}
+    for mode in ("train_bn", "eval_folded"):
+        net.train(mode == "train_bn")
+
+        def fwd():
+            with torch.no_grad():
+                return net(x)
+        t = timed(fwd, n=8, w=2)
+        keep = streams.ENABLED
+        streams.ENABLED = False
+        ops.kernel_profile_collect()
+        ops.kernel_profile(True)
+        for _ in range(2):
+            fwd()
+        ops.kernel_profile(False)
+        streams.ENABLED = keep
+        kp = ops.kernel_profile_collect()
+        g_ms = (kp["gemm_fwd"]["ms"] + kp["gemm_bf16"]["ms"] + kp["first_layer"]["ms"] * 0) / 2
+        issued = (kp["gemm_fwd"]["work"] + kp["gemm_bf16"]["work"]) / 2
+        out[mode] = {"ms": t * 1e3, "img_per_s": B / t,
+                     "algorithmic_tflops": algorithmic / t / 1e12, "frac_of_mfma_peak_algorithmic": algorithmic / t / 1e12 / peak,
+                     "issued_gflop": issued / 1e9, "issued_tflops_whole_forward": issued / t / 1e12,
+                     "frac_of_mfma_peak_issued_whole_forward": issued / t / 1e12 / peak,
+                     "mfma_kernels_ms": g_ms, "issued_tflops_in_mfma_kernels": issued / (g_ms * 1e-3) / 1e12 if g_ms else None,
+                     "frac_of_mfma_peak_issued_in_mfma_kernels": issued / (g_ms * 1e-3) / 1e12 / peak if g_ms else None,
+                     "kernel_ms_by_class": {k: v["ms"] / 2 for k, v in kp.items() if v["launches"]}}
+    out["note"] = ("algorithmic = direct-convolution FLOPs (1210.0 GFLOP at B=64, BASELINE.md); issued = MFMA FLOPs the kernels "
+                   "really execute (the fp32 Winograd layers issue 4x / 2.25x fewer; the first layer's direct-operand kernel is "
+                   "HBM-bound and not counted as issued MFMA work); 'whole_forward' divides by the wall time of the forward "
+                   "incl. its HBM-bound passes, 'in_mfma_kernels' by the GEMM kernels' own HIP-event time on one stream")
+    del net
     return out
 
 
-def pmc_traffic(name):
-    """A committed rocprofv3 PMC summary (profiles/<name>, produced by tools/pmc_traffic.py from separate FETCH_SIZE /
-    WRITE_SIZE passes of this very command).  Counters cannot be read live; None if the summary is absent."""
-    for rnd in ("r02", "r01"):
-        p = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
-        try:
-            return json.load(open(p)), "profiles/%s_%s (offline rocprofv3 PMC passes of this command)" % (rnd, name)
-        except Exception:
-            continue
-    return None, None
+def inference_latency(leg, dev, S):
+    """valid_ensemble.py's shape: 2 query images per batch through the eval-mode detect_forward with fixed (ensembled)
+    reweighting vectors; eager with the unfolded BatchNorm, the inference form (folded), and its hipGraph replay."""
+    from fewshot_detection_amd import engine
+    net = leg.net
+    was_training = net.training
+    net.eval()
+    vec = [torch.rand(20, 1024, 1, 1, device=dev)]
+    out = {"what": "eval-mode detect_forward, 20 ensembled reweighting vectors, ms per batch (median-free mean of 50 after 5)"}
+    try:
+        for b in (2, 32):
+            x = torch.rand(b, 3, S, S, device=dev)
+            res = {}
+            for name, fold, graph in (("eager_unfolded", False, False), ("eager_folded", True, False), ("graph_folded", True, True)):
+                engine.FOLD_EVAL_BN, net.inference_graphs = fold, graph
+
+                def f():
+                    with torch.no_grad():
+                        return net.detect_forward(x, vec)
+                res[name] = timed(f, n=50 if b == 2 else 10, w=5) * 1e3
+            res["img_per_s_graph"] = b / (res["graph_folded"] * 1e-3)
+            out["batch_%d" % b] = res
+    finally:
+        engine.FOLD_EVAL_BN, net.inference_graphs = True, False
+        net._graphs.clear()
+        net.train(was_training)
+    return out
+
+
+def other_configs(leg, args, dev, blocks, lblocks):
+    """Train-step times of the other BASELINE configs' shapes on one GPU (1 warm-up + 5 steps each)."""
+    from fewshot_detection_amd.cfg import cfg
+    out = {}
+    keep = cfg.neg_ratio
+    shapes = [("configs1_cfg_episode", 64, 15, 416, 416, 1, "BASELINE configs[1] with the cfg's own 416x416 supports and 15 base classes"),
+              ("configs3_tuning_C4", 32, 20, 416, 416, 0, "BASELINE configs[3]: 5-shot fine-tune shape, B=32, 20-way, neg_ratio=0"),
+              ("configs4_shape_C5", 64, 80, 608, 416, 1, "BASELINE configs[4] shape on ONE GPU: 64 queries 608x608, 80-way (COCO)")]
+    try:
+        for key, B, N, S, Sm, neg, what in shapes:
+            if (B, N, S, Sm) == (args.batch, args.classes, args.size, args.support):
+                key, B, N, S, Sm, neg, what = ("metric_string_episode", 64, 20, 416, 224, 1, "the shape in BASELINE.json's metric string")
+            cfg.neg_ratio = neg
+            x, metax, mask, target = synth_episode(2000 + N, B, N, S, Sm)
+            step = leg.stepper(x.to(dev).contiguous(), metax.to(dev), mask.to(dev), target, batch=B)
+            t = timed(step, n=5, w=1)
+            fl = episode_flops(blocks, lblocks, B, N, S, Sm)
+            out[key] = {"what": "train step, B=%d queries %dx%d + %d supports %dx%d, neg_ratio=%s (%s)" % (B, S, S, N, Sm, Sm, neg, what),
+                        "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t, "img_per_s": B / t,
+                        "episode_forward_gflop": fl / 1e9, "dtype": leg.dtype}
+            del x, metax, mask, step
+            torch.cuda.empty_cache()
+    finally:
+        cfg.neg_ratio = keep
+    return out
 
 
 def main():
@@ -274,8 +534,9 @@ def main():
     ap.add_argument("--mode", choices=["train", "forward"], default=None)
     ap.add_argument("--neg", default="1", help="cfg.neg_ratio ('full' or a number; metayolo.data uses 1)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="conv compute mode: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, fp32 "
-                         "accumulate, fp32 BN/loss/master weights (BASELINE C3/C5)")
+                    help="conv compute mode of the HEADLINE: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, "
+                         "fp32 accumulate, fp32 BN/loss/master weights (BASELINE C3/C5).  The default f32 line also carries the "
+                         "bf16 train step under also_measured.bf16_mode")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
                          "the ranks, supports replicated (SURVEY 8e)")
@@ -285,7 +546,7 @@ def main():
                          "default: on unless FSD_STREAMS=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle comparison on the cpu_baseline sample")
-    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only / other-episode timings")
+    ap.add_argument("--no-extras", action="store_true", help="skip also_measured (bf16 mode, backbone forward, other configs, ...)")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
     args = ap.parse_args()
 
@@ -320,7 +581,6 @@ def main():
     from fewshot_detection_amd import backward as bw
     from fewshot_detection_amd import cfgs, ops, streams
     from fewshot_detection_amd.cfg import cfg, parse_cfg
-    from fewshot_detection_amd.darknet_meta import Darknet
 
     if args.mode is None:
         args.mode = "train" if getattr(bw, "AVAILABLE", False) else "forward"
@@ -332,42 +592,15 @@ def main():
         cfg.neg_ratio = int(cfg.neg_ratio)
     tmp = tempfile.mkdtemp()
     dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(tmp)
-    torch.manual_seed(0)
-    random.seed(0)
-    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints like the reference; stdout carries ONE JSON line
-        net = Darknet(dyn_cfg, rw_cfg).to(dev).train().set_compute_dtype(args.dtype)
-    region = net.models[len(net.models) - 1]
-    region.verbose = False
+    blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
+    leg = Leg(dyn_cfg, rw_cfg, args.dtype, dev, dist, global_batch, args.mode)
     if strong:      # one global episode: this rank's slice of the queries and targets, every support on every rank
         gx, metax, mask, gt = synth_episode(1000, args.batch, args.classes, args.size, args.support)
         x, target = gx[rank * local_batch:(rank + 1) * local_batch], gt[rank * local_batch:(rank + 1) * local_batch]
     else:
         x, metax, mask, target = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
     x, metax, mask = x.to(dev).contiguous(), metax.to(dev), mask.to(dev)
-
-    opt = None
-    if args.mode == "train":
-        from fewshot_detection_amd.dp import EpisodeTrainer
-        # train_meta.py:123-147: lr = 0.001/factor/global_batch, wd = decay*global_batch*factor (factor 3 for
-        # neg=1).  From RANDOM init (no pretrained darknet19 weights here) that step size diverges within
-        # two steps, so the bench shrinks lr by 1e-4; the work per step is unchanged.
-        opt = EpisodeTrainer(net, lr=1e-4 * 0.001 / 3 / global_batch, momentum=0.9,
-                             weight_decay=0.0005 * global_batch * 3, process_group=dist,
-                             grad_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-        opt.time_allreduce = world > 1
-
-    def step():
-        region.seen += global_batch
-        out = net(x, metax, mask)
-        loss = region(out, target)
-        if opt is not None:
-            opt.backward_and_step(loss)
-        return loss
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step = leg.stepper(x, metax, mask, target)
 
     # The shader clock the chip sustains under matrix-core load (a dependent-MFMA chain, ~1 ms).  A box that was throttled
     # by an earlier tenant / process shows up here as a fraction of the nominal 2400 MHz: wait (bounded) for it to recover
@@ -378,142 +611,35 @@ def main():
         time.sleep(3.0)
         clock["probe_mhz_start"] = ops.clock_probe_mhz(dev)
         clock["waited_s"] = time.perf_counter() - t_wait
-    for _ in range(args.warmup):
-        step()
-    fence()
-    clock["probe_mhz_after_warmup"] = ops.clock_probe_mhz(dev)
-    if opt is not None:
-        opt.allreduce_wait_ms = [0.0] * len(opt.buckets)
-    # the per-launch event records below create python objects: keep the cyclic collector from stopping the host for a
-    # full-heap pass in the middle of the timed region
-    gc.collect()
-    gc.disable()
-    # Per-kernel HIP events (roofline) are recorded INSIDE the timed region, on its first `prof_steps` steps only: each
-    # record is a barrier packet in the queue and a few hundred of them per step cost ~1 ms of the step.
-    # The profiled steps run on ONE stream: with the side streams a kernel shares the chip with the launches of the other
-    # strands and its duration says how the chip was shared, not how good the kernel is.  They are part of the timed
-    # region (the headline therefore includes a few un-overlapped steps); ms_per_step_unprofiled is the rest ...
-    prof_steps = min(args.steps, args.profile_steps) if rank == 0 else 0
-    # ... and they sit in the MIDDLE of the timed region: the first step after the fence runs at ramping clocks (its
-    # kernels measured 6-8 % slower than the same kernels a few steps later)
-    prof_lo = (args.steps - prof_steps) // 2
-    prof_hi = prof_lo + prof_steps
-    prof = []
-    t_a = t_b = None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == prof_lo and prof_steps:
-            torch.cuda.synchronize()
-            t_a = time.perf_counter()
-            ops.PROFILE = prof
-            ops.kernel_profile(True)
-            streams.ENABLED = False
-        elif i == prof_hi and prof_steps:
-            ops.PROFILE = None
-            ops.kernel_profile(False)
-            streams.ENABLED = streams_on
-            torch.cuda.synchronize()
-            t_b = time.perf_counter()
-        loss = step()
-    ops.PROFILE = None
-    ops.kernel_profile(False)
-    streams.ENABLED = streams_on
-    fence()
-    t_end = time.perf_counter()
-    if prof_steps and t_b is None:           # the profiled steps were the last ones
-        t_b = t_end
-    elapsed = t_end - t0
-    gc.enable()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss)
-    assert np.isfinite(loss_val), "non-finite loss"
+    r = leg.run(step, args.steps, args.warmup, args.profile_steps, streams_on)
     clock["probe_mhz_after_timing"] = ops.clock_probe_mhz(dev)
-    clock["throttled"] = bool(min(clock["probe_mhz_after_warmup"], clock["probe_mhz_after_timing"]) < 0.6 * 2400.0)
+    clock["throttled"] = bool(clock["probe_mhz_after_timing"] < 0.6 * 2400.0)
+    elapsed = r["elapsed"]
 
     if rank == 0:
-        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        kp = ops.kernel_profile_collect()
-        per = max(1, prof_steps)
-
-        def mfma(cls):
-            k = kp[cls]
-            tf = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            return {"achieved": tf, "peak": peak if cls != "gemm_bf16" else PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / (peak if cls != "gemm_bf16" else PEAK_BF16_MFMA_TFLOPS),
-                    "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
-                    "avg_kernel_ms": k["ms"] / max(1, k["launches"]), "issued_gflop_per_step": k["work"] / per / 1e9}
-
-        def hbm(cls):
-            k = kp[cls]
-            gbs = k["work"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
-            return {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
-                    "algorithmic_mb_per_step": k["work"] / per / 1e6}
-
-        conv_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
-        conv_flops = sum(e[2] for e in prof)
-        algorithmic = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        if args.per_layer and prof_steps:
-            n_l = len(prof) // prof_steps
+        if args.per_layer and r["prof_steps"]:
+            prof, ps = r["prof"], r["prof_steps"]
+            n_l = len(prof) // ps
             for i in range(n_l):
-                ms_i = sum(prof[s_ * n_l + i][0].elapsed_time(prof[s_ * n_l + i][1]) for s_ in range(prof_steps)) / prof_steps
+                ms_i = sum(prof[s_ * n_l + i][0].elapsed_time(prof[s_ * n_l + i][1]) for s_ in range(ps)) / ps
                 fl = prof[i][2]
                 sys.stderr.write("conv launch %2d: %8.3f ms  %8.2f GFLOP  %6.1f TFLOP/s\n" % (i, ms_i, fl / 1e9, fl / ms_i / 1e9))
-        blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
         full_flops = episode_flops(blocks, lblocks, local_batch, args.classes, args.size, args.support)
         ms = elapsed / args.steps * 1e3
         episodes_per_step = 1 if strong else world
-        dom = "gemm_fwd" if args.dtype == "f32" or kp["gemm_bf16"]["ms"] < kp["gemm_fwd"]["ms"] else "gemm_bf16"
-        roof = mfma(dom)
-        traffic, traffic_src = pmc_traffic("conv_traffic.json")
-        is_c2 = (args.mode == "train" and local_batch == 64 and args.dtype == "f32")
-        roof.update({
-            "bound": "mfma",
-            "kernel": ("conv_gemm_kernel: the fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernel behind the direct "
-                       "3x3/1x1 convolutions, the data gradients and the 36 / 16 position GEMMs of the Winograd layers"
-                       if dom == "gemm_fwd" else "conv_gemm_bf16_kernel: bf16-operand MFMA implicit GEMM"),
-            "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
-                    "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
-                    "its own duration, HIP events recorded by the library right around every launch on the launch stream "
-                    "during `profiled_steps` steps in the middle of the timed region, which run on one stream (no side-stream overlap: a "
-                    "kernel's duration in isolation); avg_kernel_ms is what rocprofv3 --kernel-trace --stats shows for this "
-                    "kernel under `bench.py --streams 0` (profiles/)",
-            "profiled_steps": prof_steps,
-            "traffic": (traffic or {}).get("hbm_bytes_per_launch") if is_c2 else None,
-            "traffic_source": traffic_src if is_c2 else None,
-            "traffic_note": "HBM bytes per CONV LAUNCH (direct kernel, or transform + GEMM + transform of a Winograd layer), "
-                            "FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes; measured on the configs[1] episode",
-            "algorithmic_speedup": {
-                "what": "direct-convolution FLOPs (2*k*k*Cin*Cout*pixels, SURVEY 8d) of the forward + data-gradient conv "
-                        "launches / the HIP-event time of those launches (transforms included)",
-                "algorithmic_tflops": algorithmic, "x_mfma_peak": algorithmic / peak,
-                "conv_launch_ms_per_step": conv_ms / per, "launches_per_step": len(prof) // per},
-            "wgrad_kernel": dict(mfma("gemm_wgrad"), kernel="wgrad_kernel: fp32 MFMA weight-gradient reduction GEMMs "
-                                                            "(direct layers and the F(3x3,4x4) Winograd batches)"),
-            "hbm": dict(hbm("wino_transform"), bound="hbm",
-                        kernel="Winograd input / output / gradient transform kernels (wino4_input, wino4_output, wino4_dy, ...)",
-                        note="achieved = algorithmic bytes (activation once + transformed positions once, per launch) / "
-                             "kernel duration"),
-            "hbm_other": {"bn_leaky_pool_backward": hbm("act_bwd"), "bn_leaky_pool_forward": hbm("act_fwd"),
-                          "region_loss": hbm("region"), "sgd": hbm("sgd"), "first_layer": hbm("first_layer")},
-        })
-        if kp["gemm_bf16"]["launches"] and dom != "gemm_bf16":
-            roof["bf16_kernels"] = mfma("gemm_bf16")
-        mf = kp["gemm_fwd"]["ms"] + kp["gemm_wgrad"]["ms"] + kp["gemm_bf16"]["ms"]
-        mw = kp["gemm_fwd"]["work"] + kp["gemm_wgrad"]["work"] + kp["gemm_bf16"]["work"]
-        roof["mfma_all"] = {"issued_tflops": mw / (mf * 1e-3) / 1e12 if mf > 0 else 0.0, "kernel_ms_per_step": mf / per,
-                            "issued_gflop_per_step": mw / per / 1e9,
-                            "frac_of_step_time": (mf / per) / ms if ms > 0 else 0.0,
-                            "whole_step_issued_tflops": (mw / per) / (ms * 1e-3) / 1e12}
-        roof["timed_kernel_ms_per_step"] = sum(v["ms"] for v in kp.values()) / per
+        roof = roofline_block(r, args.dtype, ms)
+        headline_shape = (args.batch, args.classes, args.size, args.support) == (64, 20, 416, 224)
+        traffic, traffic_src = newest_profile("conv_traffic.json")
+        use_traffic = bool(traffic) and args.mode == "train" and local_batch == 64 and args.dtype == "f32" and \
+            (traffic.get("episode") in (None, "metric_string") if headline_shape else traffic.get("episode") == "configs1")
+        roof["traffic"] = traffic.get("hbm_bytes_per_launch") if use_traffic else None
+        roof["traffic_source"] = traffic_src if use_traffic else None
+        roof["traffic_note"] = ("HBM bytes per CONV LAUNCH (direct kernel, or transform + GEMM + transform of a Winograd layer), "
+                                "FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of this command on this episode")
         sname = "B=%d queries %dx%d + N=%d supports %dx%d" % (local_batch, args.size, args.size, args.classes,
                                                                 args.support, args.support)
         which = ("the episode of BASELINE.json's metric string (64x416x416 query + 20x224x224 support) on configs[1]'s "
-                 "darknet_dynamic.cfg + reweighting_net.cfg base-training model"
-                 if (args.batch, args.classes, args.size, args.support) == (64, 20, 416, 224) else
+                 "darknet_dynamic.cfg + reweighting_net.cfg base-training model" if headline_shape else
                  "BASELINE configs[1] darknet_dynamic.cfg + reweighting_net.cfg base-training episode")
         res = {
             "metric": "episodes/sec (%dx%dx%d query + %dx%dx%d support) %s" % (
@@ -523,7 +649,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "img_per_s": global_batch * args.steps / elapsed,
-            "loss": loss_val,
+            "loss": r["loss"],
             "config": {"workload": "%s: %s per %s, %s, neg_ratio=%s" % (
                            which, sname, "rank (supports replicated, queries split)" if strong else "GPU",
                            "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
@@ -531,27 +657,68 @@ def main():
                        "episode_forward_gflop": full_flops / 1e9},
             "roofline": roof,
             "gpu_clock": dict(clock, what="shader clock from a dependent fp32-MFMA chain on every SIMD (fsd_clock_probe), right "
-                                          "before the warm-up, after it and after the timed region; the MFMA peaks in "
-                                          "`roofline` are quoted at the nominal clock"),
+                                          "before the warm-up and after the timed region; the MFMA peaks in `roofline` are "
+                                          "quoted at the nominal clock"),
             "streams": {"enabled": bool(streams_on),
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
                                 "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
-                        "profiled_steps_on_one_stream": prof_steps,
-                        "profiled_step_index": [prof_lo, prof_hi] if prof_steps else None,
-                        "ms_per_step_unprofiled": (((t_a - t0) + (t_end - t_b)) / (args.steps - prof_steps) * 1e3
-                                                   if t_a is not None and args.steps > prof_steps else None),
-                        "ms_per_step_profiled": ((t_b - t_a) / prof_steps * 1e3 if t_a is not None else None)},
+                        "profiled_steps_on_one_stream": r["prof_steps"], "profiled_step_index": r["prof_index"],
+                        "ms_per_step_unprofiled": r["ms_unprofiled"], "ms_per_step_profiled": r["ms_profiled"]},
         }
-        if opt is not None:
-            res["dp"] = {"world_size": opt.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
-                         "gradient_buckets": len(opt.buckets), "allreduce_dtype": str(opt.grad_dtype).replace("torch.", ""), "bucket_mb": [4e-6 * (hi - lo) for lo, hi in opt.buckets],
-                         "allreduce_wait_ms_per_step": [v / args.steps for v in opt.allreduce_wait_ms]}
+        if leg.opt is not None:
+            o = leg.opt
+            res["dp"] = {"world_size": o.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
+                         "gradient_buckets": len(o.buckets), "allreduce_dtype": str(o.grad_dtype).replace("torch.", ""),
+                         "bucket_mb": [4e-6 * (hi - lo) for lo, hi in o.buckets], "bucket_launch_order": list(o.launch_order_last),
+                         "allreduce_wait_ms_per_step": [v / args.steps for v in o.allreduce_wait_ms],
+                         "overlap": o.overlap_report()}
         if world == 1 and not args.no_extras:
-            res["also_measured"] = extras(net, region, opt, args, dev, x, metax, mask, target, full_flops, blocks, lblocks)
+            also = {}
+            # (1) keep the GPU busy in one stretch: the sustained run of the headline step, then every other GPU leg
+            t = timed(step, n=150, w=0)
+            also["sustained_run"] = {"what": "150 more steps of the headline episode right after the timed region (thermal / clock "
+                                             "steady state)", "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t,
+                                     "probe_mhz_after": ops.clock_probe_mhz(dev)}
+
+            def fwd():
+                with torch.no_grad():
+                    leg.region(leg.net(x, metax, mask), target)
+            t = timed(fwd, n=5, w=2)
+            peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            also["forward_only"] = {"what": "forward (train-mode BN) + RegionLoss forward/grad kernel, no backward, same episode",
+                                    "ms": t * 1e3, "episodes_per_s": 1.0 / t, "algorithmic_tflops": full_flops / t / 1e12,
+                                    "frac_of_mfma_peak_algorithmic": full_flops / t / 1e12 / peak}
+            also["backbone_forward"] = backbone_forward(dyn_cfg, args.dtype, dev, args.batch, args.size)
+            if args.mode == "train":
+                also.update(other_configs(leg, args, dev, blocks, lblocks))
+            also["inference"] = {args.dtype: inference_latency(leg, dev, args.size)}
+            other = "bf16" if args.dtype == "f32" else "f32"
+            if args.mode == "train":
+                # (2) the other storage mode on the same episode: its own model, trainer, timed region and roofline
+                leg2 = Leg(dyn_cfg, rw_cfg, other, dev, None, global_batch, args.mode)
+                step2 = leg2.stepper(x, metax, mask, target)
+                r2 = leg2.run(step2, 12, 5, 1, streams_on)
+                ms2 = r2["elapsed"] / r2["steps"] * 1e3
+                also[other + "_mode"] = {
+                    "what": "the same episode and train step in the %s (BASELINE configs[2] / [4] arithmetic on one GPU): "
+                            "5 warm-up + 12 timed steps, 1 of them profiled on one stream"
+                            % ("bf16 storage mode" if other == "bf16" else "fp32 mode"),
+                    "ms_per_step": ms2, "episodes_per_s": 1e3 / ms2, "img_per_s": args.batch * 1e3 / ms2, "dtype": other,
+                    "ms_per_step_unprofiled": r2["ms_unprofiled"], "loss": r2["loss"], "roofline": roofline_block(r2, other, ms2)}
+                also["backbone_forward_" + other] = backbone_forward(dyn_cfg, other, dev, args.batch, args.size)
+                also[other + "_mode"]["other_configs"] = other_configs(leg2, args, dev, blocks, lblocks)
+                also["inference"][other] = inference_latency(leg2, dev, args.size)
+                del leg2, step2
+                torch.cuda.empty_cache()
+            res["also_measured"] = also
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev)
-            if parity is not None:
-                res["parity"] = parity
+            dtypes = [args.dtype] + (["bf16" if args.dtype == "f32" else "f32"] if (args.mode == "train" and not args.no_extras) else [])
+            res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes)
+            if args.dtype in parity:
+                res["parity"] = parity[args.dtype]
+            for d in parity:
+                if d != args.dtype and (d + "_mode") in res.get("also_measured", {}):
+                    res["also_measured"][d + "_mode"]["parity"] = parity[d]
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -156,6 +156,23 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
         _accumulate(grads, xv, dx)
 
 
+def run_early(ctx, grad_out):
+    """Backward sweep of the network behind autograd context `ctx` (darknet_meta._NetFn), run by its CONSUMER's sweep the
+    moment d(output) exists.  The result is parked on the context; _NetFn.backward hands it to autograd when the engine
+    gets there (and recomputes if autograd presents a different gradient, i.e. the output had another consumer)."""
+    grad_out = grad_out.contiguous()
+    if ctx.side is not None:
+        main = torch.cuda.current_stream()
+        s = streams.side(grad_out.device, ctx.side)
+        s.wait_event(main.record_event())
+        with torch.cuda.stream(s):
+            grads = run(ctx.net, ctx.tape, grad_out, ctx.params, wgrad_stream=False)
+        streams.keep_alive(s, grad_out)
+    else:
+        grads = run(ctx.net, ctx.tape, grad_out, ctx.params)
+    ctx.early_result = (grad_out.data_ptr(), tuple(grad_out.shape), grads)
+
+
 def run(net, tape, grad_out, params, wgrad_stream=True):
     """Returns {"params": [grad or None, ... in the order of `params`], "dyn": grad of the vectors}.
     wgrad_stream: launch the weight gradients on the "wgrad" side stream (streams.py); the current stream waits for
@@ -190,9 +207,15 @@ def run(net, tape, grad_out, params, wgrad_stream=True):
             d_head, d_dyn = ops.head_unfold_bwd(dweff, head.weight.detach(), dyn.detach(), param=head.weight)
             pgrads[id(head.weight)] = d_head
             grad_dyn = d_dyn
-            # the reweighting net's backward (its own stream) may start as soon as this exists; published only when the
-            # vectors really came from a network that ran on a side stream (otherwise nobody would ever claim the event)
-            if streams.ENABLED and streams.META and streams.from_side(dyn):
+            early = streams.take_early(dyn)
+            if early is not None and early.tape is not None:
+                # the vectors came from the reweighting net of the same forward() call: queue ITS backward sweep now (on its
+                # side stream when it has one) instead of after this whole sweep -- its gradients are complete a few ms
+                # into the step, and a data-parallel trainer starts their all-reduce under the detector's backward
+                run_early(early, d_dyn)
+            # otherwise the reweighting net's backward (its own stream) may start as soon as this exists; published only when
+            # the vectors really came from a network that ran on a side stream (nobody else would ever claim the event)
+            elif streams.ENABLED and streams.META and streams.from_side(dyn):
                 streams.publish(d_dyn, torch.cuda.current_stream().record_event())
             if head.bias is not None:
                 dst = ops.grad_dst(head.bias, (o_ch,), g.t.device)
@@ -224,6 +247,8 @@ def run(net, tape, grad_out, params, wgrad_stream=True):
             pass
         else:
             raise NotImplementedError("backward of tape record %r" % kind)
+        if ops.GRAD_HOOK is not None and kind in ("conv", "head"):
+            ops.GRAD_HOOK((ws,))             # a trainer may start the all-reduce of a bucket this layer completed
     if ws is not None:
         torch.cuda.current_stream().wait_stream(ws)
     # gradients the kernels wrote straight into a trainer's flat buffer are not handed to autograd again

@@ -255,13 +255,30 @@ class _NetFn(torch.autograd.Function):
             out, tape = net.forward(inputs, dyn=dyn, training=training, record=record)
         ctx.net, ctx.tape, ctx.n_inputs, ctx.has_dyn = net, tape, n_inputs, has_dyn
         ctx.params = tensors[n_inputs + (1 if has_dyn else 0):]
+        ctx.early_result = None
+        if defer and record:                  # forward(): the vectors have one consumer, the detector of this very call
+            streams.register_early(out, ctx)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         from . import backward as bw
         grad_out = grad_out.contiguous()
-        if ctx.side is not None:
+        early = ctx.early_result
+        if early is not None and early[0] == grad_out.data_ptr() and early[1] == tuple(grad_out.shape):
+            # the detector's sweep already ran this network's backward on this very gradient (backward.run_early)
+            grads = early[2]
+            ctx.early_result = None
+            if ctx.side is not None:
+                main = torch.cuda.current_stream()
+                main.wait_stream(streams.side(grad_out.device, ctx.side))
+                streams.keep_alive(main, *[g for g in grads["params"] if g is not None])
+        elif early is not None:
+            # the sweep ran early on another tensor than autograd now presents (a hook or a second consumer changed the
+            # gradient): its results may already be inside a running all-reduce -- refuse rather than overwrite them
+            raise RuntimeError("the reweighting vectors of Darknet.forward() received a gradient that differs from the one "
+                               "their early backward sweep consumed; call meta_forward() / detect_forward() separately")
+        elif ctx.side is not None:
             main = torch.cuda.current_stream()
             s = streams.side(grad_out.device, ctx.side)
             if not streams.await_tensor(grad_out, s):     # published by the head's backward: start as soon as it is there

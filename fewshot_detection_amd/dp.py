@@ -10,16 +10,40 @@ by the global batch, train_meta.py:144).  BatchNorm statistics stay per-rank, as
 Parameters and momentum live in ONE flat fp32 buffer each, so the optimizer step is a single fused
 HIP kernel per bucket (fsd_sgd_step) instead of ~200 small launches, and each collective moves tens
 of MB (xGMI is point-to-point: few large transfers beat many small ones).
+
+Overlap ("bucket the grads in reverse layer order, overlap with the remaining dgrad / wgrad").  The flat
+buffer is laid out in the order in which the backward pass FINISHES the gradients: the reweighting net first (its
+backward starts as soon as the head's backward has produced d(vectors) and is a few ms long), then the detector from
+its last layer down to layer 0 -- the 47 / 38 / 38 MB tensors of L29 / L24 / L23 come first, the small early layers last.
+Buckets are contiguous ranges of that order, the last one small.  The backward sweep calls the trainer after EVERY layer
+(ops.GRAD_HOOK); a bucket whose last gradient kernel has just been queued gets a "comm" stream that waits for the
+streams those kernels run on, and its all-reduce is started there -- while the sweep is still queueing (and the GPU still
+running) the layers below.  Buckets start in ascending index on every rank (enforced), which is their readiness order.
 """
+import time
+
 import torch
 
 from . import ops
 from .engine import bump_weight_epoch
 
 
-def flatten_parameters(module):
-    """Re-home every parameter of `module` as a view into one contiguous fp32 buffer."""
-    params = [p for p in module.parameters()]
+def readiness_order(module):
+    """Parameters in the order their gradients are completed by one backward pass: for the meta detector the reweighting
+    net (its sweep is queued as soon as d(vectors) exists, see backward.run_early), then the detector from the head down;
+    for any other module the reverse of the registration order."""
+    learnet, det = getattr(module, "learnet_models", None), getattr(module, "models", None)
+    if learnet is not None and det is not None:
+        order = list(reversed(list(learnet.parameters()))) + list(reversed(list(det.parameters())))
+        seen = {id(p) for p in order}
+        order += [p for p in reversed(list(module.parameters())) if id(p) not in seen]
+        return order
+    return list(reversed(list(module.parameters())))
+
+
+def flatten_parameters(module, order=None):
+    """Re-home every parameter of `module` as a view into one contiguous fp32 buffer, laid out in `order`."""
+    params = list(order) if order is not None else [p for p in module.parameters()]
     total = sum(p.numel() for p in params)
     flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
     off = 0
@@ -37,10 +61,20 @@ def bucket_bounds(total, n_buckets):
     return [(s, min(total, s + step)) for s in range(0, total, step)]
 
 
+def tapered_bounds(total, n_buckets, tail=0.07):
+    """n_buckets contiguous ranges, 1024-aligned, the LAST one only `tail` of the buffer: it holds the gradients the
+    backward pass finishes last, and its all-reduce is the one nothing is left to hide."""
+    if n_buckets <= 1 or total < 4096 * n_buckets:
+        return bucket_bounds(total, max(1, n_buckets))
+    cut = int(total * (1.0 - tail)) // 1024 * 1024
+    head = bucket_bounds(cut, n_buckets - 1)
+    return head + [(cut, total)]
+
+
 class EpisodeTrainer(object):
     """SGD(momentum, weight decay) + gradient all-reduce for one Darknet replica."""
 
-    def __init__(self, net, lr, momentum=0.9, weight_decay=0.0, process_group=None, n_buckets=4, step_fn=None,
+    def __init__(self, net, lr, momentum=0.9, weight_decay=0.0, process_group=None, n_buckets=6, step_fn=None,
                  grad_dtype=torch.float32):
         """grad_dtype: wire format of the gradient all-reduce.  torch.bfloat16 (BASELINE configs[2] / [4]) halves the
         xGMI payload (133 MB instead of 265 MB per step): each bucket is rounded to bf16 right before its
@@ -50,10 +84,10 @@ class EpisodeTrainer(object):
         self.grad_dtype = grad_dtype
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.dist = process_group            # the torch.distributed module (or None for one GPU)
-        self.flat, self.params = flatten_parameters(net)
+        self.flat, self.params = flatten_parameters(net, readiness_order(net))
         self.grad = torch.zeros_like(self.flat)
         self.mom = torch.zeros_like(self.flat)
-        self.buckets = bucket_bounds(self.flat.numel(), n_buckets)
+        self.buckets = tapered_bounds(self.flat.numel(), n_buckets)
         self.sink, off = {}, 0               # parameter -> its slice of the flat gradient buffer
         self._bucket_params = [[] for _ in self.buckets]         # ids of the parameters overlapping each bucket
         for p in self.params:
@@ -64,6 +98,12 @@ class EpisodeTrainer(object):
             off += p.numel()
         self._works = [None] * len(self.buckets)
         self._launch_order = []              # bucket indices in the order their all-reduce was started this step
+        self.launch_order_last = []          # ... of the last completed step
+        self._t_backward0 = 0.0
+        self._launch_host_ms = [None] * len(self.buckets)        # host time since the start of backward() at launch
+        self._ready_events = [None] * len(self.buckets)          # GPU: "this bucket's gradients are complete"
+        self._bw_end_event, self._bw_host_ms = None, 0.0
+        self._overlap = None                 # last step's measurements (time_allreduce only)
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
         self.world_size = 1 if self.dist is None else int(self.dist.get_world_size())
@@ -110,12 +150,13 @@ class EpisodeTrainer(object):
                 p.grad = None
             off += n
 
-    def _launch_ready(self, sunk, final=False):
+    def _launch_ready(self, sunk, final=False, wait_streams=()):
         """Start the all-reduce of every bucket whose gradients are complete (all of its parameters were written by
-        the backward kernels, or -- `final` -- everything has been gathered).  Called once per network as its backward
-        finishes (ops.GRAD_HOOK), so the reduction of the detector's buckets runs under the reweighting net's backward;
-        every rank launches the same buckets in the same order."""
-        if self.dist is None or self.dist.get_world_size() <= 1:
+        the backward kernels, or -- `final` -- everything has been gathered).  Called by the backward sweep after every
+        layer (ops.GRAD_HOOK) with the streams its gradient kernels were queued on: the collective is started on a
+        "comm" stream that waits for exactly those, so it runs under the rest of the sweep.  Every rank launches the
+        same buckets in the same (ascending = readiness) order."""
+        if self.dist is None or self.world_size <= 1:
             return
         for i, (lo, hi) in enumerate(self.buckets):
             if self._works[i] is not None:
@@ -126,17 +167,52 @@ class EpisodeTrainer(object):
                 raise RuntimeError("gradient buckets must be reduced in ascending order on every rank (bucket %d after "
                                    "%d): ranks would pair different buckets in one collective" % (i, self._launch_order[-1]))
             self._launch_order.append(i)
-            buf = self.grad[lo:hi]
-            if self.grad_lp is not None:
-                buf = self.grad_lp[lo:hi]
-                buf.copy_(self.grad[lo:hi])
-            self._works[i] = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+            self._launch_host_ms[i] = (time.perf_counter() - self._t_backward0) * 1e3
+            if self.grad.is_cuda:
+                from . import streams
+                cur = torch.cuda.current_stream()
+                comm = streams.side(self.grad.device, "comm")
+                comm.wait_stream(cur)
+                for s_ in wait_streams:
+                    if s_ is not None and s_ != cur:
+                        comm.wait_stream(s_)
+                with torch.cuda.stream(comm):
+                    if self.time_allreduce:
+                        self._ready_events[i] = comm.record_event(torch.cuda.Event(enable_timing=True))
+                    self._works[i] = self._start(lo, hi)
+            else:
+                self._works[i] = self._start(lo, hi)
+
+    def _start(self, lo, hi):
+        buf = self.grad[lo:hi]
+        if self.grad_lp is not None:
+            buf = self.grad_lp[lo:hi]
+            buf.copy_(self.grad[lo:hi])
+        return self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def overlap_report(self):
+        """Where the collectives of the LAST step started relative to its backward pass (needs time_allreduce and > 1
+        rank; synchronises): per bucket the host time since loss.backward() began at which its all-reduce was queued,
+        and how long before the END of the backward pass on the GPU its gradients were complete (positive = the
+        collective could start that many ms before the backward finished)."""
+        o = self._overlap
+        if not o:
+            return None
+        torch.cuda.synchronize() if self.grad.is_cuda else None
+        ready = [None if (e is None or o["bw_end"] is None) else e.elapsed_time(o["bw_end"]) for e in o["ready"]]
+        return {"launch_order": o["order"], "launch_host_ms_after_backward_start": o["host_ms"],
+                "backward_enqueue_host_ms": o["bw_host_ms"], "gpu_ms_ready_before_backward_end": ready,
+                "buckets_launched_before_backward_enqueue_ended": sum(1 for v in o["host_ms"] if v is not None and v < o["bw_host_ms"])}
 
     def reduce_and_step(self):
         """Bucketed SUM all-reduce overlapped with the per-bucket optimizer kernel."""
         self._launch_ready((), final=True)
         if self.world_size > 1 and self._launch_order != list(range(len(self.buckets))):
             raise RuntimeError("all-reduce launch order %r is not 0..%d ascending" % (self._launch_order, len(self.buckets) - 1))
+        if self.time_allreduce and self.world_size > 1:
+            self._overlap = {"order": list(self._launch_order), "host_ms": list(self._launch_host_ms),
+                             "ready": list(self._ready_events), "bw_end": self._bw_end_event,
+                             "bw_host_ms": self._bw_host_ms}
         for i, (lo, hi) in enumerate(self.buckets):
             if self._works[i] is not None:
                 if self.time_allreduce:
@@ -150,7 +226,9 @@ class EpisodeTrainer(object):
                     self.grad[lo:hi].copy_(self.grad_lp[lo:hi])
             self._step_fn(lo, hi)
         self._works = [None] * len(self.buckets)
-        self._launch_order = []
+        self.launch_order_last, self._launch_order = self._launch_order, []
+        self._launch_host_ms = [None] * len(self.buckets)
+        self._ready_events = [None] * len(self.buckets)
         self.steps += 1
         bump_weight_epoch()
 
@@ -158,12 +236,17 @@ class EpisodeTrainer(object):
         # While this backward runs, the HIP gradient kernels write dW / dgamma / dbeta straight into the flat
         # buffer (ops.GRAD_SINK); whatever still arrives through autograd is gathered afterwards.
         ops.GRAD_SINK, ops.GRAD_SUNK = self.sink, set()
-        ops.GRAD_HOOK = lambda: self._launch_ready(ops.GRAD_SUNK)
+        ops.GRAD_HOOK = lambda wait_streams=(): self._launch_ready(ops.GRAD_SUNK, wait_streams=wait_streams)
+        self._t_backward0 = time.perf_counter()
+        self._bw_end_event, self._bw_host_ms = None, 0.0
         try:
             loss.backward()
             sunk = ops.GRAD_SUNK
         finally:
             ops.GRAD_SINK, ops.GRAD_SUNK, ops.GRAD_HOOK = None, set(), None
+        self._bw_host_ms = (time.perf_counter() - self._t_backward0) * 1e3
+        if self.time_allreduce and self.grad.is_cuda and self.world_size > 1:
+            self._bw_end_event = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
         # a bucket that is already being reduced had all of its parameters sunk: nothing of it is left to gather
         self.gather_grads(sunk)
         self.reduce_and_step()

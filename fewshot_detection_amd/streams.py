@@ -85,6 +85,24 @@ def from_side(t):
         return _key(t) in _FROM_SIDE
 
 
+_EARLY = {}       # (device index, data_ptr) of reweighting vectors -> the autograd context of the network that made them
+
+
+def register_early(t, ctx):
+    """`t` = vectors that go straight into the detector of the same forward() call (single consumer): the detector's
+    backward may run the producer's backward sweep itself as soon as d(t) exists (backward.run_early)."""
+    with _LOCK:
+        _EARLY.pop(_key(t), None)
+        _EARLY[_key(t)] = ctx
+        while len(_EARLY) > 4:
+            _EARLY.pop(next(iter(_EARLY)))
+
+
+def take_early(t):
+    with _LOCK:
+        return _EARLY.pop(_key(t), None)
+
+
 def keep_alive(stream, *tensors):
     """Tell the allocator that `stream` has work pending on these tensors (allocated on another stream)."""
     for t in tensors:

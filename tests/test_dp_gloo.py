@@ -53,7 +53,10 @@ def _worker(rank, world, port, out_dir):
     for _ in range(3):
         loss = (net(shard) ** 2).sum()                           # a SUM loss, like the region loss
         tr.backward_and_step(loss)
-    torch.save(tr.flat.clone(), os.path.join(out_dir, "rank%d.pt" % rank))
+    assert tr.launch_order_last == list(range(len(tr.buckets)))   # every bucket was reduced, in ascending = readiness order
+    # the flat buffer is laid out in gradient-readiness order (last layer first): compare in registration order
+    assert tr.params[0] is net.b.bias and tr.params[-1] is net.a.weight
+    torch.save(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -76,11 +79,32 @@ def test_two_rank_sum_allreduce_equals_full_batch_sgd(tmp_path):
 
 
 def test_bucket_bounds_cover_buffer():
-    from fewshot_detection_amd.dp import bucket_bounds
+    from fewshot_detection_amd.dp import bucket_bounds, tapered_bounds
     for total in (1, 1023, 1024, 5000, 66287742):
-        b = bucket_bounds(total, 4)
-        assert b[0][0] == 0 and b[-1][1] == total
-        assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+        for b in (bucket_bounds(total, 4), tapered_bounds(total, 6)):
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            assert all(lo % 1024 == 0 for lo, _ in b)
+    b = tapered_bounds(66287742, 6)
+    assert len(b) == 6 and (b[-1][1] - b[-1][0]) < 0.08 * 66287742   # the bucket nothing can hide is the small one
+
+
+def test_flat_buffer_follows_gradient_readiness_order(tmp_path):
+    """The meta detector's flat parameter buffer: reweighting net first (its backward sweep is queued as soon as
+    d(vectors) exists), then the detector from the head down to layer 0 -- SURVEY 5: L29 / L24 / L23 lead, L0 is last."""
+    from fewshot_detection_amd import cfgs
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from fewshot_detection_amd.dp import readiness_order
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    net = Darknet(dyn_cfg, rw_cfg)
+    order = readiness_order(net)
+    assert len(order) == len(list(net.parameters())) and len({id(p) for p in order}) == len(order)
+    n_learnet = len(list(net.learnet_models.parameters()))
+    assert all(any(p is q for q in net.learnet_models.parameters()) for p in order[:n_learnet])
+    det = order[n_learnet:]
+    assert det[-1] is net.models[0][0].weight                      # layer 0's 3x3x3x32 filter is the last gradient
+    big = [p.numel() for p in det if p.numel() > 9_000_000]
+    assert big == [1280 * 1024 * 9, 1024 * 1024 * 9, 1024 * 1024 * 9]   # L29, L24, L23 in that order
 
 
 class _TinyBN(nn.Module):
@@ -103,7 +127,7 @@ def _worker_sync(rank, world, port, out_dir):
     net.bn.running_mean.fill_(float(rank + 1))
     net.bn.running_var.fill_(float(rank + 2))
     tr = EpisodeTrainer(net, 0.01, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
-    torch.save(dict(flat=tr.flat.clone(), mean=net.bn.running_mean.clone(), var=net.bn.running_var.clone(),
+    torch.save(dict(flat=torch.cat([p.detach().reshape(-1) for p in net.parameters()]), mean=net.bn.running_mean.clone(), var=net.bn.running_var.clone(),
                     world=tr.world_size), os.path.join(out_dir, "sync%d.pt" % rank))
     # buckets must be reduced in ascending order on every rank: a descending launch is refused loudly
     tr._launch_order = [1]

@@ -57,8 +57,12 @@ def _train(rank, world, steps, dist_mod):
     sl = slice(rank * per, (rank + 1) * per)
     x, tgt = x[sl].to(dev), tgt[sl]
     tr = EpisodeTrainer(net, lr=1e-4, momentum=0.9, weight_decay=0.01, process_group=dist_mod, n_buckets=3)
+    tr.time_allreduce = world > 1
     for _ in range(steps):
         tr.backward_and_step(region(net(x, metax.to(dev), mask.to(dev)), tgt))
+    if world > 1 and rank == 0:
+        _train.report = dict(tr.overlap_report(), buckets=len(tr.buckets), first_params_are_learnet=bool(
+            any(tr.params[0] is p for p in net.learnet_models.parameters())))
     return tr.flat.detach().cpu()
 
 
@@ -69,6 +73,8 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     flat = _train(rank, world, 3, dist)
     torch.save(flat, os.path.join(out_dir, "rank%d.pt" % rank))
+    if rank == 0:
+        torch.save(_train.report, os.path.join(out_dir, "overlap.pt"))
     dist.destroy_process_group()
 
 
@@ -85,6 +91,16 @@ def test_two_ranks_reproduce_one_full_batch_process(tmp_path):
     assert float((r0 - ref).abs().max()) < 1e-5 * float(ref.abs().max())
     moved = _train(0, 1, 0, None)
     assert float((ref - moved).abs().max()) > 1e-6                # the steps really changed the parameters
+    # VERDICT r2 #4 / SURVEY 8e: the collectives start UNDER the backward pass.  The flat buffer is in readiness order
+    # (reweighting net first, detector head-down), the sweep calls the trainer after every layer, and a finished bucket's
+    # all-reduce is queued on the "comm" stream at once: the first bucket is launched while the host is still queueing
+    # the detector's sweep, and on the GPU its gradients are complete before the backward pass ends.
+    rep = torch.load(os.path.join(str(tmp_path), "overlap.pt"))
+    assert rep["first_params_are_learnet"] and rep["buckets"] == 3 and rep["launch_order"] == [0, 1, 2]
+    host = rep["launch_host_ms_after_backward_start"]
+    assert host[0] < host[1] < host[2] and host[0] < rep["backward_enqueue_host_ms"], rep
+    assert rep["buckets_launched_before_backward_enqueue_ended"] >= 2, rep
+    assert rep["gpu_ms_ready_before_backward_end"][0] > 0.0, rep
 
 
 def test_bench_two_ranks_one_json_line():
@@ -132,6 +148,9 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu():
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
     assert abs(res["img_per_s"] - 4 * res["value"]) < 1e-6 * res["img_per_s"]        # one 4-query episode per step
     assert res["dp"]["world_size"] == 2 and len(res["dp"]["allreduce_wait_ms_per_step"]) == res["dp"]["gradient_buckets"]
+    ov = res["dp"]["overlap"]
+    assert res["dp"]["bucket_launch_order"] == list(range(res["dp"]["gradient_buckets"]))
+    assert ov["buckets_launched_before_backward_enqueue_ended"] >= 1 and ov["gpu_ms_ready_before_backward_end"][0] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: >= 2 GPUs")
