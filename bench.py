@@ -496,7 +496,8 @@ def inference_latency(leg, dev, S):
 
 
 def other_configs(leg, args, dev, blocks, lblocks):
-    """Train-step times of the other BASELINE configs' shapes on one GPU (1 warm-up + 5 steps each)."""
+    """Train-step times of the other BASELINE configs' shapes on one GPU (2 warm-up + 5 timed steps each).  No
+    empty_cache() in between: handing the pool back makes the next shape's steps pay hipMalloc of multi-GB blocks."""
     from fewshot_detection_amd.cfg import cfg
     out = {}
     keep = cfg.neg_ratio
@@ -510,13 +511,12 @@ def other_configs(leg, args, dev, blocks, lblocks):
             cfg.neg_ratio = neg
             x, metax, mask, target = synth_episode(2000 + N, B, N, S, Sm)
             step = leg.stepper(x.to(dev).contiguous(), metax.to(dev), mask.to(dev), target, batch=B)
-            t = timed(step, n=5, w=1)
+            t = timed(step, n=5, w=2)           # (a new shape re-sizes every cached workspace: two warm-up steps)
             fl = episode_flops(blocks, lblocks, B, N, S, Sm)
             out[key] = {"what": "train step, B=%d queries %dx%d + %d supports %dx%d, neg_ratio=%s (%s)" % (B, S, S, N, Sm, Sm, neg, what),
                         "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t, "img_per_s": B / t,
                         "episode_forward_gflop": fl / 1e9, "dtype": leg.dtype}
             del x, metax, mask, step
-            torch.cuda.empty_cache()
     finally:
         cfg.neg_ratio = keep
     return out

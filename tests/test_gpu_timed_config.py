@@ -203,3 +203,128 @@ def test_c2_full_batch_episode_vs_oracle(dev, tmp_path, seen):
     for name in ("models.31.conv24.weight", "models.31.conv24.bias", "models.29.bn22.weight", "learnet_models.12.conv7.weight"):
         gm, gr = mine[name].grad.cpu(), named[name].grad
         assert float((gm - gr).abs().max()) / float(gr.abs().max()) < 1e-3, name
+
+
+# Blocks of darknet_dynamic.cfg whose backward is checked in isolation at the TIMED shapes (B = 64, 416x416):
+#   0  first block 3->32 @416 + pool (one-sweep first-layer backward, no data gradient)
+#   2  direct 3x3 32->64 @208 + pool          4  F(4x4) Winograd 64->128 @104          5  1x1 128->64 @104
+#   6  F(4x4) 64->128 @104 + pool             8  F(4x4) 128->256 @52                   12 F(4x4) 256->512 @26
+#   18 F(4x4) 512->1024 @13 (DMA 128x128 GEMMs, weight-gradient tail launch)           19 1x1 1024->512 @13
+#   23 F(4x4) 1024->1024 @13                  29 F(4x4) 1280->1024 @13 (the concatenated route input)
+TEACHER_BLOCKS = [0, 2, 4, 5, 6, 8, 12, 18, 19, 23, 29]
+
+
+def test_teacher_forced_block_backward_at_the_timed_shapes(dev, tmp_path):
+    """the end-to-end gradient check above has to allow 4e-2 (winner flips of two fp32 forwards propagate
+    to every earlier layer).  Here every block kind gets the ORACLE's own block input x and output gradient dz from one
+    B = 64 run of the oracle detector, so the HIP backward of that block -- with the kernel variants only the timed shapes
+    select -- is compared on identical inputs: dx, dW, dgamma, dbeta against fp64 autograd of the block, relative L2
+    <= 1e-4 (measured <= 1.6e-5; VERDICT asked for 1e-3), with dz zeroed where the activation kink / a pooling tie is within 1e-4 (see below)."""
+    import torch.nn.functional as F
+    from fewshot_detection_amd import backward as bw
+    from fewshot_detection_amd import cfgs, ops
+    from fewshot_detection_amd.cfg import parse_cfg
+    from fewshot_detection_amd.darknet import Darknet as PlainDarknet
+    from fewshot_detection_amd.ops import View
+    from oracle.net import OracleDarknet
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    blocks = parse_cfg(dyn_cfg)
+    torch.manual_seed(9)
+    ora = OracleDarknet(dyn_cfg, rw_cfg).train()
+    B, S = 64, 416
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(B, 3, S, S, generator=g)
+    dyn = [torch.rand(2, 1024, 1, 1, generator=g)]
+    # ---- one oracle run of the detector: block inputs and output gradients of the selected blocks -------------------
+    cap = {}
+    hooks = []
+    for i in TEACHER_BLOCKS:
+        pooled = blocks[i + 2]["type"] == "maxpool"               # blocks[0] is [net]: layer i is blocks[i + 1]
+
+        def fwd_in(mod, inp, out, i=i):
+            cap.setdefault(i, {})["x"] = inp[0].detach().clone()
+
+        def fwd_out(mod, inp, out, i=i):
+            out.register_hook(lambda gr, i=i: cap[i].__setitem__("dz", gr.detach().clone()))
+
+        hooks.append(ora.models[i].register_forward_hook(fwd_in))
+        hooks.append(ora.models[i + 1 if pooled else i].register_forward_hook(fwd_out))
+    out = ora.detect_forward(x, dyn)
+    (out * torch.randn(out.shape, generator=g)).sum().backward()
+    for h in hooks:
+        h.remove()
+    del out
+    worst = {}
+    for i in TEACHER_BLOCKS:
+        blk = blocks[i + 1]
+        pooled = blocks[i + 2]["type"] == "maxpool"
+        xi, dz = cap[i]["x"], cap[i]["dz"]
+        conv, bn = ora.models[i][0], ora.models[i][1]
+        # ---- fp64 autograd of the block on (x, dz) ---------------------------------------------------------------
+        x64 = xi.double().requires_grad_(True)
+        w64 = conv.weight.detach().double().requires_grad_(True)
+        ga64 = bn.weight.detach().double().requires_grad_(True)
+        be64 = bn.bias.detach().double().requires_grad_(True)
+        y = F.conv2d(x64, w64, None, 1, (conv.kernel_size[0] - 1) // 2)
+        t = F.batch_norm(y, None, None, ga64, be64, True, 0.1, bn.eps)
+        z = F.leaky_relu(t, 0.1)
+        # Positions whose pre-activation sits within 1e-4 of the leaky kink (or whose pooling window is that close to a tie)
+        # take a different slope / winner in two correct evaluations that differ in the 7th digit -- a fraction f of
+        # flipped elements costs sqrt(f) of relative L2 (measured 1e-3 at f = 1e-6).  Their dz is zeroed on BOTH sides
+        # (about 1e-4 of all positions), so the comparison is about the kernels, not about ties.
+        with torch.no_grad():
+            if pooled:
+                win = t.detach().reshape(t.shape[0], t.shape[1], t.shape[2] // 2, 2, t.shape[3] // 2, 2)
+                win = win.permute(0, 1, 2, 4, 3, 5).reshape(t.shape[0], t.shape[1], t.shape[2] // 2, t.shape[3] // 2, 4)
+                top = torch.topk(win, 2, dim=-1).values
+                act = F.leaky_relu(top, 0.1)
+                safe = ((act[..., 0] - act[..., 1]) > 1e-4) & (top[..., 0].abs() > 1e-4)
+            else:
+                safe = t.detach().abs() > 1e-4
+            masked = float((~safe).double().mean())
+            dz = dz * safe.to(dz.dtype)
+        if pooled:
+            z = F.max_pool2d(z, 2, 2)
+        z.backward(dz.double())
+        ref = {"dx": x64.grad, "dW": w64.grad, "dgamma": ga64.grad, "dbeta": be64.grad, "z": z.detach()}
+        del y, z
+        # ---- the HIP block: the same cfg block (+ its maxpool) as a one-block network ------------------------------
+        net_blk = dict(blocks[0], channels=str(xi.shape[1]), height=str(xi.shape[2]), width=str(xi.shape[3]))
+        sub = [net_blk, dict(blk)] + ([dict(blocks[i + 2])] if pooled else [])
+        net = PlainDarknet(sub)
+        net.models[0][0].weight.data.copy_(conv.weight.data)
+        net.models[0][1].weight.data.copy_(bn.weight.data)
+        net.models[0][1].bias.data.copy_(bn.bias.data)
+        net = net.to(dev).train()
+        eng = net._net
+        res, tape = eng.forward([xi.to(dev)], training=True, record=True)
+        rec = [r for r in tape if r["kind"] == "conv"][0]
+        zerr = float((res.cpu().double() - ref["z"]).norm() / ref["z"].norm())
+        zv = rec["z"]
+        gv = ops.nchw_to_nhwc(dz.to(dev), pad_to=4)
+        grads = {id(zv): View(gv.t, zv.B, zv.H, zv.W, zv.C, 0)}
+        pgrads = {}
+        first = tape[0]["x"] if i == 0 else None
+        bw._conv_backward(eng, rec, grads, pgrads, first)
+        torch.cuda.synchronize()
+        errs = {"z": zerr, "masked": masked}
+        cw, cb = net.models[0][0], net.models[0][1]
+        for name, t in (("dW", pgrads[id(cw.weight)]), ("dgamma", pgrads[id(cb.weight)]), ("dbeta", pgrads[id(cb.bias)])):
+            r = ref[name]
+            errs[name] = float((t.detach().cpu().double().reshape(r.shape) - r).norm() / r.norm())
+        if i != 0:
+            dxv = grads[id(rec["x"])]
+            dx = ops.nhwc_to_nchw(dxv).cpu().double()[:, :xi.shape[1]]
+            errs["dx"] = float((dx - ref["dx"]).norm() / ref["dx"].norm())
+        wino = rec.get("wino_tile") or 0
+        print("block %2d (%s%s): %s" % (i, "F(%dx%d)" % (wino, wino) if wino else "%dx%d direct" % (rec["k"], rec["k"]),
+                                       " + pool" if pooled else "", ", ".join("%s %.1e" % kv for kv in errs.items())), flush=True)
+        masked = errs.pop("masked")
+        worst[i] = max(errs.values())
+        assert max(errs.values()) < 1e-4 and masked < 1e-3, (i, errs, masked)
+        if i in (4, 6, 8, 12, 18, 23, 29):
+            assert wino == 4, (i, wino)                            # the timed configuration runs these on F(4x4)
+        del net, eng, tape, rec, grads, pgrads, ref, x64
+        torch.cuda.empty_cache()
+    print("teacher-forced block backward, worst relative L2 per block:", {k: "%.1e" % v for k, v in worst.items()})
