@@ -49,6 +49,7 @@ struct ConvHArgs {
   int Kpad;            // packed weight row stride (elements)
   int m_tiles, n_tiles;
   float slope;         // leaky slope applied to (acc + bias) before the bf16 store; 1 = linear
+  int wide;            // bf16 NHWC epilogue through LDS with 16-byte stores (needs y 16-byte aligned, y_ld % 8 == 0, Cout % 8 == 0)
 };
 
 
@@ -65,18 +66,39 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)__builtin_bit_cast(u16, a) | ((unsigned)__builtin_bit_cast(u16, b) << 16);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT>
-__global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+// 4 waves (256 threads, two workgroups per CU) or 8 waves (512 threads, ONE workgroup per CU = two waves per SIMD): the
+// larger tiles halve the L2 -> LDS bytes per MFMA of the 128x128 tile -- at 128x128x64 a CU running the matrix pipe flat
+// out needs (128+128)*128 B per 512 cycles x 2 workgroups = 64 B/clk of operand delivery, more than the ~56 B/clk/CU the
+// L2 sustains (MI355X_MICROARCH.md); 256x256 needs 32 B/clk.
+//
+// ILV: the DMA pieces of the NEXT chunk are issued between the fragment reads and the MFMAs of the first k-steps of the
+// current one (a piece costs the issuing wave 60-180 cycles of issue time, MI355X_MICROARCH.md; up front, all waves pay
+// that at once with the matrix pipe idle -- spread out, the SIMD's other wave fills the pipe meanwhile): +5 % on the
+// 8-wave tiles, +-1 % on 128x128.
+//
+// NS: LDS stages.  NS = 2: the chunk after the current one is in flight and fully drained (vmcnt(0)) before the barrier.
+// NS > 2: a ring -- chunk kc + NS - 1 is issued while chunk kc is computed, and the wait before the barrier is COUNTED
+// (only chunk kc + 1 has to have landed: (NS - 2) * PIECES newer DMA instructions may stay in flight).  Kept as a
+// tuning aid (FSD_CONV_H_RING=1): measured 5-15 % SLOWER than two drained stages (see the tile choice below).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT, bool ILV = false, int NS = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(ConvHArgs p) {
+  static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
   static_assert(BK == 64 || BK == 32, "k-chunk of 64 or 32 bf16");
+  static_assert(NS >= 2 && NS <= 6, "2 .. 6 LDS stages");
+  static_assert(NS == 2 || ILV, "the ring is written for the interleaved issue");
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
+  static_assert(TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile = whole 32x32 accumulators per wave");
   static_assert(TN == 2 || (TN == 1 && WAVES_N == 1 && !NCHW_F32_OUT),
                 "a wave owns one even/odd pair of 32-channel accumulators, or (32-channel outputs) a single one");
   constexpr int LPR = BK / 8;                 // lanes (16-byte groups) per tile row
-  constexpr int RPP = 256 / LPR;              // tile rows staged per pass of the workgroup
+  constexpr int RPP = NT / LPR;               // tile rows staged per pass of the workgroup
   constexpr int RPW = 64 / LPR;               // ... per wave instruction
-  constexpr int A_PER_T = BM / RPP, B_PER_T = BN / RPP;
+  constexpr int A_PER_T = (BM + RPP - 1) / RPP, B_PER_T = BN / RPP;
+  // the last A pass may be partial (192 rows on 128-row passes): whole WAVES skip it (a_short), never single lanes
+  constexpr bool A_PARTIAL = A_PER_T * RPP != BM;
+  static_assert(B_PER_T * RPP == BN && BM % RPW == 0, "whole B passes; A rows in whole wave instructions");
   constexpr int STAGE = (BM + BN) * BK;       // elements per LDS stage
   constexpr int HSH = BK == 64 ? 1 : 2, HMASK = LPR - 1;
   extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
@@ -89,6 +111,7 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
   const int r0 = tid / LPR, pg = tid % LPR;
   const int g_src = pg ^ ((r0 >> HSH) & HMASK);        // logical k-group this lane fetches for its physical slot
 
+  const bool a_short = A_PARTIAL && (A_PER_T - 1) * RPP + wave * RPW >= BM;   // this wave has no rows in the last A pass
   // im2col bookkeeping of this thread's A rows
   int a_y[A_PER_T], a_x[A_PER_T];
   unsigned a_pix[A_PER_T];
@@ -128,21 +151,28 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
   };
   retap();
 
-  auto gload_lds = [&](int kc, u16* st) {
-    const unsigned coff = (unsigned)f_cc * BK;
-#pragma unroll
-    for (int j = 0; j < A_PER_T; ++j) {
-      const u16* src = (tap_mask >> j) & 1u ? p.x + (a_off[j] + coff) : g_zero_page_h + pg * 8;
-      dma16(src, st + (j * RPP + wave * RPW) * BK);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER_T; ++j)
+  // one DMA piece (a wave instruction = RPW tile rows) of chunk kc: pieces [0, A_PER_T) are A rows, the rest B rows
+  auto piece = [&](int q, int kc, u16* st) {
+    if (q < A_PER_T) {
+      if (A_PARTIAL && q == A_PER_T - 1 && a_short) return;
+      const u16* src = (tap_mask >> q) & 1u ? p.x + (a_off[q] + (unsigned)f_cc * BK) : g_zero_page_h + pg * 8;
+      dma16(src, st + (q * RPP + wave * RPW) * BK);
+    } else {
+      const int j = q - A_PER_T;
       dma16(wrow[j] + kc * BK, st + (BM + j * RPP + wave * RPW) * BK);
+    }
+  };
+  auto advance = [&]() {                    // after the last piece of a chunk: next chunk's channel offset / tap
     if (++f_cc == p.cpt) {
       f_cc = 0;
       ++f_tap;
       retap();
     }
+  };
+  auto gload_lds = [&](int kc, u16* st) {
+#pragma unroll
+    for (int q = 0; q < A_PER_T + B_PER_T; ++q) piece(q, kc, st);
+    advance();
   };
 
   f32x16 acc[TM][TN];
@@ -174,16 +204,76 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
     }
   };
 
-  gload_lds(0, smem_h);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kc = 0; kc < p.nk; ++kc) {
-    if (kc + 1 < p.nk) gload_lds(kc + 1, smem_h + (cur ^ 1) * STAGE);     // that buffer was last read before the previous barrier
-    compute(smem_h + cur * STAGE);
+  // compute with the next chunk's DMA pieces spread over the k-steps (two stages: the last step stays DMA-free, cover
+  // before the drain; a ring has whole chunks of cover)
+  auto compute_ilv = [&](const u16* st, int kc_next, u16* st_next) {
+    constexpr int KS = BK / 16, PIECES = A_PER_T + B_PER_T;
+    constexpr int PPS = NS > 2 ? (PIECES + KS - 1) / KS : KS > 1 ? (PIECES + KS - 2) / (KS - 1) : PIECES;
+    const u16* sa = st + (wm * TM * 32 + (lane & 31)) * BK;
+    const u16* sb = st + (BM + wn * TN * 32 + (lane & 31)) * BK;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ko = (((2 * s + (lane >> 5)) ^ hl) & HMASK) * 8;
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * BK + ko);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 32 * BK + ko);
+      if (st_next != nullptr) {
+#pragma unroll
+        for (int q = s * PPS; q < (s + 1) * PPS && q < PIECES; ++q) piece(q, kc_next, st_next);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = NCHW_F32_OUT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (st_next != nullptr) advance();
+  };
+
+  if constexpr (NS == 2) {
+    gload_lds(0, smem_h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kc = 0; kc < p.nk; ++kc) {
+      if constexpr (ILV) {
+        compute_ilv(smem_h + cur * STAGE, kc + 1, kc + 1 < p.nk ? smem_h + (cur ^ 1) * STAGE : nullptr);
+      } else {
+        if (kc + 1 < p.nk) gload_lds(kc + 1, smem_h + (cur ^ 1) * STAGE);   // that buffer was last read before the previous barrier
+        compute(smem_h + cur * STAGE);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    constexpr int PIECES = A_PER_T + B_PER_T;
+    constexpr int KEEP = (NS - 2) * PIECES;        // DMA instructions of the chunks after the next one
+    constexpr int KEEP_S = (NS - 2) * (PIECES - 1);   // waves that skip the partial A pass issue one piece less per chunk
+    static_assert(KEEP <= 63, "vmcnt is a 6-bit counter");
+    auto wait_next = [&](bool ring_full) {
+      if (!ring_full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (A_PARTIAL && a_short) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP_S) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    };
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+      if (c < p.nk) gload_lds(c, smem_h + c * STAGE);
+    wait_next(p.nk >= NS - 1);
+    __syncthreads();
+    int cur = 0, fill = NS - 1;                    // stage being computed / stage the next issue goes to
+    for (int kc = 0; kc < p.nk; ++kc) {
+      const int nxt = kc + NS - 1;
+      // stage `fill` was computed in iteration kc - 1: every wave is past the barrier that ended it
+      compute_ilv(smem_h + cur * STAGE, nxt, nxt < p.nk ? smem_h + fill * STAGE : nullptr);
+      wait_next(nxt < p.nk);                         // chunk kc + 1 has landed
+      __syncthreads();
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      fill = fill + 1 == NS ? 0 : fill + 1;
+    }
   }
 
   // ---- epilogue ----
@@ -216,17 +306,19 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
     float bv0 = 0.f, bv1 = 0.f;
     if (p.bias != nullptr && n_ok) { bv0 = p.bias[n]; bv1 = p.bias[n + 1]; }
     u16* yb = static_cast<u16*>(p.y);
+    if (!p.wide) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-        if (n_ok && m < p.M) {
-          float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
-          if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
-          *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(v0, v1);
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          if (n_ok && m < p.M) {
+            float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
+            if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
+            *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(v0, v1);
+          }
         }
-      }
+    }
     if (p.bn_partial != nullptr) {
       // per-tile column sums of the fp32 accumulators (rows past M are exact zeros: zero-page operands)
       float* s_stat = reinterpret_cast<float*>(smem_h);            // [WAVES_M][BN][2]
@@ -250,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
         }
       }
       __syncthreads();
-      if (tid < BN) {
+      if (tid < BN) {                                               // (BN <= 256 <= NT)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES_M; ++w) {
@@ -263,6 +355,33 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
           dst[0] = s;
           dst[1] = q;
         }
+      }
+      if (p.wide) __syncthreads();                                  // s_stat is read: the tile below re-uses the space
+    }
+    if (p.wide) {
+      // Wide stores.  A lane's own values are 4 bytes per pixel row (32 store instructions per wave for a 64 x 64 wave
+      // tile), and store ISSUE -- not bandwidth -- is what a short-K tile then waits for (MI355X_MICROARCH.md: an
+      // epilogue of 16 narrow stores per lane costs ~9 k cycles, wide stores halve it).  The tile goes through LDS once
+      // ([BM][BN] bf16, written as it lies in the accumulators, conflict-free) and leaves as 16-byte pieces: a wave
+      // instruction = 4 pixel rows x 256 contiguous bytes (BN = 128), 4x fewer store instructions.  Measured at B = 64:
+      // 104x104 64->128 0.251 -> 0.223 ms, 52x52 128->256 0.163 -> 0.146, 1x1 128->64 data gradient 0.082 -> 0.058.
+      u16* s_tile = smem_h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+          float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
+          if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
+          *reinterpret_cast<unsigned*>(s_tile + ml * BN + wn * 64 + 2 * c_lane) = pack2(v0, v1);
+        }
+      __syncthreads();
+      constexpr int PPR = BN / 8;                                   // 16-byte pieces per tile row
+      for (int it = tid; it < BM * PPR; it += NT) {
+        const int row = it / PPR, pc = it - row * PPR;
+        const int m = m0 + row, nn = n0 + pc * 8;
+        if (m < p.M && nn < p.Cout)                                 // Cout % 8 == 0 (launcher): whole pieces
+          *reinterpret_cast<uint4*>(yb + (long long)m * p.y_ld + nn) = *reinterpret_cast<const uint4*>(s_tile + row * BN + pc * 8);
       }
     }
   } else {
@@ -288,14 +407,15 @@ __global__ __launch_bounds__(256) void conv_bf16_dma_kernel(ConvHArgs p) {
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool ILV = false, int NS = 2>
 int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(u16);
-  const dim3 grid(a.m_tiles * a.n_tiles), block(256);
+  size_t lds = NS * (size_t)(BM + BN) * BK * sizeof(u16);
+  if (a.wide && lds < (size_t)BM * BN * sizeof(u16)) lds = (size_t)BM * BN * sizeof(u16);     // the epilogue's [BM][BN] tile
+  const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.nk * BK), stream);
   if (nchw) {
-    if constexpr (BN >= 64) {
-      auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true>;
+    if constexpr (BN >= 64 && WM * WN == 4) {
+      auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true, ILV, NS>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k, grid, block, lds, stream, a);
@@ -303,7 +423,7 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
       return FSD_ERR_UNSUPPORTED;
     }
   } else {
-    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false>;
+    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, block, lds, stream, a);
@@ -323,9 +443,76 @@ inline bool narrow_tile(long long pixels, int cout) {
   return cout <= 64;
 }
 
+// ---- tile choice ---------------------------------------------------------------------------------------------------
+// Tile ids: 0 = 128x128, 6 = 192x128 (4 waves, TWO workgroups per CU); 1 = 256x256, 2 = 192x256, 3 = 256x128 (8 waves,
+// ONE workgroup per CU); 4 = 128x64, 5 = 128x32 (4 waves, narrow outputs).  The tiles past 0 / 4 / 5 need Cin % 64 == 0,
+// Cout % BN == 0 and the bf16 NHWC store.  FSD_CONV_H_TILE forces one (tuning aid).
+//
+// Measured on MI355X at B = 64 (tools/layer_bench.py; forward / data gradient, TFLOP/s; round 3):
+//   * two independent 4-wave workgroups per CU beat one 8-wave workgroup of the same wave tile (256x128: 811 vs 700 on
+//     13x13 1024->1024): with one barrier domain per CU every wave issues its DMA pieces, drains and restarts in phase;
+//     two domains run out of phase and fill each other's stalls.  A counted-vmcnt ring (4 stages of 32-element chunks,
+//     3 stages at 256x128) LOSES 5-15 % against two drained stages: twice the barriers, and DMA latency was not the wait.
+//   * what the large tiles buy is (a) fewer L2 -> LDS bytes per MFMA and (b) the round count of the 13x13 maps: 10816
+//     pixels = 85 row tiles of 128 (680 tiles of 128x128 on 512 slots = two rounds for 1.33 rounds of work) but 57 of 192:
+//     192x256 -> 228 tiles = ONE round on 256 CUs (1006 vs 811), 192x128 -> 456 of 512 slots (957).
+//   * 192x128 (two workgroups per CU, wide stores) is the best or within 3 % of the best tile on every >= 128-channel
+//     layer with >= 43 k pixels (26x26: 829 vs 722, 52x52: 703 vs 626, 104x104: 500 vs 406).
+struct TileH { int bm, bn, per_cu; };
+constexpr int kNumTiles = 7;
+constexpr TileH kTiles[kNumTiles] = {{128, 128, 2}, {256, 256, 1}, {192, 256, 1}, {256, 128, 1},
+                                     {128, 64, 2}, {128, 32, 2}, {192, 128, 2}};
+
+inline double fill_of(const TileH& t, long long pixels, int cout) {      // used slots / slots of the rounds it takes
+  const long long tiles = ((pixels + t.bm - 1) / t.bm) * ((cout + t.bn - 1) / t.bn);
+  const long long slots = 256LL * t.per_cu;
+  return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
+}
+
+inline int pick_tile_h(long long pixels, int cin, int cout, int ksize, bool nchw, bool has_partial, int bk) {
+  const char* env = getenv("FSD_CONV_H_TILE");                    // read per launch: tests / tuning flip it in-process
+  static const char* n32_env = getenv("FSD_CONV_H_N32");          // tuning aid: 0 disables the 32-channel tile
+  if (!nchw && cout <= 32 && !has_partial && bk == 64 && !(n32_env && n32_env[0] == '0')) return 5;
+  if (!nchw && narrow_tile(pixels, cout)) return 4;
+  if (nchw || bk != 64 || cin % 64) return 0;
+  if (env && env[0] >= '0' && env[0] <= '6' && env[0] != '4' && env[0] != '5') {
+    const int t = env[0] - '0';
+    return (cout % kTiles[t].bn == 0) ? t : 0;
+  }
+  if (cout % 128) return 0;
+  // small maps with a long reduction (the 13x13 / 19x19 layers): an 8-wave tile if it fills one round of CUs well
+  if (pixels <= 32768 && cout % 256 == 0 && (long long)ksize * ksize * cin >= 2304) {
+    if (fill_of(kTiles[2], pixels, cout) >= 0.85) return 2;
+    if (fill_of(kTiles[1], pixels, cout) >= 0.80) return 1;
+  }
+  return fill_of(kTiles[6], pixels, cout) >= fill_of(kTiles[0], pixels, cout) - 0.15 ? 6 : 0;
+}
+
+inline int bk_of(int cin, int ksize) {
+  // k-chunk: 64 elements (128-byte rows) by default; 32 for Cin = 32 and for the short reductions of the 1x1 layers
+  // (K <= 512: measured 104x104 128->64 0.072 -> 0.062 ms, 26x26 512->256 0.035 -> 0.029 ms, their data gradients
+  // likewise; the 3x3 layers and the K = 1024 head lose 3-20 % with it).  FSD_CONV_H_BK=32|64 forces one (tuning aid).
+  static const char* bk_env = getenv("FSD_CONV_H_BK");
+  int bk = (cin % 64 == 0 && !(ksize == 1 && cin <= 512)) ? 64 : 32;
+  if (bk_env && cin % 64 == 0) bk = atoi(bk_env) == 32 ? 32 : 64;
+  return bk;
+}
+
+inline int tile_bm(int tile) { return kTiles[tile].bm; }
+
 }  // namespace
 
 extern "C" int fsd_conv_row_tiles_h(long long pixels) { return (int)((pixels + 127) / 128); }
+
+extern "C" int fsd_conv2d_h_plan(long long pixels, int cin, int cout, int ksize, int out_nchw_f32, int has_partial) {
+  return pick_tile_h(pixels, cin, cout, ksize, out_nchw_f32 != 0, has_partial != 0, bk_of(cin, ksize));
+}
+
+extern "C" int fsd_conv2d_h_partial_rows(long long pixels, int cin, int cout, int ksize) {
+  const int tile = pick_tile_h(pixels, cin, cout, ksize, false, true, bk_of(cin, ksize));
+  const int bm = tile_bm(tile);
+  return (int)((pixels + bm - 1) / bm);
+}
 
 extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
                                 long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
@@ -352,31 +539,52 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;
   a.bn_partial = bn_partial; a.x_ld = x_ld; a.y_ld = y_ld;
   a.slope = slope;
+  static const char* wide_env = getenv("FSD_CONV_H_WIDE");        // tuning aid: 0 = 4-byte stores straight from registers
+  a.wide = (!out_nchw_f32 && cout % 8 == 0 && y_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+            !(wide_env && wide_env[0] == '0')) ? 1 : 0;            // (switched off below for the 8-wave tiles)
   a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
   a.Cout = cout; a.ks = ksize; a.pad = (ksize - 1) / 2;
   a.Kpad = round_up(ksize * ksize * cin, 64);                    // row stride of fsd_pack_conv_weight_bf16
-  // k-chunk: 64 elements (128-byte rows) by default; 32 for Cin = 32 and for the short reductions of the 1x1 layers
-  // (K <= 512: measured 104x104 128->64 0.072 -> 0.062 ms, 26x26 512->256 0.035 -> 0.029 ms, their data gradients
-  // likewise; the 3x3 layers and the K = 1024 head lose 3-20 % with it).  FSD_CONV_H_BK=32|64 forces one (tuning aid).
-  static const char* bk_env = getenv("FSD_CONV_H_BK");
-  int bk = (cin % 64 == 0 && !(ksize == 1 && cin <= 512)) ? 64 : 32;
-  if (bk_env && cin % 64 == 0) bk = atoi(bk_env) == 32 ? 32 : 64;
+  const int bk = bk_of(cin, ksize);
   a.nk = ksize * ksize * cin / bk;
   a.cpt = cin / bk;
-  a.m_tiles = (int)((pixels + 127) / 128);
   const bool nchw = out_nchw_f32 != 0;
-  static const char* n32_env = getenv("FSD_CONV_H_N32");          // tuning aid: 0 disables the 32-channel tile
-  if (!nchw && cout <= 32 && !bn_partial && bk == 64 && !(n32_env && n32_env[0] == '0')) {
-    // 32 output channels (data gradient of the 32 -> 64 layer at 208x208): a 64-wide tile would issue twice the MFMAs
-    a.n_tiles = 1;
-    return launch_conv<128, 32, 64, 4, 1>(a, false, stream);
+  const int tile = pick_tile_h(pixels, cin, cout, ksize, nchw, bn_partial != nullptr, bk);
+  // 8-wave tiles: the 96-128 KB tile would cross LDS behind one barrier for all eight waves; measured -15 % on the 13x13
+  // layers they are picked for (long K: the store tail is a small share there)
+  if (tile >= 1 && tile <= 3 && !(wide_env && wide_env[0] == '1')) a.wide = 0;
+  const char* ilv_env = getenv("FSD_CONV_H_ILV");                 // tuning aid: 0 / 1 forces the DMA interleave off / on
+  const bool ilv = ilv_env ? ilv_env[0] == '1' : (tile >= 1 && tile <= 3) || tile == 6;
+  const char* ring_env = getenv("FSD_CONV_H_RING");               // tuning aid: 1 = counted-vmcnt ring (measured slower)
+  const bool ring = ring_env && ring_env[0] == '1';
+  a.m_tiles = (int)((pixels + tile_bm(tile) - 1) / tile_bm(tile));
+  switch (tile) {
+    case 5:   // 32 output channels (data gradient of the 32 -> 64 layer at 208x208): a 64-wide tile would issue twice the MFMAs
+      a.n_tiles = 1;
+      return launch_conv<128, 32, 64, 4, 1>(a, false, stream);
+    case 4:
+      a.n_tiles = (cout + 63) / 64;
+      return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);
+    case 1:
+      a.n_tiles = cout / 256;
+      if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<256, 256, 32, 2, 4, true, 4>(a, false, stream); }
+      return ilv ? launch_conv<256, 256, 64, 2, 4, true>(a, false, stream) : launch_conv<256, 256, 64, 2, 4>(a, false, stream);
+    case 2:
+      a.n_tiles = cout / 256;
+      if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<192, 256, 32, 2, 4, true, 4>(a, false, stream); }
+      return ilv ? launch_conv<192, 256, 64, 2, 4, true>(a, false, stream) : launch_conv<192, 256, 64, 2, 4>(a, false, stream);
+    case 3:
+      a.n_tiles = cout / 128;
+      if (ring) return launch_conv<256, 128, 64, 4, 2, true, 3>(a, false, stream);
+      return ilv ? launch_conv<256, 128, 64, 4, 2, true>(a, false, stream) : launch_conv<256, 128, 64, 4, 2>(a, false, stream);
+    case 6:
+      a.n_tiles = cout / 128;
+      return ilv ? launch_conv<192, 128, 64, 2, 2, true>(a, false, stream) : launch_conv<192, 128, 64, 2, 2>(a, false, stream);
+    default:
+      a.n_tiles = (cout + 127) / 128;
+      if (bk == 64) return ilv ? launch_conv<128, 128, 64, 2, 2, true>(a, nchw, stream) : launch_conv<128, 128, 64, 2, 2>(a, nchw, stream);
+      return launch_conv<128, 128, 32, 2, 2>(a, nchw, stream);
   }
-  if (!nchw && narrow_tile(pixels, cout)) {
-    a.n_tiles = (cout + 63) / 64;
-    return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);
-  }
-  a.n_tiles = (cout + 127) / 128;
-  return bk == 64 ? launch_conv<128, 128, 64, 2, 2>(a, nchw, stream) : launch_conv<128, 128, 32, 2, 2>(a, nchw, stream);
 }
 
 // ================= weight gradient: K = pixels, fragments through the LDS transpose read =====================

@@ -338,7 +338,13 @@ int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, flo
  * tensor (`void*`) holds raw bfloat16 bits in the same NHWC layout with leading dimensions counted in ELEMENTS; all
  * arithmetic, the BatchNorm partial sums and every parameter / parameter gradient stay float.  Arguments, shapes,
  * return codes and the kernels behind them are otherwise identical (one kernel template, two instantiations). */
-int fsd_conv_row_tiles_h(long long pixels);          /* rows of the bn_partial array fsd_conv2d_fwd_h fills */
+int fsd_conv_row_tiles_h(long long pixels);          /* upper bound of the rows of any bn_partial array (128-row tiles) */
+/* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick) */
+int fsd_conv2d_h_partial_rows(long long pixels, int cin, int cout, int ksize);
+/* which tile fsd_conv2d_fwd_h will run this layer on: 0 = 128x128 (4 waves, two workgroups per CU), 1 = 256x256,
+ * 2 = 192x256, 3 = 256x128 (8 waves, one workgroup per CU), 4 = 128x64, 5 = 128x32.  Tests assert through it that the
+ * timed shapes really take the 8-wave tiles; FSD_CONV_H_TILE=0..3 forces one (tuning aid). */
+int fsd_conv2d_h_plan(long long pixels, int cin, int cout, int ksize, int out_nchw_f32, int has_partial);
 /* bf16 activations x packed bf16 weights (fsd_pack_conv_weight_bf16) -> bf16 NHWC y (or float NCHW when out_nchw_f32),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, operands staged global -> LDS by DMA.  cin % 32 == 0, cout even. */
 int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,

@@ -78,6 +78,67 @@ def test_conv_bf16_dma_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin
         assert float((e2 - gref.abs() * 2.0 ** -8).max()) < 1e-3 * max(1.0, float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("tile,B,H,W,cin,cout,k", [
+    (1, 2, 26, 30, 64, 256, 3),          # 256x256, ragged M (1560 rows = 6.1 tiles)
+    (1, 1, 13, 13, 1280, 512, 3),        # ... one partial row tile, K = 11520
+    (2, 2, 26, 30, 64, 256, 3),          # 192x256 (3 accumulator rows per wave)
+    (2, 3, 13, 13, 1024, 1024, 1),       # ... 1x1, four column tiles
+    (3, 2, 26, 30, 64, 256, 3),          # 256x128 (4 x 2 waves)
+    (3, 1, 20, 20, 128, 128, 3),
+    (6, 2, 26, 30, 64, 256, 3),          # 192x128, 4 waves (2 x 2, three accumulator rows), two workgroups per CU
+    (6, 3, 13, 13, 1024, 1024, 1),
+])
+def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypatch, tile, B, H, W, cin, cout, k):
+    """The 8-wave tiles of conv_bf16_dma_kernel (one workgroup per CU), forced through FSD_CONV_H_TILE: forward with the
+    BatchNorm partial sums (one row per row tile of THAT tile), and the data gradient."""
+    from fewshot_detection_amd import ops
+    from fewshot_detection_amd._lib import lib
+    monkeypatch.setenv("FSD_CONV_H_TILE", str(tile))
+    assert lib().fsd_conv2d_h_plan(B * H * W, cin, cout, k, 0, 1) == tile
+    bm = {1: 256, 2: 192, 3: 256, 6: 192}[tile]
+    assert lib().fsd_conv2d_h_partial_rows(B * H * W, cin, cout, k) == (B * H * W + bm - 1) // bm
+    g = torch.Generator().manual_seed(tile * 100 + cin)
+    x = _bf(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), _bf(w).double(), None, 1, (k - 1) // 2)
+    yv, part = ops.conv2d(_view_bf16(x, dev), ops.pack_weight(w.to(dev), 0, "bf16"), cout, k, bn_partial=True)
+    assert part.shape[0] == (B * H * W + bm - 1) // bm
+    err = (_nchw(yv).double() - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) < 1e-3, float(err.max())
+    assert float(err.mean()) < 2.0 ** -9 * float(ref.abs().mean()) * 1.2
+    p = part.double().sum(0).cpu()
+    flat = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+    assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=2e-4, atol=1e-2)
+    # with a bias and the leaky epilogue (inference form), no statistics
+    b = torch.randn(cout, generator=g)
+    y2, _ = ops.conv2d(_view_bf16(x, dev), ops.pack_weight(w.to(dev), 0, "bf16"), cout, k, bias=b.to(dev), slope=0.1)
+    ref2 = F.leaky_relu(ref + b.double().view(1, -1, 1, 1), 0.1)
+    e2 = (_nchw(y2).double() - ref2).abs()
+    assert float((e2 - ref2.abs() * 2.0 ** -8).max()) < 1e-3
+    # data gradient: the same kernel on mode-1 weights (N = Cin: only tiles whose width divides it are taken)
+    gy = _bf(torch.randn(B, cout, H, W, generator=g))
+    xg = x.double().requires_grad_(True)
+    F.conv2d(xg, _bf(w).double(), None, 1, (k - 1) // 2).backward(gy.double())
+    dx, _ = ops.conv2d(_view_bf16(gy, dev), ops.pack_weight(w.to(dev), 1, "bf16"), cin, k)
+    e3 = (_nchw(dx).double() - xg.grad).abs()
+    assert float((e3 - xg.grad.abs() * 2.0 ** -8).max()) < 1e-3 * max(1.0, float(xg.grad.abs().max()))
+
+
+def test_timed_bf16_shapes_take_the_large_tiles(dev):
+    """Plan query on the B = 64, 416x416 layer shapes (no launches): the 13x13 layers run on 192x256 (one round of 228
+    workgroups), the data gradient of L29 (1280 outputs) on 256x256, every other >= 128-channel 3x3 layer on 192x128;
+    64-channel outputs, the Cin = 32 layer and the float-NCHW head keep the small 4-wave tiles."""
+    from fewshot_detection_amd._lib import lib
+    plan = lib().fsd_conv2d_h_plan
+    for pixels, cin, cout, k, want in [(64 * 169, 512, 1024, 3, 2), (64 * 169, 1024, 1024, 3, 2), (64 * 169, 1280, 1024, 3, 2),
+                                       (64 * 169, 1024, 1280, 3, 1), (64 * 169, 1024, 512, 3, 0), (64 * 676, 256, 512, 3, 6),
+                                       (64 * 676, 512, 256, 3, 6), (64 * 2704, 128, 256, 3, 6), (64 * 10816, 64, 128, 3, 6)]:
+        assert plan(pixels, cin, cout, k, 0, 1) == want, (pixels, cin, cout, plan(pixels, cin, cout, k, 0, 1))
+    assert plan(64 * 10816, 128, 64, 1, 0, 1) == 4 and plan(64 * 43264, 64, 32, 3, 0, 0) == 5
+    assert plan(64 * 43264, 32, 64, 3, 0, 1) == 4 and plan(64 * 169, 1024, 450, 1, 1, 0) == 0
+
+
 @pytest.mark.parametrize("cout,cin,k", [(64, 32, 3), (128, 64, 1), (1024, 512, 3), (30, 1024, 1), (72, 200, 3), (1024, 1280, 3)])
 def test_single_pass_weight_pair_equals_the_two_single_packings(dev, cout, cin, k):
     """fsd_pack_conv_weight_bf16_pair (one read of W) == mode 0 and mode 1 of fsd_pack_conv_weight_bf16, bit for bit,
