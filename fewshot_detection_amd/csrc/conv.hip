@@ -354,20 +354,29 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool GLDS = false>
 int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
   const bool fast = a.cpt > 0;
   constexpr int NT = WM * WN * 64;
+  const size_t tile_bytes = a.wide ? (size_t)BM * BN * sizeof(float) : 0;       // the wide epilogue's [BM][BN] tile
   if constexpr (GLDS) {
     if (fast) {      // the DMA path needs the per-tap fast path; other layers fall through to register staging
-      const size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
+      size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
+      if (lds_g < tile_bytes) lds_g = tile_bytes;
       return nchw ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, true>, a, lds_g, NT, stream)
                   : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, STAGES, true, true>, a, lds_g, NT, stream);
     }
   }
   constexpr int RS = STAGES > 2 ? 2 : STAGES;
-  const size_t lds = RS * (size_t)(BM + BN) * kLd * sizeof(float);
+  size_t lds = RS * (size_t)(BM + BN) * kLd * sizeof(float);
+  if (lds < tile_bytes) lds = tile_bytes;
   if (nchw)
     return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, RS, true, false>, a, lds, NT, stream)
                 : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, RS, false, false>, a, lds, NT, stream);
   return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, RS, true, false>, a, lds, NT, stream)
               : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, RS, false, false>, a, lds, NT, stream);
+}
+
+// float4 epilogue (conv_epilogue): FSD_CONV_WIDE=0 switches it off (tuning aid)
+inline bool wide_ok(const float* y, long long y_ld, int cout) {
+  static const char* env = getenv("FSD_CONV_WIDE");
+  return !(env && env[0] == '0') && cout % 4 == 0 && y_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 }
 
 // Tail splitting for kTile128: rows covered by WHOLE rounds of co-resident workgroups use 128x128 tiles; the
@@ -438,6 +447,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.batches = batches;
   a.slope = 1.f;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
+  a.wide = wide_ok(y, y_ld, cout) && y_bs % 4 == 0;
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
   if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages
@@ -510,6 +520,7 @@ extern "C" int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w
   a.part_base = 0;
   a.batches = 1;
   a.slope = slope;
+  a.wide = !out_nchw && wide_ok(y, y_ld, cout);
   a.x_bs = a.w_bs = a.y_bs = 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;

@@ -30,6 +30,7 @@ struct ConvArgs {
   long long x_bs, w_bs, y_bs;
   int batches;
   float slope;   // leaky slope applied to (acc + bias) in the NHWC epilogue; 1 = linear (fsd_conv2d_fwd_act)
+  int wide;      // NHWC epilogue through LDS with float4 stores (needs y 16-byte aligned, y_ld % 4 == 0, Cout % 4 == 0)
 };
 
 // fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)
@@ -52,20 +53,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                                               int mt, int tid, int lane, int wm, int wn) {
   const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
   if constexpr (!NCHW_OUT) {
+    if (!p.wide) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + c_lane;
-      const bool n_ok = n < p.Cout;
-      const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + c_lane;
+        const bool n_ok = n < p.Cout;
+        const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-          if (n_ok && m < p.M) {
-            float v = acc[i][j][r] + bv;
-            if (p.slope != 1.f) v = v > 0.f ? v : v * p.slope;      // inference: BatchNorm folded into w / bias, leaky here
-            p.y[(long long)m * p.y_ld + n] = v;
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+            if (n_ok && m < p.M) {
+              float v = acc[i][j][r] + bv;
+              if (p.slope != 1.f) v = v > 0.f ? v : v * p.slope;      // inference: BatchNorm folded into w / bias, leaky here
+              p.y[(long long)m * p.y_ld + n] = v;
+            }
           }
         }
       }
@@ -106,6 +109,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
           dst[0] = s;
           dst[1] = q;
         }
+      }
+      if (p.wide) __syncthreads();          // s_stat is read: the tile below re-uses the space
+    }
+    if (p.wide) {
+      // Wide stores.  Straight from the accumulators a lane stores ONE float per instruction (16 x TM x TN instructions per
+      // wave, 128 contiguous bytes per pixel row each); store ISSUE, not bandwidth, is what a short-K tile then waits for
+      // (MI355X_MICROARCH.md: an epilogue of 16 narrow stores per lane costs ~9 k cycles -- a K = 64 Winograd position tile is
+      // 2 k cycles of MFMA).  The tile crosses LDS once ([BM][BN] floats, written as it lies in the accumulators: 32 lanes =
+      // 32 consecutive floats, conflict-free) and leaves as float4: 4x fewer store instructions, 256-byte row segments.
+      constexpr int NT = WAVES_M * WAVES_N * 64;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nl = (wn * TN + j) * 32 + c_lane;
+        const float bv = (p.bias != nullptr && n0 + nl < p.Cout) ? p.bias[n0 + nl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] + bv;
+            if (p.slope != 1.f) v = v > 0.f ? v : v * p.slope;
+            smem[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane) * BN + nl] = v;
+          }
+      }
+      __syncthreads();
+      constexpr int PPR = BN / 4;           // float4 pieces per tile row
+      for (int it = tid; it < BM * PPR; it += NT) {
+        const int row = it / PPR, pc = it - row * PPR;
+        const int m = m0 + row, n = n0 + pc * 4;
+        if (m < p.M && n < p.Cout)          // Cout % 4 == 0 (launcher): whole pieces
+          *reinterpret_cast<f32x4*>(p.y + (long long)m * p.y_ld + n) = *reinterpret_cast<const f32x4*>(smem + row * BN + pc * 4);
       }
     }
   } else {
