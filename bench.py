@@ -496,7 +496,8 @@ def inference_latency(leg, dev, S):
 
 
 def other_configs(leg, args, dev, blocks, lblocks):
-    """Train-step times of the other BASELINE configs' shapes on one GPU (2 warm-up + 5 timed steps each).  No
+    """Train-step times of the other BASELINE configs' shapes on one GPU (2 warm-up steps, then 6 steps timed one by one;
+    the lower median is quoted, every step's time is kept: twice in ~10 runs one step of a shape change stalled for seconds).  No
     empty_cache() in between: handing the pool back makes the next shape's steps pay hipMalloc of multi-GB blocks."""
     from fewshot_detection_amd.cfg import cfg
     out = {}
@@ -511,10 +512,20 @@ def other_configs(leg, args, dev, blocks, lblocks):
             cfg.neg_ratio = neg
             x, metax, mask, target = synth_episode(2000 + N, B, N, S, Sm)
             step = leg.stepper(x.to(dev).contiguous(), metax.to(dev), mask.to(dev), target, batch=B)
-            t = timed(step, n=5, w=2)           # (a new shape re-sizes every cached workspace: two warm-up steps)
+            for _ in range(2):                  # (a new shape re-sizes every cached workspace: two warm-up steps)
+                step()
+            per = []
+            for _ in range(6):                  # every step timed on its own: one stalled step must not pass for the rate
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                per.append(time.perf_counter() - t0)
+            t = sorted(per)[len(per) // 2 - 1]  # lower median of 6
             fl = episode_flops(blocks, lblocks, B, N, S, Sm)
             out[key] = {"what": "train step, B=%d queries %dx%d + %d supports %dx%d, neg_ratio=%s (%s)" % (B, S, S, N, Sm, Sm, neg, what),
                         "ms_per_step": t * 1e3, "episodes_per_s": 1.0 / t, "img_per_s": B / t,
+                        "ms_each_step": [round(v * 1e3, 2) for v in per],
                         "episode_forward_gflop": fl / 1e9, "dtype": leg.dtype}
             del x, metax, mask, step
     finally:
