@@ -3,6 +3,8 @@
 // reweighting (x) head gradient, and small utilities.  NHWC, float4 along channels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "fsdet.h"
 #include "profile.hpp"
 #include "ew_types.hpp"
@@ -309,6 +311,40 @@ __global__ void bn_bwd_apply_kernel(T* __restrict__ dt, const T* __restrict__ y,
   st4<T>(dt + pix * C + g * 4, d);
 }
 
+// bf16 storage, 8 channels (16 bytes) per lane: with 4 channels a lane moves 8 bytes and a wave instruction 512 -- the bf16
+// twins of the HBM-bound kernels then reach 3.5-4.1 TB/s where their fp32 versions (16 bytes per lane) reach 5.1-5.4
+__global__ void bn_bwd_apply8_kernel(bf16_t* __restrict__ dt, const bf16_t* __restrict__ y, long long y_ld,
+                                     const float* __restrict__ coef, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, int C, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C >> 3;
+  const int g = (int)(idx % cg);
+  const long long pix = idx / cg;
+  const uint4 yu = *reinterpret_cast<const uint4*>(y + pix * y_ld + g * 8);
+  uint4 du = *reinterpret_cast<const uint4*>(dt + pix * C + g * 8);
+  const unsigned yw[4] = {yu.x, yu.y, yu.z, yu.w};
+  unsigned dw[4] = {du.x, du.y, du.z, du.w};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = g * 8 + h * 4;
+    const f32x4 c1 = ld4(coef + c), c2 = ld4(coef + C + c), c3 = ld4(coef + 2 * C + c);
+    const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned yv2 = yw[h * 2 + k], dv2 = dw[h * 2 + k];
+      const float y0 = __uint_as_float(yv2 << 16), y1 = __uint_as_float(yv2 & 0xffff0000u);
+      const float d0 = __uint_as_float(dv2 << 16), d1 = __uint_as_float(dv2 & 0xffff0000u);
+      const int e = 2 * k;
+      const float r0 = c1[e] * (d0 - c2[e] - (y0 - mu[e]) * is[e] * c3[e]);
+      const float r1 = c1[e + 1] * (d1 - c2[e + 1] - (y1 - mu[e + 1]) * is[e + 1] * c3[e + 1]);
+      dw[h * 2 + k] = (unsigned)fsd_ew::f32_to_bf16(r0) | ((unsigned)fsd_ew::f32_to_bf16(r1) << 16);
+    }
+  }
+  du.x = dw[0]; du.y = dw[1]; du.z = dw[2]; du.w = dw[3];
+  *reinterpret_cast<uint4*>(dt + pix * C + g * 8) = du;
+}
+
 // column sums of a (rows, ld) matrix, any C: partial[blocks][C][2] with the second slot zero
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ m, long long ld, float* __restrict__ partial, int C, long long rows,
@@ -499,8 +535,18 @@ int bn_bwd_apply_impl(T* dt, const T* y, long long y_ld, const float* coef, cons
                       long long pixels, int channels, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dt || !y || !coef || !mean || !invstd || (channels & 3) || (y_ld & 3)) return FSD_ERR_ARG;
-  const long long total = pixels * (channels / 4);
   fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * 3.0 * pixels, stream);      // read dt, y; write dy
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    static const char* env = getenv("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
+    if (channels % 8 == 0 && y_ld % 8 == 0 && !(reinterpret_cast<uintptr_t>(dt) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
+        !(env && env[0] == '0')) {
+      const long long total8 = pixels * (channels / 8);
+      hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(blocks_for(total8, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
+                         invstd, channels, total8);
+      return (int)hipGetLastError();
+    }
+  }
+  const long long total = pixels * (channels / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
                      invstd, channels, total);
   return (int)hipGetLastError();

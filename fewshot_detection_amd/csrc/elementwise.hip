@@ -3,6 +3,8 @@
 // channel-reweighting helpers.  All NHWC / float4-vectorised where the layout allows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "fsdet.h"
 #include "profile.hpp"
 #include "ew_types.hpp"
@@ -11,6 +13,7 @@ namespace {
 
 using fsd_ew::bf16_t;
 using fsd_ew::f32x4;
+using fsd_ew::f32x8;
 using fsd_ew::ld1;
 using fsd_ew::ld4;
 using fsd_ew::st1;
@@ -151,6 +154,50 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
     for (int k = 0; k < 4; ++k) out[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
   }
   st4<T>(z + opix * z_ld + g * 4, out);
+}
+
+// bf16 storage, 8 channels (one 16-byte access) per lane: see ew_types.hpp
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_act_pool8_kernel(const bf16_t* __restrict__ y, long long y_ld,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float slope,
+                                                           bf16_t* __restrict__ z, long long z_ld, int H, int W,
+                                                           int OH, int OW, int cg8, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % cg8);
+  const long long opix = idx / cg8;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc0 = scale ? *reinterpret_cast<const f32x4*>(scale + g * 8) : one;
+  const f32x4 sc1 = scale ? *reinterpret_cast<const f32x4*>(scale + g * 8 + 4) : one;
+  const f32x4 sh0 = shift ? *reinterpret_cast<const f32x4*>(shift + g * 8) : zero;
+  const f32x4 sh1 = shift ? *reinterpret_cast<const f32x4*>(shift + g * 8 + 4) : zero;
+  auto act8 = [&](const bf16_t* p) {
+    f32x8 v = fsd_ew::ld8(p);
+    v.lo = affine_act(v.lo, sc0, sh0, slope);
+    v.hi = affine_act(v.hi, sc1, sh1, slope);
+    return v;
+  };
+  f32x8 out;
+  if constexpr (POOL == 0) {
+    out = act8(y + opix * y_ld + g * 8);
+  } else {
+    const int ox = (int)(opix % OW);
+    const long long t = opix / OW;
+    const int oy = (int)(t % OH);
+    const long long b = t / OH;
+    const int y0 = POOL == 1 ? 2 * oy : oy, x0 = POOL == 1 ? 2 * ox : ox;
+    const int y1 = (y0 + 1 < H) ? y0 + 1 : H - 1, x1 = (x0 + 1 < W) ? x0 + 1 : W - 1;   // replicate pad (stride 1)
+    const bf16_t* base = y + (b * H * (long long)W) * y_ld + g * 8;
+    const f32x8 v00 = act8(base + ((long long)y0 * W + x0) * y_ld), v01 = act8(base + ((long long)y0 * W + x1) * y_ld);
+    const f32x8 v10 = act8(base + ((long long)y1 * W + x0) * y_ld), v11 = act8(base + ((long long)y1 * W + x1) * y_ld);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      out.lo[k] = fmaxf(fmaxf(v00.lo[k], v01.lo[k]), fmaxf(v10.lo[k], v11.lo[k]));
+      out.hi[k] = fmaxf(fmaxf(v00.hi[k], v01.hi[k]), fmaxf(v10.hi[k], v11.hi[k]));
+    }
+  }
+  fsd_ew::st8(z + opix * z_ld + g * 8, out);
 }
 
 // ---- batched 2-D transpose through LDS (NCHW <-> NHWC) ---------------------------------------
@@ -299,11 +346,27 @@ int bn_act_pool_impl(const T* y, long long y_ld, const float* scale, const float
   if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
   const int OH = pool == 1 ? height / 2 : height, OW = pool == 1 ? width / 2 : width;
   if (OH < 1 || OW < 1) return FSD_ERR_ARG;
+  // algorithmic bytes: read y once, write z once
+  fsd_prof::Scope prof(fsd_prof::kActFwd, (double)sizeof(T) * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    static const char* env = getenv("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
+    if (channels % 8 == 0 && y_ld % 8 == 0 && z_ld % 8 == 0 && !(reinterpret_cast<uintptr_t>(y) & 15) &&
+        !(reinterpret_cast<uintptr_t>(z) & 15) && !(env && env[0] == '0')) {
+      const int cg8 = channels / 8;
+      const long long total8 = (long long)batch * OH * OW * cg8;
+      const dim3 grid8(blocks_for(total8, 256)), block8(256);
+      if (pool == 0)
+        hipLaunchKernelGGL((bn_act_pool8_kernel<0>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+      else if (pool == 1)
+        hipLaunchKernelGGL((bn_act_pool8_kernel<1>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+      else
+        hipLaunchKernelGGL((bn_act_pool8_kernel<2>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+      return (int)hipGetLastError();
+    }
+  }
   const int cg = channels / 4;
   const long long total = (long long)batch * OH * OW * cg;
   const dim3 grid(blocks_for(total, 256)), block(256);
-  // algorithmic bytes: read y once, write z once
-  fsd_prof::Scope prof(fsd_prof::kActFwd, (double)sizeof(T) * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
   if (pool == 0)
     hipLaunchKernelGGL((bn_act_pool_kernel<T, 0>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else if (pool == 1)

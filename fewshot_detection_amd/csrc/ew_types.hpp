@@ -39,6 +39,26 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// 8 bf16 channels = one 16-byte access per lane (the 4-channel form moves 8 bytes per lane, 512 per wave instruction)
+struct f32x8 { f32x4 lo, hi; };
+__device__ __forceinline__ f32x8 ld8(const bf16_t* p) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  f32x8 v;
+  v.lo[0] = __uint_as_float(u.x << 16); v.lo[1] = __uint_as_float(u.x & 0xffff0000u);
+  v.lo[2] = __uint_as_float(u.y << 16); v.lo[3] = __uint_as_float(u.y & 0xffff0000u);
+  v.hi[0] = __uint_as_float(u.z << 16); v.hi[1] = __uint_as_float(u.z & 0xffff0000u);
+  v.hi[2] = __uint_as_float(u.w << 16); v.hi[3] = __uint_as_float(u.w & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f32x8& v) {
+  uint4 u;
+  u.x = (unsigned)f32_to_bf16(v.lo[0]) | ((unsigned)f32_to_bf16(v.lo[1]) << 16);
+  u.y = (unsigned)f32_to_bf16(v.lo[2]) | ((unsigned)f32_to_bf16(v.lo[3]) << 16);
+  u.z = (unsigned)f32_to_bf16(v.hi[0]) | ((unsigned)f32_to_bf16(v.hi[1]) << 16);
+  u.w = (unsigned)f32_to_bf16(v.hi[2]) | ((unsigned)f32_to_bf16(v.hi[3]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
