@@ -663,29 +663,41 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
     b_y[j] = (int)(q % p.H);
   }
 
+  // Staging addresses are carried from chunk to chunk (a chunk = the next KC pixel rows: one 64-bit add per piece) and the
+  // padding select is branch-free.  (Round 2 recomputed pix * ld with 64-bit multiplies under divergent `ok` branches for
+  // every piece: ~300 scalar / vector instructions per 16 MFMAs, PMC: 45 % of wave time parked, 0.25 MFMA-busy.)
+  const bool a_ch_ok = (m0 + (a_pp ^ GA::swz(a_row)) * 8) < p.Cout;       // the swizzle is the same in every pass
+  const u16* a_ptr[GA::PASSES];
+  const u16* b_ptr[GB::PASSES];
+#pragma unroll
+  for (int j = 0; j < GA::PASSES; ++j)
+    a_ptr[j] = p.dy + (pix0 + a_row + GA::ROWS_PER_PASS * j) * p.dy_ld + m0 + (a_pp ^ GA::swz(a_row)) * 8;
+#pragma unroll
+  for (int j = 0; j < GB::PASSES; ++j)
+    b_ptr[j] = p.x + (pix0 + b_row + GB::ROWS_PER_PASS * j + shift) * p.x_ld + b_ci;
+  const long long a_step = (long long)KC * p.dy_ld, b_step = (long long)KC * p.x_ld;
+  int a_left = (int)(pix_end - pix0) - a_row, b_left = (int)(pix_end - pix0) - b_row;     // rows left below this lane's row
+  const u16* const zero_src = g_zero_page_h;
+
   auto stage = [&](int kc, u16* st) {
-    const long long base = pix0 + (long long)kc * KC;
+    (void)kc;
 #pragma unroll
     for (int j = 0; j < GA::PASSES; ++j) {
-      const int row = a_row + GA::ROWS_PER_PASS * j;
       if (GA::ROWS_PER_PASS * j + wave * GA::RPI < KC) {            // CH = 32: 64 rows per pass, only KC exist
-        const int piece = a_pp ^ GA::swz(row);
-        const long long pix = base + row;
-        const bool ok = row < KC && pix < pix_end && (m0 + piece * 8) < p.Cout;
-        const u16* src = ok ? p.dy + pix * p.dy_ld + m0 + piece * 8 : g_zero_page_h;
-        dma16(src, st + (GA::ROWS_PER_PASS * j + wave * GA::RPI) * BM);
+        const bool ok = a_ch_ok && (a_row + GA::ROWS_PER_PASS * j < KC) && a_left > GA::ROWS_PER_PASS * j;
+        dma16(ok ? a_ptr[j] : zero_src, st + (GA::ROWS_PER_PASS * j + wave * GA::RPI) * BM);
       }
+      a_ptr[j] += a_step;
     }
+    a_left -= KC;
 #pragma unroll
     for (int j = 0; j < GB::PASSES; ++j) {
-      const int row = b_row + GB::ROWS_PER_PASS * j;
       if (GB::ROWS_PER_PASS * j + wave * GB::RPI < KC) {
-        const long long pix = base + row;
-        const bool ok = row < KC && pix < pix_end && b_col_ok &&
+        const bool ok = b_col_ok && (b_row + GB::ROWS_PER_PASS * j < KC) && b_left > GB::ROWS_PER_PASS * j &&
                         (unsigned)(b_y[j] + dyo) < (unsigned)p.H && (unsigned)(b_x[j] + dxo) < (unsigned)p.W;
-        const u16* src = ok ? p.x + (pix + shift) * p.x_ld + b_ci : g_zero_page_h;
-        dma16(src, st + KC * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
+        dma16(ok ? b_ptr[j] : zero_src, st + KC * BM + (GB::ROWS_PER_PASS * j + wave * GB::RPI) * BN);
       }
+      b_ptr[j] += b_step;
       // advance this row's image coordinates by one chunk (KC pixels).  (v + 0.5) / n is never within 1/(2n) of an
       // integer, so the float quotients are exact; the row index wraps by the same rule (a chunk spans up to KC image
       // rows on the 3x3 / 2x2 / 1x1 maps at the end of the reweighting net, so a fixed number of subtractions is not
@@ -698,6 +710,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
       b_x[j] = xx;
       b_y[j] = yy;
     }
+    b_left -= KC;
   };
 
   f32x16 acc[TM][TN];
@@ -741,6 +754,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(WgradHArgs p) {
     }
   };
 
+  // (The compiler puts `s_waitcnt vmcnt(0)` in front of the first transpose read that follows a global_load_lds in program
+  // order -- it cannot prove the two do not alias.  Issuing every fragment read of the chunk BEFORE the next chunk's DMA
+  // removes that wait and was measured: no change, +3 % time on the 32-pixel-chunk variants (64 fragment registers cost
+  // occupancy).  The kernel is bound by operand delivery -- 512 bytes of L2 -> LDS DMA per MFMA at this tile size, i.e.
+  // 64 B/clk/CU at the full matrix rate -- not by that wait.)
   if (nk > 0) {
     stage(0, smem_w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
