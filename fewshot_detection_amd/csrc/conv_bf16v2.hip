@@ -853,6 +853,170 @@ int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int
   return (int)hipGetLastError();
 }
 
+// 8-wave 256 x 256 tile of the weight gradient (round 3).  The 128 x 128 kernel above moves 512 bytes of L2 -> LDS DMA per
+// MFMA -- 64 B/clk/CU at the full matrix rate, more than the L2 delivers -- and sits at 0.25 MFMA-busy whatever the issue
+// order; this tile halves that.  Both operand tiles are kept as 128-channel SUB-tiles ([KC pixels][128 channels], the
+// geometry and swizzle of TileGeom<128, KC>, verified by the hardware probes): 2 of dy + 2 of x per stage.  2 x 4 waves of
+// 128 x 64 (TM = 4, TN = 2: 128 accumulator registers), one workgroup per CU.
+template <int KC>
+__global__ __launch_bounds__(512) void wgrad_bf16_tr8_kernel(WgradHArgs p) {
+  static_assert(KC == 32 || KC == 64, "k-chunk of 32 or 64 pixels");
+  constexpr int BM = 256, BN = 256, TM = 4, TN = 2, SA = 2, SB = 2;
+  typedef TileGeom<128, KC> GT;
+  constexpr int RPASS = 32;                         // pixel rows staged per pass of the 8 waves (4 per wave instruction)
+  constexpr int PASSES = KC / RPASS;
+  constexpr int SUB = KC * 128;                     // elements of one sub-tile
+  constexpr int STAGE = (SA + SB) * SUB;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_w8[];
+
+  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int nt = L % p.n_tiles, mt = L / p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ncols = p.taps * p.Cin;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const long long pix0 = (long long)blockIdx.y * p.pix_per_split;
+  long long pix_end = pix0 + p.pix_per_split;
+  if (pix_end > p.M) pix_end = p.M;
+  const int nk = (int)((pix_end - pix0 + KC - 1) / KC);
+
+  const int row0 = wave * GT::RPI + lane / GT::LPR, pp = lane % GT::LPR;     // this lane's row (of a pass) and 16-byte slot
+  const int piece = pp ^ GT::swz(row0);                                       // the piece it fetches (same in every pass)
+  bool a_ok[SA], b_ok[SB];
+  const u16* a_ptr[SA][PASSES];
+  const u16* b_ptr[SB][PASSES];
+  int b_dy[SB], b_dx[SB];
+#pragma unroll
+  for (int t = 0; t < SA; ++t) {
+    const int ch = m0 + t * 128 + piece * 8;
+    a_ok[t] = ch < p.Cout;
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) a_ptr[t][j] = p.dy + (pix0 + row0 + RPASS * j) * p.dy_ld + ch;
+  }
+#pragma unroll
+  for (int t = 0; t < SB; ++t) {
+    const int col = n0 + t * 128 + piece * 8;                                 // column of dW = tap * Cin + ci
+    b_ok[t] = col < ncols;
+    const int tap = col / p.Cin, ci = col - tap * p.Cin;
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    b_dy[t] = ky - p.pad;
+    b_dx[t] = kx - p.pad;
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j)
+      b_ptr[t][j] = p.x + (pix0 + row0 + RPASS * j + b_dy[t] * p.W + b_dx[t]) * p.x_ld + ci;
+  }
+  int b_y[PASSES], b_x[PASSES];
+  const float inv_w = 1.0f / (float)p.W, inv_h = 1.0f / (float)p.H;
+#pragma unroll
+  for (int j = 0; j < PASSES; ++j) {
+    const long long q0 = pix0 + row0 + RPASS * j;
+    const long long q = q0 / p.W;
+    b_x[j] = (int)(q0 - q * p.W);
+    b_y[j] = (int)(q % p.H);
+  }
+  const long long a_step = (long long)KC * p.dy_ld, b_step = (long long)KC * p.x_ld;
+  int left = (int)(pix_end - pix0) - row0;                                    // pixel rows left below this lane's row
+  const u16* const zero_src = g_zero_page_h;
+
+  auto stage = [&](u16* st) {
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+      const bool row_ok = left > RPASS * j;
+      u16* dst = st + (RPASS * j + wave * GT::RPI) * 128;
+#pragma unroll
+      for (int t = 0; t < SA; ++t) {
+        dma16(row_ok && a_ok[t] ? a_ptr[t][j] : zero_src, dst + t * SUB);
+        a_ptr[t][j] += a_step;
+      }
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        const bool ok = row_ok && b_ok[t] && (unsigned)(b_y[j] + b_dy[t]) < (unsigned)p.H &&
+                        (unsigned)(b_x[j] + b_dx[t]) < (unsigned)p.W;
+        dma16(ok ? b_ptr[t][j] : zero_src, dst + (SA + t) * SUB);
+        b_ptr[t][j] += b_step;
+      }
+      // advance the row's image coordinates by one chunk (exact float quotients, see wgrad_bf16_tr_kernel)
+      int xx = b_x[j] + KC;
+      const int q = (int)(((float)xx + 0.5f) * inv_w);
+      xx -= q * p.W;
+      int yy = b_y[j] + q;
+      yy -= (int)(((float)yy + 0.5f) * inv_h) * p.H;
+      b_x[j] = xx;
+      b_y[j] = yy;
+    }
+    left -= KC;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int G = lane >> 4, Lq = lane & 15;
+  auto frag = [&](const u16* tile, int ch0, int krow, int swzmask) -> bf16x8 {
+    const int row = krow + (Lq >> 2);
+    const int ch = ch0 + 16 * (G & 1) + 4 * (Lq & 3);
+    const int pc = (ch >> 3) ^ swzmask;
+    const u16* a = tile + row * 128 + pc * 8 + (ch & 7);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a + 4 * 128));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto compute = [&](const u16* st) {
+#pragma unroll
+    for (int s = 0; s < KC / 16; ++s) {
+      const int krow = s * 16 + (G >> 1) * 8;
+      const int sw = GT::swz(krow + (Lq >> 2));
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int cb = (wm * TM + i) * 32;                                    // channel block inside the 256-row tile
+        af[i] = frag(st + (cb >> 7) * SUB, cb & 127, krow, sw);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cb = (wn * TN + j) * 32;
+        bf[j] = frag(st + (SA + (cb >> 7)) * SUB, cb & 127, krow, sw);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    stage(smem_w8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk) stage(smem_w8 + (cur ^ 1) * STAGE);
+      compute(smem_w8 + cur * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = p.ws + (long long)blockIdx.y * p.Cout * ncols;
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + c_lane;
+    if (n >= ncols) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        if (m < p.Cout) out[(long long)m * ncols + n] = acc[i][j][r];
+      }
+  }
+}
+
 inline int wgrad_h_kc(long long pixels);
 // workgroups of the weight-gradient kernel resident on the chip at a time, for the tile wgrad_h_tiles picks
 inline int wgrad_h_resident(int bm, int bn, long long pixels) { return (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64) ? 512 : 1536; }
@@ -889,7 +1053,37 @@ inline int wgrad_h_splits(long long pixels, int tiles, int resident) {
   return s < 1 ? 1 : s > 1024 ? 1024 : s;
 }
 
-inline void wgrad_h_tiles(int cout, int ncols, int* bm, int* bn) {
+// split count for the one-workgroup-per-CU 256 x 256 tile.  Many tiles: whole rounds of 256, a small price per workspace
+// slice.  Few tiles: one round, as long as a split keeps 32 chunks of 64 pixels.
+inline int wgrad_h_big_splits(long long pixels, int tiles) {
+  const long long max_s = (pixels + 2047) / 2048;
+  int s = 1;
+  if (tiles >= 128) {
+    double best = 1e30;
+    for (int c = 1; c <= 16; ++c) {
+      const double wgs = (double)tiles * c, rounds = (double)((long long)((wgs + 255) / 256));
+      const double cost = rounds / (wgs / 256.0) * (1.0 + 0.03 * c);
+      if (cost < best - 1e-9) { best = cost; s = c; }
+    }
+  } else {
+    s = 256 / tiles;
+  }
+  if (s > max_s) s = (int)max_s;
+  return s < 1 ? 1 : s;
+}
+
+// the 8-wave 256 x 256 tile: from 256 x 256 of dW, when tiles x splits fill at least three quarters of the CUs (the 1x1
+// layers and short maps do not: 26x26 512->256 1x1 has 2 tiles and 21 splits' worth of pixels).  FSD_WGRAD_H_BIG=0
+// switches it off (tuning aid).
+inline bool wgrad_h_big(int cout, int ncols, long long pixels) {
+  const char* env = getenv("FSD_WGRAD_H_BIG");
+  if ((env && env[0] == '0') || cout < 256 || ncols < 256) return false;
+  const int tiles = ((cout + 255) / 256) * ((ncols + 255) / 256);
+  return (long long)tiles * wgrad_h_big_splits(pixels, tiles) >= 192;
+}
+
+inline void wgrad_h_tiles(int cout, int ncols, long long pixels, int* bm, int* bn) {
+  if (wgrad_h_big(cout, ncols, pixels)) { *bm = 256; *bn = 256; return; }
   *bm = cout <= 64 ? 64 : 128;
   *bn = ncols <= 32 ? 32 : ncols <= 64 ? 64 : 128;     // ncols = taps * Cin: the packed column space of dW
   if (*bn == 32) *bm = 128;                            // the 32-wide variant runs 4 x 1 waves of 32 rows
@@ -923,9 +1117,10 @@ inline int wgrad_h_kc(long long pixels) {
 extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
   int bm, bn;
   const int ncols = ksize * ksize * cin;
-  wgrad_h_tiles(cout, ncols, &bm, &bn);
+  wgrad_h_tiles(cout, ncols, (long long)batch * height * width, &bm, &bn);
   const int tiles = ((cout + bm - 1) / bm) * ((ncols + bn - 1) / bn);
-  const int splits = wgrad_h_splits((long long)batch * height * width, tiles, wgrad_h_resident(bm, bn, (long long)batch * height * width));
+  const int splits = bm == 256 ? wgrad_h_big_splits((long long)batch * height * width, tiles)
+                               : wgrad_h_splits((long long)batch * height * width, tiles, wgrad_h_resident(bm, bn, (long long)batch * height * width));
   return (size_t)(splits + wgrad_h_fold_extra_slices(splits)) * cout * ksize * ksize * cin * sizeof(float);
 }
 
@@ -947,14 +1142,24 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   a.ks = ksize; a.pad = (ksize - 1) / 2; a.taps = ksize * ksize;
   int bm, bn;
   const int ncols = a.taps * cin;
-  wgrad_h_tiles(cout, ncols, &bm, &bn);
+  wgrad_h_tiles(cout, ncols, pixels, &bm, &bn);
   a.m_tiles = (cout + bm - 1) / bm;
   a.n_tiles = (ncols + bn - 1) / bn;
-  const int splits = wgrad_h_splits(pixels, a.m_tiles * a.n_tiles, wgrad_h_resident(bm, bn, pixels));
-  const bool kc64 = bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64;
+  const int splits = bm == 256 ? wgrad_h_big_splits(pixels, a.m_tiles * a.n_tiles)
+                               : wgrad_h_splits(pixels, a.m_tiles * a.n_tiles, wgrad_h_resident(bm, bn, pixels));
+  const bool kc64 = bm == 256 || (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64);
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kc64 ? 64 : 32);
   int rc;
-  if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);
+  if (bm == 256) {
+    const size_t lds = 2 * (size_t)64 * (256 + 256) * sizeof(u16);
+    fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
+    auto k = wgrad_bf16_tr8_kernel<64>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(512), lds, stream, a);
+    rc = (int)hipGetLastError();
+  }
+  else if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);
   else if (kc64) rc = launch_wgrad_h<128, 128, 2, 2, 64>(a, splits, stream);
   else if (bm == 128 && bn == 128) rc = launch_wgrad_h<128, 128, 2, 2>(a, splits, stream);
   else if (bm == 128 && bn == 64) rc = launch_wgrad_h<128, 64, 2, 2>(a, splits, stream);

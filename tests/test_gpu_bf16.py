@@ -185,6 +185,9 @@ def test_conv_bf16_head_nchw_float_output(dev):
     (9, 2, 2, 32, 64, 3),           # 2x2 and 1x1 maps: every tap but the centre is padding for most pixels
     (70, 1, 1, 128, 128, 3),
     (3, 5, 4, 128, 128, 3),         # non-square map smaller than a chunk
+    (8, 26, 26, 256, 512, 3),       # 8-wave 256 x 256 tile: 2 x 9 tiles, several splits, 64-pixel chunks that wrap image rows
+    (2, 13, 13, 264, 328, 3),       # ... ragged in both dimensions (328 = 256 + 72 rows, 2376 = 9 x 256 + 72 columns)
+    (3, 7, 5, 512, 256, 1),         # ... 1x1, 105 pixels: one partial chunk
 ])
 def test_wgrad_bf16_transpose_read_kernel_matches_fp64(dev, B, H, W, cin, cout, k):
     from fewshot_detection_amd import ops
