@@ -857,14 +857,19 @@ int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int
 // MFMA -- 64 B/clk/CU at the full matrix rate, more than the L2 delivers -- and sits at 0.25 MFMA-busy whatever the issue
 // order; this tile halves that.  Both operand tiles are kept as 128-channel SUB-tiles ([KC pixels][128 channels], the
 // geometry and swizzle of TileGeom<128, KC>, verified by the hardware probes): 2 of dy + 2 of x per stage.  2 x 4 waves of
-// 128 x 64 (TM = 4, TN = 2: 128 accumulator registers), one workgroup per CU.
-template <int KC>
-__global__ __launch_bounds__(512) void wgrad_bf16_tr8_kernel(WgradHArgs p) {
+// 128 x 64 (TM = 4, TN = 2: 128 accumulator registers), one workgroup per CU.  Measured at B = 64 (tools/layer_bench.py
+// wgrad, incl. the fold): 26x26 256->512 0.180 -> 0.153 ms, 52x52 128->256 0.196 -> 0.172, 13x13 512->1024 0.182 -> 0.153,
+// 1024->1024 0.322 -> 0.313, 1280->1024 0.383 -> 0.366.  The same kernel as 256 x 128 on 4 waves (SA = 2, SB = 1, two
+// workgroups per CU, 32-pixel chunks) is no faster than 128 x 128 (0.170 / 0.180 / 0.174 / 0.347 / 0.415 on those layers).
+template <int KC, int SA = 2, int SB = 2, int WM = 2, int WN = 4>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_tr8_kernel(WgradHArgs p) {
   static_assert(KC == 32 || KC == 64, "k-chunk of 32 or 64 pixels");
-  constexpr int BM = 256, BN = 256, TM = 4, TN = 2, SA = 2, SB = 2;
+  constexpr int BM = 128 * SA, BN = 128 * SB, TM = BM / WM / 32, TN = BN / WN / 32, NT = 64 * WM * WN;
+  static_assert(TM * 32 * WM == BM && TN * 32 * WN == BN, "whole 32 x 32 accumulators per wave");
   typedef TileGeom<128, KC> GT;
-  constexpr int RPASS = 32;                         // pixel rows staged per pass of the 8 waves (4 per wave instruction)
+  constexpr int RPASS = 4 * WM * WN;                // pixel rows staged per pass of the workgroup (4 per wave instruction)
   constexpr int PASSES = KC / RPASS;
+  static_assert(PASSES >= 1 && PASSES * RPASS == KC, "whole staging passes");
   constexpr int SUB = KC * 128;                     // elements of one sub-tile
   constexpr int STAGE = (SA + SB) * SUB;
   extern __shared__ __attribute__((aligned(16))) u16 smem_w8[];
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_tr8_kernel(WgradHArgs p) {
   const int m0 = mt * BM, n0 = nt * BN;
   const int ncols = p.taps * p.Cin;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const long long pix0 = (long long)blockIdx.y * p.pix_per_split;
   long long pix_end = pix0 + p.pix_per_split;
   if (pix_end > p.M) pix_end = p.M;
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_tr8_kernel(WgradHArgs p) {
 
 inline int wgrad_h_kc(long long pixels);
 // workgroups of the weight-gradient kernel resident on the chip at a time, for the tile wgrad_h_tiles picks
-inline int wgrad_h_resident(int bm, int bn, long long pixels) { return (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64) ? 512 : 1536; }
+inline int wgrad_h_resident(int bm, int bn, long long pixels) { return (bm == 256 || (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64)) ? 512 : 1536; }
 
 inline int wgrad_h_splits(long long pixels, int tiles, int resident) {
   const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
@@ -1119,7 +1124,7 @@ extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int 
   const int ncols = ksize * ksize * cin;
   wgrad_h_tiles(cout, ncols, (long long)batch * height * width, &bm, &bn);
   const int tiles = ((cout + bm - 1) / bm) * ((ncols + bn - 1) / bn);
-  const int splits = bm == 256 ? wgrad_h_big_splits((long long)batch * height * width, tiles)
+  const int splits = (bm == 256 && bn == 256) ? wgrad_h_big_splits((long long)batch * height * width, tiles)
                                : wgrad_h_splits((long long)batch * height * width, tiles, wgrad_h_resident(bm, bn, (long long)batch * height * width));
   return (size_t)(splits + wgrad_h_fold_extra_slices(splits)) * cout * ksize * ksize * cin * sizeof(float);
 }
@@ -1145,12 +1150,12 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   wgrad_h_tiles(cout, ncols, pixels, &bm, &bn);
   a.m_tiles = (cout + bm - 1) / bm;
   a.n_tiles = (ncols + bn - 1) / bn;
-  const int splits = bm == 256 ? wgrad_h_big_splits(pixels, a.m_tiles * a.n_tiles)
+  const int splits = (bm == 256 && bn == 256) ? wgrad_h_big_splits(pixels, a.m_tiles * a.n_tiles)
                                : wgrad_h_splits(pixels, a.m_tiles * a.n_tiles, wgrad_h_resident(bm, bn, pixels));
-  const bool kc64 = bm == 256 || (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64);
+  const bool kc64 = (bm == 256 && bn == 256) || (bm == 128 && bn == 128 && wgrad_h_kc(pixels) == 64);
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kc64 ? 64 : 32);
   int rc;
-  if (bm == 256) {
+  if (bm == 256 && bn == 256) {
     const size_t lds = 2 * (size_t)64 * (256 + 256) * sizeof(u16);
     fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
     auto k = wgrad_bf16_tr8_kernel<64>;
