@@ -103,6 +103,7 @@ class EpisodeTrainer(object):
         self._launch_host_ms = [None] * len(self.buckets)        # host time since the start of backward() at launch
         self._ready_events = [None] * len(self.buckets)          # GPU: "this bucket's gradients are complete"
         self._bw_end_event, self._bw_host_ms = None, 0.0
+        self._streams_seen = []              # streams the current backward pass has queued gradient kernels on
         self._overlap = None                 # last step's measurements (time_allreduce only)
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
@@ -158,6 +159,10 @@ class EpisodeTrainer(object):
         same buckets in the same (ascending = readiness) order."""
         if self.dist is None or self.world_size <= 1:
             return
+        if self.grad.is_cuda:
+            for s_ in (torch.cuda.current_stream(),) + tuple(wait_streams):
+                if s_ is not None and not any(s_ == t for t in self._streams_seen):
+                    self._streams_seen.append(s_)
         for i, (lo, hi) in enumerate(self.buckets):
             if self._works[i] is not None:
                 continue
@@ -170,12 +175,13 @@ class EpisodeTrainer(object):
             self._launch_host_ms[i] = (time.perf_counter() - self._t_backward0) * 1e3
             if self.grad.is_cuda:
                 from . import streams
-                cur = torch.cuda.current_stream()
                 comm = streams.side(self.grad.device, "comm")
-                comm.wait_stream(cur)
-                for s_ in wait_streams:
-                    if s_ is not None and s_ != cur:
-                        comm.wait_stream(s_)
+                # A bucket can hold gradients queued on several streams at different times (the tail of the reweighting
+                # net's share, queued on the "meta" stream by the early sweep, shares a bucket with the detector's head):
+                # wait for EVERY stream this backward pass has reported so far, not only the reporting call's.  Streams are
+                # FIFO, so this waits for nothing that is not already due.
+                for s_ in self._streams_seen:
+                    comm.wait_stream(s_)
                 with torch.cuda.stream(comm):
                     if self.time_allreduce:
                         self._ready_events[i] = comm.record_event(torch.cuda.Event(enable_timing=True))
@@ -229,6 +235,7 @@ class EpisodeTrainer(object):
         self.launch_order_last, self._launch_order = self._launch_order, []
         self._launch_host_ms = [None] * len(self.buckets)
         self._ready_events = [None] * len(self.buckets)
+        self._streams_seen = []
         self.steps += 1
         bump_weight_epoch()
 

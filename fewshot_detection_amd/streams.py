@@ -94,7 +94,7 @@ def register_early(t, ctx):
     with _LOCK:
         _EARLY.pop(_key(t), None)
         _EARLY[_key(t)] = ctx
-        while len(_EARLY) > 4:
+        while len(_EARLY) > 2:          # (an entry pins its network's tape until it is taken or evicted)
             _EARLY.pop(next(iter(_EARLY)))
 
 
