@@ -58,3 +58,13 @@ def test_bench_refuses_to_run_without_a_gpu():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "no CPU fallback" in out.stderr
     assert out.stdout.strip() == ""                                       # and prints no JSON line
+
+
+def test_bench_quotes_the_newest_committed_traffic_summary():
+    """bench.py looked for profiles/r02_conv_traffic.json while the current file was r02b_...; it now takes the
+    newest rNN[letter]_<name> by round number, and the committed round-3 summary was measured on the headline episode."""
+    import bench
+    data, src = bench.newest_profile("conv_traffic.json")
+    assert data is not None and "r03" in src, src
+    assert data["episode"] == "metric_string" and 5e8 < data["hbm_bytes_per_launch"] < 2e9
+    assert bench.newest_profile("no_such_summary.json") == (None, None)

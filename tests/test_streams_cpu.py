@@ -55,3 +55,27 @@ def test_switches_follow_the_environment(monkeypatch):
         monkeypatch.delenv("FSD_STREAMS_WGRAD")
         importlib.reload(streams)
     assert streams.ENABLED is True and streams.WGRAD is True
+
+
+def test_early_backward_registry_hands_a_context_out_once_and_stays_small():
+    """streams.register_early / take_early: the reweighting net's autograd context is parked under its output's address
+    until the detector's sweep takes it; an entry nobody takes (a forward pass without backward) is evicted, oldest first,
+    so that at most two tapes stay pinned."""
+    streams._EARLY.clear()
+    outs = [torch.zeros(3) for _ in range(5)]
+    ctxs = [object() for _ in outs]
+    for t, c in zip(outs, ctxs):
+        streams.register_early(t, c)
+    assert len(streams._EARLY) <= 2
+    assert streams.take_early(outs[0]) is None                   # evicted
+    assert streams.take_early(outs[4]) is ctxs[4] and streams.take_early(outs[4]) is None
+    assert streams.take_early(outs[3][:2]) is ctxs[3]            # a view of the same storage address finds it
+
+
+def test_side_output_marks_are_bounded_and_queryable():
+    streams._FROM_SIDE.clear()
+    keep = [torch.zeros(2) for _ in range(40)]
+    for t in keep:
+        streams.mark_side_output(t)
+    assert len(streams._FROM_SIDE) <= 16
+    assert streams.from_side(keep[-1]) and not streams.from_side(keep[0]) and not streams.from_side(torch.zeros(2))
