@@ -349,7 +349,16 @@ class Leg(object):
                 "ms_profiled": ((t_b - t_a) / prof_steps * 1e3 if t_a is not None else None)}
 
 
-def roofline_block(r, dtype, ms):
+F32_GEMM_WHAT = {
+    "split": "fp32 operands split inside the kernel into three bfloat16 planes x = x1 + x2 + x3 (exact: 3 x 8 significant bits), "
+             "a product = the six cross terms down to 2^-16 relative on v_mfma_f32_32x32x16_bf16, fp32 accumulate; storage, "
+             "results and every non-GEMM kernel fp32.  Error against float64 <= the native fp32 MFMA's "
+             "(profiles/r03_split_probe.txt, tests/test_gpu_split.py)",
+    "native": "v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)",
+}
+
+
+def roofline_block(r, dtype, ms, gemm_mode="native"):
     """`roofline` of the bench line from the per-kernel-class HIP events of the profiled steps (r = Leg.run(...))."""
     kp, prof, per = r["kp"], r["prof"], max(1, r["prof_steps"])
     peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
@@ -378,10 +387,14 @@ def roofline_block(r, dtype, ms):
         "bound": "mfma",
         "kernel": ("conv_gemm_kernel: the fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernel behind the direct "
                    "3x3/1x1 convolutions, the data gradients and the 36 / 16 position GEMMs of the Winograd layers"
+                   if dom == "gemm_fwd" and gemm_mode == "native" else
+                   "conv_gemm_kernel<..., SPLIT>: the implicit-GEMM kernel behind the direct 3x3/1x1 convolutions, the data "
+                   "gradients and the 36 / 16 position GEMMs of the Winograd layers; fp32 operands split in-kernel into three "
+                   "bf16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 accumulate"
                    if dom == "gemm_fwd" else
                    "conv_bf16_*_kernel + wgrad_bf16_tr_kernel: the bf16-operand MFMA (v_mfma_f32_32x32x16_bf16) implicit-GEMM "
                    "kernels of the bf16 storage mode (forward, data gradient, weight gradient)"),
-        "note": "achieved = MFMA FLOPs this kernel really issues (2*rows*Cout*K per launch; the Winograd layers count "
+        "note": "achieved = fp32 GEMM FLOPs this kernel really computes (2*rows*Cout*K per launch; the Winograd layers count "
                 "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
                 "its own duration, HIP events recorded by the library right around every launch on the launch stream "
                 "during `profiled_steps` steps in the middle of the timed region, which run on one stream (no side-stream "
@@ -397,6 +410,18 @@ def roofline_block(r, dtype, ms):
                       "region_loss": hbm("region"), "sgd": hbm("sgd"), "first_layer": hbm("first_layer")},
     })
     if dtype == "f32":
+        roof["f32_gemm_arithmetic"] = {"mode": gemm_mode, "what": F32_GEMM_WHAT[gemm_mode]}
+        if gemm_mode == "split":
+            # `peak` above stays the dense fp32 MFMA peak (the dtype of the path); the instruction actually issued is the
+            # bf16 MFMA, six per fp32 product
+            roof["f32_gemm_arithmetic"].update({
+                "issued_bf16_tflops": 6.0 * roof["achieved"], "bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS,
+                "frac_of_bf16_peak_issued": 6.0 * roof["achieved"] / PEAK_BF16_MFMA_TFLOPS,
+                "fp32_equivalent_peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
+                "frac_of_fp32_equivalent_peak": roof["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                "note": "roofline.peak / frac are quoted against the dense fp32 MFMA peak (157.3 TFLOP/s, the dtype of the path); "
+                        "the same achieved figure against the ceiling of the instruction that runs (2500 / 6 = 416.7 TFLOP/s "
+                        "fp32-equivalent) is frac_of_fp32_equivalent_peak"})
         roof["wgrad_kernel"] = dict(mfma("gemm_wgrad"), kernel="wgrad_kernel: fp32 MFMA weight-gradient reduction GEMMs "
                                                                 "(direct layers and the F(3x3,4x4) Winograd batches)")
         roof["hbm"] = dict(hbm("wino_transform"), bound="hbm",
@@ -559,6 +584,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle comparison on the cpu_baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip also_measured (bf16 mode, backbone forward, other configs, ...)")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch conv timing to stderr")
+    ap.add_argument("--f32-gemm", choices=["split", "native"], default=None,
+                    help="arithmetic of the fp32 GEMM kernels: split = six bf16 MFMA terms of three-way split fp32 operands, fp32 "
+                         "accumulate (default; error <= the native instruction's, tests/test_gpu_split.py); native = "
+                         "v_mfma_f32_32x32x2_f32.  The default line also times the native arithmetic (also_measured)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -595,6 +624,9 @@ def main():
 
     if args.mode is None:
         args.mode = "train" if getattr(bw, "AVAILABLE", False) else "forward"
+    if args.f32_gemm is not None:
+        ops.f32_gemm_mode(args.f32_gemm)
+    gemm_mode = ops.f32_gemm_mode()
     if args.streams is not None:
         streams.ENABLED = bool(args.streams)
     streams_on = streams.ENABLED
@@ -638,7 +670,7 @@ def main():
         full_flops = episode_flops(blocks, lblocks, local_batch, args.classes, args.size, args.support)
         ms = elapsed / args.steps * 1e3
         episodes_per_step = 1 if strong else world
-        roof = roofline_block(r, args.dtype, ms)
+        roof = roofline_block(r, args.dtype, ms, gemm_mode)
         headline_shape = (args.batch, args.classes, args.size, args.support) == (64, 20, 416, 224)
         traffic, traffic_src = newest_profile("conv_traffic.json")
         use_traffic = bool(traffic) and args.mode == "train" and local_batch == 64 and args.dtype == "f32" and \
@@ -665,6 +697,7 @@ def main():
                            which, sname, "rank (supports replicated, queries split)" if strong else "GPU",
                            "fp32" if args.dtype == "f32" else "bf16 convs / fp32 BN+loss+master weights", args.neg),
                        "mode": args.mode, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "f32_gemm": gemm_mode if args.dtype == "f32" else None,
                        "episode_forward_gflop": full_flops / 1e9},
             "roofline": roof,
             "gpu_clock": dict(clock, what="shader clock from a dependent fp32-MFMA chain on every SIMD (fsd_clock_probe), right "
@@ -704,6 +737,22 @@ def main():
                 also.update(other_configs(leg, args, dev, blocks, lblocks))
             also["inference"] = {args.dtype: inference_latency(leg, dev, args.size)}
             other = "bf16" if args.dtype == "f32" else "f32"
+            if args.mode == "train" and args.dtype == "f32":
+                # the same step with the other arithmetic of the fp32 GEMMs (same model, weights and buffers: the mode is a
+                # launch-time switch of the kernels)
+                alt = "native" if gemm_mode == "split" else "split"
+                ops.f32_gemm_mode(alt)
+                try:
+                    r_alt = leg.run(step, 12, 5, 1, streams_on)
+                finally:
+                    ops.f32_gemm_mode(gemm_mode)
+                ms_alt = r_alt["elapsed"] / r_alt["steps"] * 1e3
+                also["f32_gemm_" + alt] = {
+                    "what": "the headline episode and train step with the fp32 GEMMs on %s: 5 warm-up + 12 timed steps, 1 of them "
+                            "profiled on one stream" % F32_GEMM_WHAT[alt].split(" (")[0],
+                    "ms_per_step": ms_alt, "episodes_per_s": 1e3 / ms_alt, "ms_per_step_unprofiled": r_alt["ms_unprofiled"],
+                    "loss": r_alt["loss"], "roofline": roofline_block(r_alt, "f32", ms_alt, alt)}
+                step()                                  # back on the headline arithmetic (weights keep training either way)
             if args.mode == "train":
                 # (2) the other storage mode on the same episode: its own model, trainer, timed region and roofline
                 leg2 = Leg(dyn_cfg, rw_cfg, other, dev, None, global_batch, args.mode)
@@ -715,7 +764,7 @@ def main():
                             "5 warm-up + 12 timed steps, 1 of them profiled on one stream"
                             % ("bf16 storage mode" if other == "bf16" else "fp32 mode"),
                     "ms_per_step": ms2, "episodes_per_s": 1e3 / ms2, "img_per_s": args.batch * 1e3 / ms2, "dtype": other,
-                    "ms_per_step_unprofiled": r2["ms_unprofiled"], "loss": r2["loss"], "roofline": roofline_block(r2, other, ms2)}
+                    "ms_per_step_unprofiled": r2["ms_unprofiled"], "loss": r2["loss"], "roofline": roofline_block(r2, other, ms2, gemm_mode)}
                 also["backbone_forward_" + other] = backbone_forward(dyn_cfg, other, dev, args.batch, args.size)
                 also[other + "_mode"]["other_configs"] = other_configs(leg2, args, dev, blocks, lblocks)
                 also["inference"][other] = inference_latency(leg2, dev, args.size)

@@ -23,13 +23,24 @@
 namespace {
 
 using namespace fsd_conv;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kBK = 32;      // k-chunk (floats) staged per LDS buffer
 constexpr int kLd = 36;      // padded LDS row stride (floats)
 
 __device__ float g_zero_page[64];   // zero-initialised, never written: source of padding for the DMA path
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, bool GLDS>
+// SPLIT: the same GEMM on the bf16 matrix cores at fp32 accuracy.  Every fp32 operand element is split, once per
+// workgroup on its way from the staging registers into LDS, into three bfloat16 planes x = x1 + x2 + x3 (x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significant bits = the 24 of fp32, the residuals are exact), and a
+// product a*b is accumulated (fp32, v_mfma_f32_32x32x16_bf16) from the six cross terms down to 2^-16 relative:
+// a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1.  The three dropped terms are <= 2^-24 |ab| each -- below the rounding of one
+// fp32 product.  Measured against a double-precision sum (tools/probes/split_gemm_probe.hip, profiles/r03_split_probe.txt):
+// relative L2 error 0.98e-6 at K = 4608 against 1.20e-6 for v_mfma_f32_32x32x2_f32, identical to all nine terms.
+// Six bf16 MFMAs cost 6/16 of the fp32 MFMAs they replace (2.48 PFLOP/s against 138 TFLOP/s measured issue rate).
+constexpr int kLdH = 40;     // SPLIT: padded LDS row stride of one plane (bf16 elements; 80 bytes: ds_read_b128 conflict-free)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, bool GLDS, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;      // threads per workgroup (4 or 8 waves)
   constexpr int RPP = NT / 8;                     // tile rows staged per pass (8 threads x 16 B per row)
@@ -40,8 +51,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   constexpr int A_PER_T = BM / RPP;   // float4 loads per thread per chunk
   constexpr int B_PER_T = BN / RPP;
   static_assert(!GLDS || (FASTK && STAGES >= 2), "direct-to-LDS staging needs the per-tap fast path and >= 2 LDS stages");
+  static_assert(!(SPLIT && GLDS), "the split happens in the staging registers");
   constexpr int LD = GLDS ? kBK : kLd;          // GLDS: linear 128-B rows (XOR-swizzled), else padded rows
-  constexpr int STAGE = (BM + BN) * LD;
+  constexpr int PLANE = (BM + BN) * kLdH;       // SPLIT: bf16 elements of one plane of one stage
+  constexpr int STAGE = SPLIT ? 3 * PLANE / 2 : (BM + BN) * LD;     // floats
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   if (gridDim.y > 1) {      // batched GEMMs: every batch has its own operand / result matrices
@@ -161,6 +174,21 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     }
   };
   auto sstore = [&](float* st) {
+    if constexpr (SPLIT) {
+      unsigned short* sp = reinterpret_cast<unsigned short*>(st);
+#pragma unroll
+      for (int j = 0; j < A_PER_T + B_PER_T; ++j) {
+        const bool is_a = j < A_PER_T;
+        const f32x4 v = is_a ? ((a_mask >> j) & 1u ? ra[is_a ? j : 0] : f32x4{0.f, 0.f, 0.f, 0.f}) : rb[is_a ? 0 : j - A_PER_T];
+        const int row = is_a ? r0 + RPP * j : BM + r0 + RPP * (j - A_PER_T);
+        uint2 h, m, l;
+        split3(v, h, m, l);
+        *reinterpret_cast<uint2*>(sp + row * kLdH + kq * 4) = h;
+        *reinterpret_cast<uint2*>(sp + PLANE + row * kLdH + kq * 4) = m;
+        *reinterpret_cast<uint2*>(sp + 2 * PLANE + row * kLdH + kq * 4) = l;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
       const f32x4 v = (a_mask >> j) & 1u ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -183,6 +211,38 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // GLDS read-side un-swizzle: logical k-group g of row r sits at physical group g ^ ((r >> 1) & 7)
   auto kofs = [&](int k8) { return GLDS ? (((k8 * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) * 4) : k8 * 8; };
   auto compute = [&](const float* st) {
+    if constexpr (SPLIT) {
+      // lane = tile row (lane & 31), 8 consecutive k of the 16 of one MFMA (lane >> 5): one ds_read_b128 per plane and tile
+      const unsigned short* sp = reinterpret_cast<const unsigned short*>(st);
+      const unsigned short* sa = sp + (wm * TM * 32 + (lane & 31)) * kLdH + (lane >> 5) * 8;
+      const unsigned short* sb = sp + (BM + wn * TN * 32 + (lane & 31)) * kLdH + (lane >> 5) * 8;
+      bf16x8 af[2][3][TM], bf[2][3][TN];
+      auto frags = [&](int k16, int buf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[buf][q][i] = *reinterpret_cast<const bf16x8*>(sa + q * PLANE + i * 32 * kLdH + k16 * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[buf][q][j] = *reinterpret_cast<const bf16x8*>(sb + q * PLANE + j * 32 * kLdH + k16 * 16);
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int k16 = 0; k16 < kBK / 16; ++k16) {
+        if (k16 + 1 < kBK / 16) frags(k16 + 1, (k16 + 1) & 1);
+        // the six terms, smallest first; each term sweeps the TM x TN independent accumulators
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = NCHW_OUT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[k16 & 1][TB[t]][j], af[k16 & 1][TA[t]][i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k16 & 1][TA[t]][i], bf[k16 & 1][TB[t]][j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const float* sa = st + (wm * TM * 32) * LD + frag_off;
     const float* sb = st + (BM + wn * TN * 32) * LD + frag_off;
     {
@@ -335,8 +395,11 @@ inline int tile_cfg(int cin, int ksize, int cout, bool nchw = false) {
   // outputs no wider than 32 channels: a 64-wide tile would idle half the MFMAs.  (Short reductions, K <= 320, used to
   // take this tile too; re-measured with the current kernel the 64x64 tile is 8-10 % faster there: 32->64 @208x208
   // 1.27 -> 1.18 ms, 128->64 1x1 @104x104 0.154 -> 0.144 ms.)
-  (void)cin; (void)ksize;
-  return (cout <= 32 && !nchw) ? kTile128x32 : kTile64;
+  (void)cin;
+  if (cout <= 32 && !nchw) return kTile128x32;
+  // split arithmetic, 3x3 into 64 channels (32 -> 64 at 208x208): 128x64 tiles 0.994 ms against 1.076 for 64x64
+  if (fsd_conv::f32_split_on() && ksize == 3 && cout == 64 && !nchw) return kTile128x64;
+  return kTile64;
 }
 
 template <typename K>
@@ -350,11 +413,24 @@ int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t s
   return (int)hipGetLastError();
 }
 
+inline bool split_on() { return fsd_conv::f32_split_on(); }
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool GLDS = false>
 int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
   const bool fast = a.cpt > 0;
   constexpr int NT = WM * WN * 64;
   const size_t tile_bytes = a.wide ? (size_t)BM * BN * sizeof(float) : 0;       // the wide epilogue's [BM][BN] tile
+  if (split_on()) {
+    // one stage of three planes is 240 B per tile row: 128x128 -> 60 KB (two workgroups per CU), 64x64 -> 30 KB
+    constexpr int SS = (BM + BN >= 256) ? 1 : (STAGES > 2 ? 2 : STAGES);
+    size_t lds_s = SS * (size_t)3 * (BM + BN) * kLdH * sizeof(unsigned short);
+    if (lds_s < tile_bytes) lds_s = tile_bytes;
+    if (nchw)
+      return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, SS, true, false, true>, a, lds_s, NT, stream)
+                  : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, SS, false, false, true>, a, lds_s, NT, stream);
+    return fast ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, SS, true, false, true>, a, lds_s, NT, stream)
+                : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, SS, false, false, true>, a, lds_s, NT, stream);
+  }
   if constexpr (GLDS) {
     if (fast) {      // the DMA path needs the per-tap fast path; other layers fall through to register staging
       size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
@@ -406,12 +482,35 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
 // The 128-row tile needs rows to fill it: the reweighting net's last layers have 20-80 tile rows per position (3x3 and
 // 7x7 maps of 20 supports), where a 128-row tile is 84 % padding -- those keep the 64x64 tile (4 launches per step,
 // 75-140 us each with the 128-row tile).
+// Split arithmetic (six bf16 MFMA terms): the 128x128 register-staged tile wins on EVERY Winograd layer of the episode
+// (measured round 3, gemm ms per launch, 64x64 / 128x128 / 128x64: 104x104 64->128 0.347 / 0.299 / 0.335, 52x52 0.252 /
+// 0.219 / 0.234, 26x26 0.243 / 0.221 / 0.234, 13x13 512->1024 0.303 / 0.251 / 0.274, 1024->1024 0.585 / 0.490 / 0.540):
+// the matrix work of a tile is a third of the native kernel's, so the operand traffic per MFMA decides.
 inline char batched_pick(long long rows, int cin, int cout) {
   static const char* env = getenv("FSD_WINO_TILE");
-  return env ? env[0] : (cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a');
+  if (env) return env[0];
+  if (fsd_conv::f32_split_on()) return rows >= 96 && cout > 64 ? 'c' : 'a';
+  return cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a';
 }
 
+// -1: not decided yet (first use reads FSD_F32_SPLIT; default 1 = split arithmetic, FSD_F32_SPLIT=0 = native fp32 MFMA)
+int g_f32_split = -1;
+
 }  // namespace
+
+bool fsd_conv::f32_split_on() {
+  if (g_f32_split < 0) {
+    const char* env = getenv("FSD_F32_SPLIT");
+    g_f32_split = (env && env[0] == '0') ? 0 : 1;
+  }
+  return g_f32_split == 1;
+}
+
+extern "C" int fsd_f32_gemm_mode(int mode) {
+  const int prev = fsd_conv::f32_split_on() ? 1 : 0;
+  if (mode == 0 || mode == 1) g_f32_split = mode;
+  return prev;
+}
 
 int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
   const char pick = batched_pick(rows, cin, cout);

@@ -37,6 +37,29 @@ struct ConvArgs {
 int conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs, float* y,
                       long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches, hipStream_t stream);
 
+// fp32 -> three bfloat16 planes x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the residuals
+// are exact: 3 x 8 significant bits = the 24 of fp32) for four values; see conv.hip, conv_gemm_kernel SPLIT.
+__device__ __forceinline__ void split3(const f32x4& v, uint2& h, uint2& m, uint2& l) {
+  unsigned short hs[4], ms[4], ls[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 b1 = (__bf16)v[i];
+    const float r1 = v[i] - (float)b1;
+    const __bf16 b2 = (__bf16)r1;
+    const float r2 = r1 - (float)b2;
+    const __bf16 b3 = (__bf16)r2;
+    hs[i] = __builtin_bit_cast(unsigned short, b1);
+    ms[i] = __builtin_bit_cast(unsigned short, b2);
+    ls[i] = __builtin_bit_cast(unsigned short, b3);
+  }
+  h = make_uint2((unsigned)hs[0] | ((unsigned)hs[1] << 16), (unsigned)hs[2] | ((unsigned)hs[3] << 16));
+  m = make_uint2((unsigned)ms[0] | ((unsigned)ms[1] << 16), (unsigned)ms[2] | ((unsigned)ms[3] << 16));
+  l = make_uint2((unsigned)ls[0] | ((unsigned)ls[1] << 16), (unsigned)ls[2] | ((unsigned)ls[3] << 16));
+}
+
+// runtime switch of the fp32 GEMM arithmetic (conv.hip): true = six bf16 MFMA terms of three-way split operands
+bool f32_split_on();
+
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   // consecutive logical tiles on one XCD (own L2): dispatch places block b on XCD b % 8
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;

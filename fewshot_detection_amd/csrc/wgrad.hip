@@ -22,6 +22,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
 
 constexpr int kBK = 32;       // pixels per k-chunk
 constexpr int kThreads = 256;
@@ -44,10 +47,15 @@ struct WgradArgs {
 //                 registers, no ds_write, no address VALU in the loop; LDS rows are unpadded (the DMA writes 1 KB per
 //                 wave instruction linearly), which is conflict-free for the 32-lane b32 fragment reads.  Needs full
 //                 tiles and full 32-row chunks: the launcher sends column remainders / the last < 32 rows elsewhere.
-template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false>
+//   SPLIT = true: the same reduction on the bf16 matrix cores at fp32 accuracy (conv.hip, conv_gemm_kernel SPLIT): every
+//                 staged fp32 value is split into three bfloat16 planes on its way into LDS ([pixel][channel] bf16 tiles,
+//                 one per plane, 16-byte pieces XOR-permuted inside a row), the k-contiguous MFMA fragments come out
+//                 through the transposing read ds_read_b64_tr_b16, and a product is six MFMA terms.  One LDS stage.
+template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   static_assert(!BF16, "fp32 kernel");
   static_assert(!DMA || (PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
+  static_assert(!SPLIT || (!DMA && STAGES == 1), "split operands: register staging, one LDS stage");
   typedef float lds_t;
   constexpr int LDT = DMA ? TILE : TILE + 4;   // LDS row stride in elements (keeps 16-byte alignment)
   constexpr int CQ = TILE / 4;                     // float4 column groups per tile row
@@ -129,7 +137,28 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
   auto put = [&](lds_t* dst, f32x4 v, bool ok) {
     *reinterpret_cast<f32x4*>(dst) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  constexpr int PT = kBK * TILE;                   // SPLIT: bf16 elements of one plane tile ([32 pixels][TILE channels])
+  auto swz = [](int row) { return TILE == 128 ? ((row & 3) << 2) : ((row & 2) << 1); };   // XOR on the 16-byte piece index
   auto sstore = [&](lds_t* st) {
+    if constexpr (SPLIT) {
+      u16* sp = reinterpret_cast<u16*>(st);
+#pragma unroll
+      for (int j = 0; j < PASSES; ++j) {
+        const int row = kr + RPP * j;
+        const int off = row * TILE + (((cq >> 1) ^ swz(row)) << 3) + (cq & 1) * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        uint2 h, m, l;
+        fsd_conv::split3((okmask >> j) & 1u ? ra[j] : zero, h, m, l);
+        *reinterpret_cast<uint2*>(sp + off) = h;
+        *reinterpret_cast<uint2*>(sp + PT + off) = m;
+        *reinterpret_cast<uint2*>(sp + 2 * PT + off) = l;
+        fsd_conv::split3((okmask >> (8 + j)) & 1u ? rb[j] : zero, h, m, l);
+        *reinterpret_cast<uint2*>(sp + 3 * PT + off) = h;
+        *reinterpret_cast<uint2*>(sp + 4 * PT + off) = m;
+        *reinterpret_cast<uint2*>(sp + 5 * PT + off) = l;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
       put(st + (kr + RPP * j) * LDT + cq * 4, ra[j], (okmask >> j) & 1u);
@@ -146,6 +175,42 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](const lds_t* st) {
+    if constexpr (SPLIT) {
+      // transpose-read geometry: 16-lane group G = lane >> 4 reads pixel rows kb + (L >> 2), channels cb + 4 * (L & 3); two
+      // reads (rows +0..3, +4..7) give the lane the 8 consecutive pixels of its channel that one 16-wide MFMA step wants
+      const u16* sp = reinterpret_cast<const u16*>(st);
+      const int G = lane >> 4, Lq = lane & 15;
+      auto frag = [&](const u16* tile, int ch0, int krow, int mask) -> bf16x8 {
+        const int row = krow + (Lq >> 2);
+        const int ch = ch0 + 16 * (G & 1) + 4 * (Lq & 3);
+        const u16* a = tile + row * TILE + (((ch >> 3) ^ mask) << 3) + (ch & 7);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a + 4 * TILE));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+#pragma unroll
+      for (int s16 = 0; s16 < kBK / 16; ++s16) {
+        const int krow = s16 * 16 + (G >> 1) * 8;
+        const int mask = swz(krow + (Lq >> 2));                  // the +4 rows of the second read share it
+        bf16x8 af[3][T], bf[3][T];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int i = 0; i < T; ++i) af[q][i] = frag(sp + q * PT, wm * (T * 32) + i * 32, krow, mask);
+#pragma unroll
+          for (int j = 0; j < T; ++j) bf[q][j] = frag(sp + (3 + q) * PT, wn * (T * 32) + j * 32, krow, mask);
+        }
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};     // the six terms, smallest first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     {
       const float* sa = st + (lane >> 5) * 4 * LDT + wm * (T * 32) + (lane & 31);
       const float* sb = st + kBK * LDT + (lane >> 5) * 4 * LDT + wn * (T * 32) + (lane & 31);
@@ -420,12 +485,14 @@ inline int first_blocks(long long pixels) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-inline int pick_splits(long long pixels, int tiles) {
+inline int pick_splits(long long pixels, int tiles, int tile = 64) {
   // Two rounds of the 1536 co-resident 64x64 workgroups (6 per CU), rounded DOWN so that the launch does not spill a few
   // workgroups into a third round.  Measured round 2 (tools/layer_bench.py wgrad; 2048 rounded up -> 3072 rounded down):
   // 208x208 32->64 1.487 -> 1.403 ms, 104x104 0.671 -> 0.663, 52x52 0.425 -> 0.423, 26x26 0.382 -> 0.375.
   static const char* env = getenv("FSD_WGRAD_TARGET");          // tuning aid: target number of 64x64 workgroups
-  const int target = env && atoi(env) > 0 ? atoi(env) : 3072;
+  // (128x128 tiles, split arithmetic: half the workgroups -- two per CU are co-resident; measured 26x26 256->512
+  // 0.254 -> 0.205 ms against a quarter, 13x13 1280->1024 0.628 -> 0.599)
+  const int target = (env && atoi(env) > 0 ? atoi(env) : 3072) / (tile == 128 ? 2 : 1);
   int s = target / tiles;
   const long long max_s = (pixels + 255) / 256;      // at least 8 k-chunks per split
   if (s > max_s) s = (int)max_s;
@@ -442,12 +509,37 @@ inline int f32_variant() {
   return v == 128 ? 1 : v == 1281 ? 2 : v == 642 ? 3 : v == 640 ? 4 : 0;     // 642: 64x64 two stages, 640: no 1x1 specialisation
 }
 inline int tile_of(int bf16) { return (bf16 || f32_variant() == 1 || f32_variant() == 2) ? 128 : 64; }
+// tile of the fp32 path for a dW of cout x ncols: split arithmetic takes the 128x128 tile where both dimensions fill it
+inline int f32_tile(int cout, int ncols) {
+  if (!fsd_conv::f32_split_on()) return tile_of(0);
+  static const char* env = getenv("FSD_WGRAD_SPLIT_TILE");      // tuning aid: 64 or 128
+  if (env) return atoi(env) == 128 ? 128 : 64;
+  return (cout % 128 == 0 && ncols >= 128) ? 128 : 64;
+}
 
-int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream) {
+int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream, int tile = 0) {
   // issued MFMA work: dW[Cout][ncols] reduced over M pixel rows, per batch (grid.z)
   fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)a.Cout * a.ncols * grid.z, stream);
   if (bf16) {
     return FSD_ERR_UNSUPPORTED;       // bf16 operands: fsd_conv2d_wgrad_h
+  } else if (fsd_conv::f32_split_on()) {
+    // three bf16 planes of the [32 pixels][TILE channels] tiles of both operands, one stage
+    if (tile == 128) {
+      const size_t lds = 6 * (size_t)kBK * 128 * sizeof(u16);
+      if (a.ks == 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 1, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wgrad_kernel<128, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
+      } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 1, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wgrad_kernel<128, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
+      }
+    } else {
+      const size_t lds = 6 * (size_t)kBK * 64 * sizeof(u16);
+      if (a.ks == 1) hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
+      else hipLaunchKernelGGL((wgrad_kernel<64, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
+    }
   } else if (f32_variant() == 1) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -478,7 +570,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   if ((dy_ld & 3) || (x_ld & 3) || dy_ld < round_up(cout, 4) || x_ld < cin4) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
   if (pixels > 0x7fffffffLL - 4096) return FSD_ERR_UNSUPPORTED;
-  const int tile = tile_of(bf16);
+  const int tile = bf16 ? tile_of(bf16) : f32_tile(cout, ksize * ksize * cin4);
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
   a.dy_ld = dy_ld; a.x_ld = x_ld;
@@ -487,12 +579,12 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   a.ncols = ksize * ksize * cin4;
   a.m_tiles = (cout + tile - 1) / tile;
   a.n_tiles = (a.ncols + tile - 1) / tile;
-  const int splits = pick_splits(pixels, a.m_tiles * a.n_tiles);
+  const int splits = pick_splits(pixels, a.m_tiles * a.n_tiles, tile);
   if (workspace_bytes < (size_t)splits * cout * a.ncols * sizeof(float)) return FSD_ERR_WORKSPACE;
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
   a.dy_bs = a.x_bs = a.ws_bs = 0;
   const dim3 grid(a.m_tiles * a.n_tiles, splits);
-  if (int rc = launch_wgrad(a, bf16, grid, stream)) return rc;
+  if (int rc = launch_wgrad(a, bf16, grid, stream, tile)) return rc;
   if (splits <= 8)
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
@@ -511,7 +603,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
 struct BatchedPlan { bool dma; int splits; int tail_rows; int slots; };
 inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) {
   static const char* env = getenv("FSD_WGRAD_DMA");         // tuning aid: 0 disables the DMA variant
-  const bool allow = !(env && env[0] == '0') && f32_variant() == 0;
+  const bool allow = !(env && env[0] == '0') && f32_variant() == 0 && !fsd_conv::f32_split_on();
   BatchedPlan pl;
   const long long full = rows / kBK * kBK;
   // measured (tools/layer_bench.py wgrad): +5-7 % on the 1024/1280-channel layers, +2 % at 512, -2 % at 128/256
@@ -530,9 +622,9 @@ inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) 
     pl.tail_rows = (int)(rows - full);
     pl.slots = pl.splits + (pl.tail_rows ? 1 : 0);
   } else {
-    const int tile = tile_of(0);
+    const int tile = f32_tile(cout, cin);
     const int tiles = ((cout + tile - 1) / tile) * ((cin + tile - 1) / tile) * batches;
-    pl.splits = pick_splits(rows, tiles);
+    pl.splits = pick_splits(rows, tiles, tile);
     pl.tail_rows = 0;
     pl.slots = pl.splits;
   }
@@ -581,11 +673,11 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
     return (int)hipGetLastError();
   }
   a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;
-  const int tile = tile_of(0);
+  const int tile = f32_tile(cout, cin);
   a.m_tiles = (cout + tile - 1) / tile;
   a.n_tiles = (cin + tile - 1) / tile;
   a.pix_per_split = round_up((int)((rows + pl.splits - 1) / pl.splits), kBK);
-  if (int rc = launch_wgrad(a, 0, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), stream)) return rc;
+  if (int rc = launch_wgrad(a, 0, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), stream, tile)) return rc;
   return (int)hipGetLastError();
 }
 
@@ -659,12 +751,16 @@ extern "C" int fsd_conv3x3_wgrad_c4_bnfused_h(const void* dt, long long dt_ld, c
 }
 
 extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
-  // sized for the finer (fp32, 64x64) tiling, which needs the larger number of splits; valid for both modes
+  // the larger of the two tilings the fp32 path may use (64x64; 128x128 under split arithmetic): valid for either mode
   const long long pixels = (long long)batch * height * width;
   const int ncols = ksize * ksize * round_up(cin, 4);
-  const int tile = tile_of(0);
-  const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
-  return (size_t)pick_splits(pixels, tiles) * cout * ncols * sizeof(float);
+  int splits = 0;
+  for (int tile : {tile_of(0), 128}) {
+    const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
+    const int s = pick_splits(pixels, tiles, tile);
+    splits = s > splits ? s : splits;
+  }
+  return (size_t)splits * cout * ncols * sizeof(float);
 }
 
 extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,

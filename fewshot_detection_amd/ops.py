@@ -657,3 +657,11 @@ def clock_probe_mhz(device, iters=2000):
     mhz = C.c_double(0.0)
     check(lib().fsd_clock_probe(scratch.data_ptr(), int(iters), C.byref(mhz), _stream()), "fsd_clock_probe")
     return float(mhz.value)
+
+
+
+def f32_gemm_mode(mode=None):
+    """Arithmetic of the fp32 GEMM kernels: "native" (fp32 MFMA) or "split" (six bf16 MFMA terms of three-way split
+    operands, fp32-accurate; include/fsdet.h fsd_f32_gemm_mode).  Returns the previous mode; None only queries."""
+    prev = lib().fsd_f32_gemm_mode(-1 if mode is None else {"native": 0, "split": 1}[mode])
+    return "split" if prev else "native"

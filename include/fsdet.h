@@ -428,6 +428,16 @@ int fsd_profile_collect(double* ms, double* work, long long* launches, int n_cla
  * synchronises.  scratch: any device buffer of >= 4 bytes (never written). */
 int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stream);
 
+/* ---- arithmetic of the fp32 GEMMs (forward / data-gradient / weight-gradient kernels of the fp32 mode) ------------------
+ * mode 0: native fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
+ * mode 1: "split" -- every fp32 operand element is split, inside the kernel on its way into LDS, into three bfloat16 planes
+ *         x = x1 + x2 + x3 (exact), and a product is accumulated in fp32 from the six cross terms down to 2^-16 relative on
+ *         the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16).  Storage, accumulation and results stay fp32; the error
+ *         against a float64 reference is at or below the native instruction's (tests/test_gpu_split.py).
+ * Any other value only queries.  Returns the previous mode.  Takes effect for kernels launched afterwards; the first use
+ * reads the environment variable FSD_F32_SPLIT (0 / 1). */
+int fsd_f32_gemm_mode(int mode);
+
 const char* fsd_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,114 @@
+"""Arithmetic of the fp32 GEMM kernels (include/fsdet.h, fsd_f32_gemm_mode): the default "split" mode -- six bf16 MFMA terms
+of three-way split operands, fp32 accumulate -- has to be as accurate as the native fp32 matrix instruction it replaces.
+The referee is a float64 convolution; both modes are run on the same inputs, forward / data gradient / weight gradient,
+Winograd and direct forms."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def restore_mode():
+    from fewshot_detection_amd import ops
+    before = ops.f32_gemm_mode()
+    yield
+    ops.f32_gemm_mode(before)
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).norm() / ref.norm())
+
+
+SHAPES = [  # B, H, W, cin, cout, k
+    (4, 52, 52, 128, 256, 3),      # Winograd F(4x4)
+    (8, 13, 13, 1024, 1024, 3),    # Winograd F(4x4), long reduction
+    (2, 104, 104, 32, 64, 3),      # direct 3x3
+    (4, 26, 26, 512, 256, 1),      # 1x1
+    (3, 7, 7, 256, 512, 3),        # small map of the reweighting net
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_split_is_as_accurate_as_the_native_fp32_mfma(dev, shape):
+    from fewshot_detection_amd import ops
+    B, H, W, cin, cout, k = shape
+    torch.manual_seed(sum(shape))
+    xn = torch.randn(B, cin, H, W, device=dev)
+    xn = torch.where(xn > 0, xn, 0.1 * xn)                       # activations as the network sees them (leaky)
+    w = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
+    dyn = torch.randn(B, cout, H, W, device=dev)
+    xd = xn.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref_y = F.conv2d(xd, wd, padding=k // 2)
+    ref_dx, ref_dw = torch.autograd.grad(ref_y, (xd, wd), dyn.double())
+    ref_y = ref_y.detach()
+
+    x = ops.nchw_to_nhwc(xn)
+    dy = ops.nchw_to_nhwc(dyn)
+    tile = ops.wino_tile(cin, cout, k, H, W)
+    errs = {}
+    outs = {}
+    for mode in ("native", "split"):
+        ops.f32_gemm_mode(mode)
+        assert ops.f32_gemm_mode() == mode
+        if tile:
+            y, _ = ops.conv3x3_wino(x, ops.pack_weight_wino(w, 0, tile), cout, tile=tile)
+            dx, _ = ops.conv3x3_wino(dy, ops.pack_weight_wino(w, 1, tile), cin, tile=tile)
+        else:
+            y, _ = ops.conv2d(x, ops.pack_weight(w), cout, k)
+            dx, _ = ops.conv2d(dy, ops.pack_weight(w, 1), cin, k)
+        dw = ops.conv2d_wgrad(dy, cout, x, cin, k)
+        outs[mode] = (ops.nhwc_to_nchw(y), ops.nhwc_to_nchw(dx), dw)
+        errs[mode] = (_rel(outs[mode][0], ref_y), _rel(outs[mode][1], ref_dx), _rel(dw, ref_dw))
+    for what, en, es in zip(("forward", "data gradient", "weight gradient"), errs["native"], errs["split"]):
+        # fp32 round-off level for both (the F(4x4) transforms contribute ~1e-5, see winograd.hip) ...
+        assert en < 5e-5 and es < 5e-5, (what, en, es)
+        # ... and the split arithmetic is not the less accurate of the two (1.25 = run-to-run slack between two roundings)
+        assert es <= 1.25 * en + 2e-7, (what, en, es)
+    # the two modes are different arithmetic: close, not identical
+    assert not torch.equal(outs["native"][0], outs["split"][0])
+
+
+def test_mode_switch_reports_the_previous_mode(dev):
+    from fewshot_detection_amd import ops
+    first = ops.f32_gemm_mode()
+    assert first in ("native", "split")
+    assert ops.f32_gemm_mode("native") == first
+    assert ops.f32_gemm_mode("split") == "native"
+    assert ops.f32_gemm_mode() == "split"
+
+
+def test_training_step_in_both_modes_agrees_to_round_off(dev, tmp_path):
+    """One episode step of the standard pair of networks per mode from the same initial state.  The loss agrees to fp32
+    round-off; the gradients agree as well as two fp32 evaluations of this network can: a different rounding flips a few
+    leaky-ReLU / max-pool winners near ties, and a fraction f of flipped winners costs ~sqrt(f) in relative L2 (the
+    teacher-forced per-block test of tests/test_gpu_timed_config.py removes exactly that and holds 1e-4; the replay of the
+    reference's train_meta.py in tests/test_gpu_drivers.py measures 9.5e-3 per update against the reference itself)."""
+    from fewshot_detection_amd import cfgs, ops
+    from fewshot_detection_amd.darknet_meta import Darknet
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    results = {}
+    for mode in ("native", "split"):
+        ops.f32_gemm_mode(mode)
+        torch.manual_seed(11)
+        net = Darknet(dyn_cfg, rw_cfg).to(dev).train()
+        n_cls = 5
+        x = torch.rand(2, 3, 160, 160, device=dev)
+        metax = torch.rand(n_cls, 3, 160, 160, device=dev)
+        mask = (torch.rand(n_cls, 1, 160, 160, device=dev) > 0.5).float()
+        out = net(x, metax, mask)
+        loss = out.float().pow(2).mean()
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None])
+        results[mode] = (float(loss.detach()), grads.double().clone())
+    (ln, gn), (ls, gs) = results["native"], results["split"]
+    assert abs(ln - ls) <= 1e-5 * abs(ln)
+    assert float((gn - gs).norm() / gn.norm()) < 3e-2

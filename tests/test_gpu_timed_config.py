@@ -24,6 +24,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["native", "split"])
+def gemm_mode(request):
+    """Both arithmetics of the fp32 GEMM kernels (include/fsdet.h fsd_f32_gemm_mode): the DMA-staged variants belong to the
+    native fp32 MFMA path; the split path (the default) takes register-staged 128x128 tiles on the same shapes."""
+    from fewshot_detection_amd import ops
+    before = ops.f32_gemm_mode(request.param)
+    yield request.param
+    ops.f32_gemm_mode(before)
+
+
 def _plan(fn, B, H, W, cin, cout, tile=4):
     a = (C.c_int * 4)()
     assert fn(B, H, W, cin, cout, tile, a) == 0
@@ -40,12 +50,14 @@ def _plan(fn, B, H, W, cin, cout, tile=4):
     (64, 13, 13, 1280, 1024, 0),      # the bench shape of L29 (T = 1024, 36 positions)
     (64, 13, 13, 1024, 1024, 0),      # L23/L24 of the bench
 ])
-def test_wgrad_dma128_variant_matches_fp64(dev, B, H, W, cin, cout, tail):
+def test_wgrad_dma128_variant_matches_fp64(dev, gemm_mode, B, H, W, cin, cout, tail):
     from fewshot_detection_amd import ops
     L = ops.lib()
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
     dma, splits, tail_rows, slots = _plan(L.fsd_wino_wgrad_plan, B, H, W, cin, cout)
-    if T >= 256:
+    if gemm_mode == "split":
+        assert dma == 0 and tail_rows == 0 and slots == splits >= 1      # one register-staged launch covers every row
+    elif T >= 256:
         assert dma == 1 and tail_rows == tail == T % 32 and slots == splits + (1 if tail else 0), (dma, splits, tail_rows)
     else:
         assert dma == 0                                   # control case: the 64x64 kernel
@@ -74,14 +86,15 @@ def test_wgrad_dma128_variant_matches_fp64(dev, B, H, W, cin, cout, tail):
     (64, 13, 13, 1280, 1024, 8),      # L29 at the bench batch
     (64, 13, 13, 1024, 1024, 8),      # L23/L24 at the bench batch
 ])
-def test_wino_gemm_dma128_multi_tile_matches_fp64(dev, B, H, W, cin, cout, m_tiles):
+def test_wino_gemm_dma128_multi_tile_matches_fp64(dev, gemm_mode, B, H, W, cin, cout, m_tiles):
     """Forward and data gradient (mode-1 weights) of the K >= 1024 Winograd layers with several M tiles."""
     from fewshot_detection_amd import ops
     L = ops.lib()
+    want_dma = 1 if gemm_mode == "native" else 0
     bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cin, cout)
-    assert (bm, bn, dma, mt) == (128, 128, 1, m_tiles)
+    assert (bm, bn, dma, mt) == (128, 128, want_dma, m_tiles)
     bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cout, cin)      # the data gradient swaps the roles
-    assert (bm, bn, dma, mt) == (128, 128, 1, m_tiles)
+    assert (bm, bn, dma, mt) == (128, 128, want_dma, m_tiles)
     g = torch.Generator().manual_seed(cin + B)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5

@@ -16,6 +16,7 @@ from fewshot_detection_amd import ops  # noqa: E402
 SHAPES = [  # B, H, W, cin, cout, k
     (64, 208, 208, 32, 64, 3), (64, 104, 104, 64, 128, 3), (64, 104, 104, 128, 64, 1), (64, 52, 52, 128, 256, 3),
     (64, 26, 26, 256, 512, 3), (64, 13, 13, 512, 1024, 3), (64, 13, 13, 1024, 1024, 3), (64, 13, 13, 1280, 1024, 3),
+    (64, 52, 52, 256, 128, 1), (64, 26, 26, 512, 256, 1), (64, 13, 13, 1024, 512, 1), (64, 26, 26, 512, 64, 1),
 ]
 
 
