@@ -458,6 +458,8 @@ def backbone_forward(dyn_cfg, dtype, dev, B, S):
     out = {"what": "Darknet-19 backbone = layers 0-22 of darknet_dynamic.cfg, forward only, B=%d %dx%d, %s"
                    % (B, S, S, "fp32" if dtype == "f32" else "bf16 storage mode"),
            "algorithmic_gflop": algorithmic / 1e9, "mfma_peak_tflops": peak}
+    if dtype == "f32":
+        out["f32_gemm"] = ops.f32_gemm_mode()       # "split": six bf16 MFMA terms per fp32 product; the peak quoted stays the fp32 MFMA's
     for mode in ("train_bn", "eval_folded"):
         net.train(mode == "train_bn")
 
@@ -483,8 +485,9 @@ def backbone_forward(dyn_cfg, dtype, dev, B, S):
                      "mfma_kernels_ms": g_ms, "issued_tflops_in_mfma_kernels": issued / (g_ms * 1e-3) / 1e12 if g_ms else None,
                      "frac_of_mfma_peak_issued_in_mfma_kernels": issued / (g_ms * 1e-3) / 1e12 / peak if g_ms else None,
                      "kernel_ms_by_class": {k: v["ms"] / 2 for k, v in kp.items() if v["launches"]}}
-    out["note"] = ("algorithmic = direct-convolution FLOPs (1210.0 GFLOP at B=64, BASELINE.md); issued = MFMA FLOPs the kernels "
-                   "really execute (the fp32 Winograd layers issue 4x / 2.25x fewer; the first layer's direct-operand kernel is "
+    out["note"] = ("algorithmic = direct-convolution FLOPs (1210.0 GFLOP at B=64, BASELINE.md); issued = fp32 GEMM FLOPs the kernels "
+                   "really compute (the fp32 Winograd layers issue 4x / 2.25x fewer; under the split arithmetic each is six bf16 MFMA "
+                   "terms, the fractions stay quoted against the fp32 MFMA peak; the first layer's direct-operand kernel is "
                    "HBM-bound and not counted as issued MFMA work); 'whole_forward' divides by the wall time of the forward "
                    "incl. its HBM-bound passes, 'in_mfma_kernels' by the GEMM kernels' own HIP-event time on one stream")
     del net

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int m0 = p.m_base + mt * BM, n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-  const int kq = tid & 7, r0 = tid >> 3;
+  const int kq = tid & 7, g8 = tid >> 3;
+  // SPLIT: a 32-lane half of a wave (what one ds_write_b64 cycle serves) stages rows {b, b+4, b+8, b+12} instead of four
+  // consecutive ones: with the 80-byte plane rows their 64-byte pieces tile the 256-byte bank row exactly (offsets 0, 64, 128,
+  // 192), where consecutive rows (0, 80, 160, 240) wrap onto each other -- PMC before: SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.32.
+  const int r0 = SPLIT ? ((g8 & ~15) | ((g8 >> 2) & 3) | ((g8 & 3) << 2)) : g8;
   // GLDS: the DMA writes LDS linearly (wave base + lane*16 B); bank conflicts are avoided by
   // permuting which 16-B k-group each lane FETCHES (same 128-B line) and un-permuting on the read.
   // The XOR mask is (row >> 1) & 7: a 16-lane service group of the ds_read_b128 fragment reads covers rows
