@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
@@ -38,6 +39,8 @@ __device__ float g_zero_page[64];   // zero-initialised, never written: source o
 // fp32 product.  Measured against a double-precision sum (tools/probes/split_gemm_probe.hip, profiles/r03_split_probe.txt):
 // relative L2 error 0.98e-6 at K = 4608 against 1.20e-6 for v_mfma_f32_32x32x2_f32, identical to all nine terms.
 // Six bf16 MFMAs cost 6/16 of the fp32 MFMAs they replace (2.48 PFLOP/s against 138 TFLOP/s measured issue rate).
+// (Non-finite inputs: an infinite operand element gives NaN here -- inf - bf16(inf) -- where the fp32 instruction gives
+// +-inf or NaN depending on its partner; finite fp32 values above bfloat16's largest, 3.3895e38, round to inf the same way.)
 constexpr int kLdH = 40;     // SPLIT: padded LDS row stride of one plane (bf16 elements; 80 bytes: ds_read_b128 conflict-free)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool NCHW_OUT, int STAGES, bool FASTK, bool GLDS, bool SPLIT = false>
@@ -498,21 +501,24 @@ inline char batched_pick(long long rows, int cin, int cout) {
 }
 
 // -1: not decided yet (first use reads FSD_F32_SPLIT; default 1 = split arithmetic, FSD_F32_SPLIT=0 = native fp32 MFMA)
-int g_f32_split = -1;
+std::atomic<int> g_f32_split{-1};
 
 }  // namespace
 
 bool fsd_conv::f32_split_on() {
-  if (g_f32_split < 0) {
+  int v = g_f32_split.load(std::memory_order_relaxed);
+  if (v < 0) {
     const char* env = getenv("FSD_F32_SPLIT");
-    g_f32_split = (env && env[0] == '0') ? 0 : 1;
+    v = (env && env[0] == '0') ? 0 : 1;
+    int expected = -1;
+    if (!g_f32_split.compare_exchange_strong(expected, v)) v = expected;      // somebody set the mode meanwhile: theirs wins
   }
-  return g_f32_split == 1;
+  return v == 1;
 }
 
 extern "C" int fsd_f32_gemm_mode(int mode) {
   const int prev = fsd_conv::f32_split_on() ? 1 : 0;
-  if (mode == 0 || mode == 1) g_f32_split = mode;
+  if (mode == 0 || mode == 1) g_f32_split.store(mode);
   return prev;
 }
 
