@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "forward"], default=None)
     ap.add_argument("--neg", default="1", help="cfg.neg_ratio ('full' or a number; metayolo.data uses 1)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="conv compute mode of the HEADLINE: f32 = exact fp32 MFMA (BASELINE C2, default); bf16 = bf16 operands, "
+                    help="conv compute mode of the HEADLINE: f32 = fp32 storage / results / accumulation (BASELINE C2, default; GEMM arithmetic: --f32-gemm); bf16 = bf16 operands, "
                          "fp32 accumulate, fp32 BN/loss/master weights (BASELINE C3/C5).  The default f32 line also carries the "
                          "bf16 train step under also_measured.bf16_mode")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",

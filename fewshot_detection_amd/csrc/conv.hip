@@ -60,14 +60,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   constexpr int STAGE = SPLIT ? 3 * PLANE / 2 : (BM + BN) * LD;     // floats
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  if (gridDim.y > 1) {      // batched GEMMs: every batch has its own operand / result matrices
-    p.x += (long long)blockIdx.y * p.x_bs;
-    p.w = static_cast<const float*>(p.w) + (long long)blockIdx.y * p.w_bs;
-    p.y += (long long)blockIdx.y * p.y_bs;
+  // XCD-aware order.  Per batch (default): XCD c takes the c-th eighth of every batch's tiles.  Flat (p.flat_xcd, the split
+  // arithmetic's batched launches): XCD c takes the c-th eighth of the flat (batch, tile) space and walks it batch by batch,
+  // so the tiles of one position share ONE L2 -- with the per-batch order every XCD re-fetches each position's whole U panel
+  // (the n-tile index runs fastest).  On the native fp32 MFMA kernel the two orders measured the same (+-2 %, round 2); with a
+  // third of the matrix time per tile the operand traffic shows.
+  int batch = blockIdx.y, L;
+  if (p.flat_xcd && gridDim.y > 1) {
+    const int Lf = xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    batch = Lf / (int)gridDim.x;
+    L = Lf - batch * (int)gridDim.x;
+  } else {
+    L = xcd_swizzle(blockIdx.x, gridDim.x);
   }
-  // (An XCD remap over the flat (batch, tile) id -- each XCD walking whole positions, so that its resident workgroups
-  // share one position's V and U panels -- measured the same time as this per-batch remap on every layer, +-2 %.)
-  const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (gridDim.y > 1) {      // batched GEMMs: every batch has its own operand / result matrices
+    p.x += (long long)batch * p.x_bs;
+    p.w = static_cast<const float*>(p.w) + (long long)batch * p.w_bs;
+    p.y += (long long)batch * p.y_bs;
+  }
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
   const int m0 = p.m_base + mt * BM, n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -557,6 +567,8 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.slope = 1.f;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
   a.wide = wide_ok(y, y_ld, cout) && y_bs % 4 == 0;
+  static const char* flat_env = getenv("FSD_CONV_FLAT_XCD");        // tuning aid: 0 / 1 force the order
+  a.flat_xcd = flat_env ? (flat_env[0] == '1') : (fsd_conv::f32_split_on() ? 1 : 0);
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
   if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages
@@ -630,6 +642,7 @@ extern "C" int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w
   a.batches = 1;
   a.slope = slope;
   a.wide = !out_nchw && wide_ok(y, y_ld, cout);
+  a.flat_xcd = 0;
   a.x_bs = a.w_bs = a.y_bs = 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;

@@ -31,6 +31,7 @@ struct ConvArgs {
   int batches;
   float slope;   // leaky slope applied to (acc + bias) in the NHWC epilogue; 1 = linear (fsd_conv2d_fwd_act)
   int wide;      // NHWC epilogue through LDS with float4 stores (needs y 16-byte aligned, y_ld % 4 == 0, Cout % 4 == 0)
+  int flat_xcd;  // batched launches: XCD-aware order over the flat (batch, tile) space instead of per batch (conv.hip)
 };
 
 // fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)

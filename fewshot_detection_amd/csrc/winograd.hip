@@ -597,39 +597,75 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   }
 }
 
-// U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.
-__global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin, int mode,
-                                    int rows, int red, int rows_pad) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)rows_pad * red) return;
-  const int row = (int)(idx / red), k = (int)(idx - (long long)row * red);
-  float gk[3][3];
+// U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
+// rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
+// row -> for each of the 36 positions the workgroup writes RB runs of KB * 4 bytes (512 for KB = 128).  (Rounds 1-2: one
+// element per thread -- 4-byte pieces into 36 position planes and, in mode 1, taps gathered at a 36 * Cin byte stride; PMC:
+// 82 % of the wave time in s_waitcnt, 2 TB/s.)  The taps of the block are staged through LDS as they lie in the weight
+// (mode 0: a row's KB x 9 floats are contiguous; mode 1: 9 x RB floats per k).
+template <int KB>
+__global__ __launch_bounds__(256) void wino4_weight_wide_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
+                                                                int cin, int mode, int rows, int red, int rows_pad) {
+  constexpr int LPR = KB / 4;                 // lanes per row
+  constexpr int RB = 256 / LPR;               // rows per workgroup
+  constexpr int LDK = KB + 4;                 // padded k extent of the LDS image [row][tap][k]
+  __shared__ float s_w[RB][9][LDK];
+  const int row0 = blockIdx.y * RB, k0 = blockIdx.x * KB;
+  const int t = threadIdx.x;
+  // all loads of a thread are issued before the first LDS store (a rolled loop would wait for each load in turn: 36 round
+  // trips to HBM per workgroup)
+  constexpr int PER_T = RB * KB * 9 / 256;          // 36
+  float v[PER_T];
+  if (mode == 0) {
+    // row = co, k = ci: w[(row * cin + k) * 9 + tap], KB * 9 contiguous floats per row
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float v = 0.f;
-      if (row < rows) {
-        v = mode == 0 ? w[(((long long)row * cin + k) * 3 + a) * 3 + b]
-                      : w[(((long long)k * cin + row) * 3 + (2 - a)) * 3 + (2 - b)];
-      }
-      gk[a][b] = v;
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = t + i * 256;
+      const int r = e / (KB * 9), c = e - r * (KB * 9);
+      v[i] = row0 + r < rows ? w[((long long)(row0 + r) * cin + k0) * 9 + c] : 0.f;
     }
-  float t[6][3];
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = t + i * 256;
+      const int r = e / (KB * 9), c = e - r * (KB * 9);
+      const int k = c / 9, tap = c - k * 9;
+      s_w[r][tap][k] = v[i];
+    }
+  } else {
+    // row = ci, k = co, rotated filter: w[((k * cin) + row) * 9 + (8 - tap)], RB * 9 contiguous floats per k
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = t + i * 256;
+      const int k = e / (RB * 9), c = e - k * (RB * 9);
+      const int r = c / 9;
+      v[i] = row0 + r < rows ? w[((long long)(k0 + k) * cin + row0) * 9 + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = t + i * 256;
+      const int k = e / (RB * 9), c = e - k * (RB * 9);
+      const int r = c / 9, tap = c - r * 9;
+      s_w[r][8 - tap][k] = v[i];
+    }
+  }
+  __syncthreads();
+  const int row_l = t / LPR, k4 = (t % LPR) * 4;
+  f32x4 tt[6][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    float r[6];
-    g6(gk[0][b], gk[1][b], gk[2][b], r);
+    f32x4 r[6];
+    g6(ld4(&s_w[row_l][0 * 3 + b][k4]), ld4(&s_w[row_l][1 * 3 + b][k4]), ld4(&s_w[row_l][2 * 3 + b][k4]), r);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) t[a][b] = r[a];
+    for (int a = 0; a < 6; ++a) tt[a][b] = r[a];
   }
+  float* dst = U + (long long)(row0 + row_l) * red + k0 + k4;
   const long long ps = (long long)rows_pad * red;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
-    float r[6];
-    g6(t[a][0], t[a][1], t[a][2], r);
+    f32x4 r[6];
+    g6(tt[a][0], tt[a][1], tt[a][2], r);
 #pragma unroll
-    for (int b = 0; b < 6; ++b) U[(a * 6 + b) * ps + idx] = r[b];
+    for (int b = 0; b < 6; ++b) st4(dst + (a * 6 + b) * ps, r[b]);
   }
 }
 
@@ -708,9 +744,12 @@ extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int co
   if (tile == 2)
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
                        cout, cin, mode, rows, red, rows_pad);
-  else
-    hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
-                       cout, cin, mode, rows, red, rows_pad);
+  else if (red % 128 == 0)                 // rows_pad is a multiple of 128: whole blocks of 8 rows
+    hipLaunchKernelGGL(wino4_weight_wide_kernel<128>, dim3(red / 128, rows_pad / 8), dim3(256), 0, stream, w_oihw, u_packed, cout,
+                       cin, mode, rows, red, rows_pad);
+  else                                     // red % 32 == 0 (checked above)
+    hipLaunchKernelGGL(wino4_weight_wide_kernel<32>, dim3(red / 32, rows_pad / 32), dim3(256), 0, stream, w_oihw, u_packed, cout,
+                       cin, mode, rows, red, rows_pad);
   return (int)hipGetLastError();
 }
 

@@ -324,7 +324,8 @@ class Darknet(nn.Module):
         self._graphs = {}
 
     def set_compute_dtype(self, dtype):
-        """"f32" (default, exact fp32 MFMA) or "bf16" (conv operands in bf16, fp32 accumulate: BASELINE C3/C5)."""
+        """"f32" (default: fp32 storage and results; GEMM arithmetic per ops.f32_gemm_mode) or "bf16" (conv operands in bf16, fp32
+        accumulate: BASELINE C3/C5)."""
         if dtype not in ("f32", "bf16"):
             raise ValueError("compute dtype must be 'f32' or 'bf16'")
         self._det.compute_dtype = self._meta.compute_dtype = dtype

@@ -93,7 +93,8 @@ class Network(object):
         self.layers = blocks[1:]
         self.cache = _WeightCache()
         self._folded = {}             # id(conv.weight) -> (tag, folded weight, folded bias): eval-mode BatchNorm folds
-        # "f32": exact fp32 MFMA, fp32 activations.  "bf16" (BASELINE configs[2] / [4]): activations and their gradients are
+        # "f32": fp32 activations and results (GEMMs: fp32-accurate split arithmetic or the native fp32 MFMA,
+        # ops.f32_gemm_mode).  "bf16" (BASELINE configs[2] / [4]): activations and their gradients are
         # STORED in HBM as bfloat16, convolutions run bf16 x bf16 -> fp32 on the bf16 matrix cores, BatchNorm statistics come
         # from the fp32 accumulators; loss, parameter gradients, master weights and the optimizer stay fp32.
         self.compute_dtype = "f32"
