@@ -77,6 +77,27 @@ def test_split_is_as_accurate_as_the_native_fp32_mfma(dev, shape):
     assert not torch.equal(outs["native"][0], outs["split"][0])
 
 
+@pytest.mark.parametrize("scale_x,scale_w", [(1e-18, 1e18), (1e15, 1e-3), (1e-30, 1.0), (3e4, 3e4)])
+def test_split_keeps_fp32_range(dev, scale_x, scale_w):
+    """bfloat16 has fp32's exponent range: operands far from 1 (tiny gradients, large activations, products near the ends of
+    the fp32 range) go through the three-way split with the same relative accuracy, no overflow, no flush to zero."""
+    from fewshot_detection_amd import ops
+    B, H, W, cin, cout = 2, 13, 13, 256, 128
+    torch.manual_seed(5)
+    xn = torch.randn(B, cin, H, W, device=dev) * scale_x
+    w = torch.randn(cout, cin, 1, 1, device=dev) * scale_w / cin ** 0.5
+    ref = F.conv2d(xn.double(), w.double())
+    x = ops.nchw_to_nhwc(xn)
+    errs = {}
+    for mode in ("native", "split"):
+        ops.f32_gemm_mode(mode)
+        y, _ = ops.conv2d(x, ops.pack_weight(w), cout, 1)
+        y = ops.nhwc_to_nchw(y)
+        assert torch.isfinite(y).all()
+        errs[mode] = _rel(y, ref)
+    assert errs["split"] < 2e-6 and errs["split"] <= 1.25 * errs["native"] + 1e-7, errs
+
+
 def test_mode_switch_reports_the_previous_mode(dev):
     from fewshot_detection_amd import ops
     first = ops.f32_gemm_mode()
