@@ -1,5 +1,7 @@
-// Convolution (3x3 / 1x1, stride 1, "same" padding) as an im2col-free implicit GEMM on the
-// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s chip peak).
+// Convolution (3x3 / 1x1, stride 1, "same" padding) as an im2col-free implicit GEMM on the gfx950 matrix cores, fp32 in and
+// out.  Two arithmetics (fsd_f32_gemm_mode): "split" (default) -- fp32 operands split in the staging registers into three
+// bfloat16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 accumulate (SPLIT below) -- and the native fp32
+// matrix instruction (v_mfma_f32_32x32x2_f32, 157 TFLOP/s chip peak), which the rest of this header describes.
 //
 //   M = B*H*W output pixels, N = Cout, K = taps * Cin.   Activations are NHWC, weights are
 //   pre-packed [Cout][tap][Cin] ("K-major" on both sides), so every 16-byte global load is a
