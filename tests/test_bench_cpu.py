@@ -68,3 +68,27 @@ def test_bench_quotes_the_newest_committed_traffic_summary():
     assert data is not None and "r03" in src, src
     assert data["episode"] == "metric_string" and 5e8 < data["hbm_bytes_per_launch"] < 2e9
     assert bench.newest_profile("no_such_summary.json") == (None, None)
+
+
+def test_roofline_block_quotes_the_fp32_peak_and_names_the_arithmetic():
+    """dtype f32: `peak` / `frac` stay the dense fp32 MFMA figures the contract asks for, whatever instruction runs; under the
+    split arithmetic the block also carries the same achieved figure against the bf16 instruction's ceiling."""
+    import bench
+    from fewshot_detection_amd.ops import PROFILE_CLASSES
+    kp = {c: dict(ms=0.0, work=0.0, launches=0) for c in PROFILE_CLASSES}
+    kp["gemm_fwd"] = dict(ms=10.0, work=1.3e12, launches=56)          # 130 TFLOP/s of fp32 GEMM work
+    kp["gemm_wgrad"] = dict(ms=5.0, work=0.6e12, launches=28)
+    kp["wino_transform"] = dict(ms=5.0, work=25e9, launches=100)
+    r = dict(kp=kp, prof=[], prof_steps=1)
+    for mode in ("split", "native"):
+        roof = bench.roofline_block(r, "f32", 28.0, mode)
+        assert roof["bound"] == "mfma" and roof["peak"] == bench.PEAK_FP32_MFMA_TFLOPS
+        assert abs(roof["achieved"] - 130.0) < 1e-6 and abs(roof["frac"] - 130.0 / 157.3) < 1e-9
+        ar = roof["f32_gemm_arithmetic"]
+        assert ar["mode"] == mode
+        if mode == "split":
+            assert abs(ar["issued_bf16_tflops"] - 780.0) < 1e-6
+            assert abs(ar["frac_of_fp32_equivalent_peak"] - 130.0 / (2500.0 / 6.0)) < 1e-9
+        else:
+            assert "issued_bf16_tflops" not in ar
+        assert roof["hbm"]["unit"] == "GB/s" and abs(roof["hbm"]["achieved"] - 5000.0) < 1e-6
