@@ -98,8 +98,14 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
             return
         if gz is None:                       # only the un-pooled tap carries gradient
             gz, gzf, pool = gzf, None, 0
+        kept = rec.get("wino_v")
+        wino4 = bool(kept) and rec.get("wino_tile") == 4 and yv.C % 4 == 0
+        # fp32 BatchNorm layers: dt is not materialised -- the first pass takes the statistics, the second one re-forms it
+        defer = (ops.DEFER_DT and bn is not None and not yv.bf16 and pool in (0, 1)
+                 and not (xv is first_input and ops.c4_bnfused_eligible(xv, cout, k))
+                 and not (ops.FUSE_WINO_GRAD and wino4))
         dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, rec.get("scale"), rec.get("shift"), rec.get("mean"),
-                                          rec.get("invstd"), rec["slope"], pool)
+                                          rec.get("invstd"), rec["slope"], pool, want_dt=not defer)
         s1, s2, coef = ops.reduce_partials(partial, yv.pixels, cout, scale=rec.get("scale"), want_coef=bn is not None,
                                            param0=bn.bias if bn is not None else conv.bias,
                                            param1=bn.weight if bn is not None else None)
@@ -125,7 +131,13 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
                 dx, _ = ops.conv3x3_wino(dt, net.cache.get(conv.weight, 1, "wino4"), xv.C, tile=4, v_in=vd)
                 _accumulate(grads, xv, dx)
                 return
-            if kept and rec.get("wino_tile") == 4 and dt.C % 4 == 0:
+            if defer and wino4:
+                dt, wt_in = ops.wino_dy_bn_transform_g(gz, gzf, yv, rec["scale"], rec["shift"], rec["slope"], pool, coef,
+                                                       rec["mean"], rec["invstd"])
+            elif defer:
+                dt = ops.bn_bwd_apply_g(gz, gzf, yv, rec["scale"], rec["shift"], rec["slope"], pool, coef, rec["mean"],
+                                        rec["invstd"])
+            elif kept and rec.get("wino_tile") == 4 and dt.C % 4 == 0:
                 # Winograd(4) layer: the BN backward rides on the weight-gradient transform (dt -> dy in place)
                 wt_in = ops.wino_dy_bn_transform(dt, yv, coef, rec["mean"], rec["invstd"])
             else:

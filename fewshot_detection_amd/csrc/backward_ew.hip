@@ -34,7 +34,7 @@ struct ActBwdArgsT {
   const float* shift;
   const float* mean;      // BN batch statistics (nullable when no BN)
   const float* invstd;
-  T* dt;                  // out: grad wrt the BN output / pre-activation, dense (pixels, C)
+  T* dt;                  // out: grad wrt the BN output / pre-activation, dense (pixels, C); null = statistics only
   float* partial;         // out: [blocks_x][C][2]  (sum dt, sum dt*xhat)
   long long dz_ld, dzf_ld, y_ld;
   int H, W, OH, OW, C, pool;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgsT<T> p) {
         s1[k] += d[k];
         s2[k] += d[k] * ((yv[k] - mu[k]) * is[k]);
       }
-      st4<T>(p.dt + pix * p.C + g * 4, d);
+      if (p.dt) st4<T>(p.dt + pix * p.C + g * 4, d);
     }
   }
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgsT<T> p) {
           s1[k] += d[k];
           s2[k] += d[k] * ((yv[q][k] - mu[k]) * is[k]);
         }
-        st4<T>(p.dt + pix * p.C + g * 4, d);
+        if (p.dt) st4<T>(p.dt + pix * p.C + g * 4, d);
       }
     }
   }
@@ -309,6 +309,89 @@ __global__ void bn_bwd_apply_kernel(T* __restrict__ dt, const T* __restrict__ y,
 #pragma unroll
   for (int k = 0; k < 4; ++k) d[k] = c1[k] * (d[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
   st4<T>(dt + pix * C + g * 4, d);
+}
+
+// The same second pass for a FIRST pass that only took the statistics (dt never written): dt is formed again from the
+// gradient of the block output -- through the 2x2 / stride-2 maxpool (first maximum in scan order, as in the first pass) and the
+// leaky activation, same expressions -- and dy = c1 * (dt - c2 - xhat * c3) is written once.  Against first pass + in-place
+// apply this drops one write and one read of a full-resolution tensor per layer (pooled layers read a quarter-size gradient
+// instead of dt).  POOL 0: one thread per pixel and 4 channels; POOL 1: one thread per 2x2 cell and 4 channels.
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const float* __restrict__ dz, long long dz_ld,
+                                                             const float* __restrict__ dz_full, long long dzf_ld,
+                                                             const float* __restrict__ y, long long y_ld,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             float slope, const float* __restrict__ coef,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ dy, int H, int W, int OH, int OW, int C,
+                                                             long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C >> 2;
+  const int g = (int)(idx % cg);
+  const long long unit = idx / cg;                       // pixel (POOL 0) or cell (POOL 1)
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc = scale ? ld4(scale + g * 4) : one, sh = shift ? ld4(shift + g * 4) : zero;
+  const f32x4 c1 = ld4(coef + g * 4), c2 = ld4(coef + C + g * 4), c3 = ld4(coef + 2 * C + g * 4);
+  const f32x4 mu = ld4(mean + g * 4), is = ld4(invstd + g * 4);
+  if constexpr (POOL == 0) {
+    const long long pix = unit;
+    const f32x4 yv = ld4(y + pix * y_ld + g * 4);
+    f32x4 gin = ld4(dz + pix * dz_ld + g * 4);
+    if (dz_full) {
+      const f32x4 gf = ld4(dz_full + pix * dzf_ld + g * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gin[k] += gf[k];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float tv = yv[k] * sc[k] + sh[k];
+      const float d = tv > 0.f ? gin[k] : gin[k] * slope;
+      o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
+    }
+    st4<float>(dy + pix * C + g * 4, o);
+  } else {
+    const int CH = (H + 1) >> 1, CW = (W + 1) >> 1;
+    const int cx = (int)(unit % CW);
+    const long long t = unit / CW;
+    const int cy = (int)(t % CH);
+    const long long b = t / CH;
+    const bool win = cy < OH && cx < OW;
+    f32x4 yv[4], tv[4];
+    bool in[4];
+    int best[4] = {0, 0, 0, 0};
+    f32x4 bv = zero;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+      in[q] = yy < H && xx < W;
+      yv[q] = in[q] ? ld4(y + ((b * H + yy) * (long long)W + xx) * y_ld + g * 4) : zero;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tv[q][k] = yv[q][k] * sc[k] + sh[k];
+        const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * slope;
+        if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
+      }
+    }
+    const f32x4 gz = win ? ld4(dz + ((b * OH + cy) * (long long)OW + cx) * dz_ld + g * 4) : zero;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!in[q]) continue;
+      const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+      const long long pix = (b * H + yy) * (long long)W + xx;
+      f32x4 gin = zero;
+      if (dz_full) gin = ld4(dz_full + pix * dzf_ld + g * 4);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (win && best[k] == q) gin[k] += gz[k];
+        const float d = tv[q][k] > 0.f ? gin[k] : gin[k] * slope;
+        o[k] = c1[k] * (d - c2[k] - (yv[q][k] - mu[k]) * is[k] * c3[k]);
+      }
+      st4<float>(dy + pix * C + g * 4, o);
+    }
+  }
 }
 
 // bf16 storage, 8 channels (16 bytes) per lane: with 4 channels a lane moves 8 bytes and a wave instruction 512 -- the bf16
@@ -461,7 +544,7 @@ int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long lo
                          int pool, T* dt, float* partial, int batch, int height, int width, int channels,
                          hipStream_t stream) {
   (void)hipGetLastError();
-  if (!dz || !y || !dt || !partial || batch < 1 || channels < 4 || (channels & 3) || (dz_ld & 3) || (y_ld & 3))
+  if (!dz || !y || !partial || batch < 1 || channels < 4 || (channels & 3) || (dz_ld & 3) || (y_ld & 3))
     return FSD_ERR_ARG;
   if (dz_full && (dz_full_ld & 3)) return FSD_ERR_ARG;
   if (pool < 0 || pool > 2) return FSD_ERR_UNSUPPORTED;
@@ -472,8 +555,8 @@ int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long lo
   a.C = channels; a.pool = pool; a.pixels = (long long)batch * height * width; a.slope = slope;
   const int cg = channels / 4;
   const int gl = cg <= 8 ? 8 : cg <= 16 ? 16 : cg <= 32 ? 32 : 64;    // channel-group lanes per block
-  // algorithmic bytes: read dz (+ dz_full) and y, write dt
-  fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * ((double)batch * a.OH * a.OW + (dz_full ? 3.0 : 2.0) * a.pixels), stream);
+  // algorithmic bytes: read dz (+ dz_full) and y, write dt (unless statistics only)
+  fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * ((double)batch * a.OH * a.OW + ((dz_full ? 2.0 : 1.0) + (dt ? 1.0 : 0.0)) * a.pixels), stream);
   if (pool == 1) {
     // window-major: a block covers cells_per_block cells = one partial row (fsd_bn_act_pool_bwd_rows)
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
@@ -606,6 +689,31 @@ extern "C" int fsd_bn_bwd_apply_h(void* dt, const void* y, long long y_ld, const
                                   const float* invstd, long long pixels, int channels, hipStream_t stream) {
   return bn_bwd_apply_impl<bf16_t>(static_cast<bf16_t*>(dt), static_cast<const bf16_t*>(y), y_ld, coef, mean, invstd, pixels,
                                    channels, stream);
+}
+
+extern "C" int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld, const float* y,
+                                 long long y_ld, const float* scale, const float* shift, float slope, int pool,
+                                 const float* coef, const float* mean, const float* invstd, float* dy, int batch, int height,
+                                 int width, int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dz || !y || !coef || !mean || !invstd || !dy || batch < 1 || height < 1 || width < 1 || channels < 4 || (channels & 3) ||
+      (dz_ld & 3) || (y_ld & 3) || (dz_full && (dz_full_ld & 3)))
+    return FSD_ERR_ARG;
+  if (pool != 0 && pool != 1) return FSD_ERR_UNSUPPORTED;
+  const int OH = pool ? height / 2 : height, OW = pool ? width / 2 : width;
+  const long long pixels = (long long)batch * height * width;
+  // algorithmic bytes: read dz (+ dz_full) and y, write dy
+  fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * ((double)batch * OH * OW + (dz_full ? 3.0 : 2.0) * pixels), stream);
+  if (pool == 0) {
+    const long long total = pixels * (channels / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
+                       dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
+  } else {
+    const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
+                       dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
+  }
+  return (int)hipGetLastError();
 }
 
 extern "C" int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,

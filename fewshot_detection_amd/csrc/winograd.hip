@@ -379,15 +379,28 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 }
 
 // dy (4x4 tile) -> G4 dy G4^T  (36 positions)
-// BN = true: `dy` holds dt (gradient w.r.t. the BatchNorm output); the BatchNorm backward c1*(dt - c2 - xhat*c3) is
+// BN = 1: `dy` holds dt (gradient w.r.t. the BatchNorm output); the BatchNorm backward c1*(dt - c2 - xhat*c3) is
 // applied on the way in and written back IN PLACE (tiles do not overlap), so fsd_bn_bwd_apply's separate pass -- and
 // one read of its result -- disappear; the data-gradient transform then reads the finished dy as usual.
-template <bool BN>
+// BN = 2: the first backward pass only took the statistics (dt never written): dt is formed here from the gradient of the
+// block output `gg.dz` (+ `gg.dz_full`) through the 2x2 / stride-2 maxpool (gg.pool == 1; a 4x4 tile is 2x2 whole pooling
+// cells) and the leaky activation -- the expressions of act_bwd_pool2_kernel / act_bwd_kernel -- and dy is WRITTEN to `dy`.
+struct DyFromG {
+  const float* dz;          // gradient of the (pooled) block output (B, OH, OW, C)
+  const float* dz_full;     // optional gradient of the un-pooled activation
+  const float* scale;       // BatchNorm affine
+  const float* shift;
+  long long dz_ld, dzf_ld;
+  float slope;
+  int pool, OH, OW;
+};
+
+template <int BN>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
                                                       int H, int W, int TH, int TW, int C, long long T,
                                                       const float* __restrict__ y, long long y_ld,
                                                       const float* __restrict__ coef, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd) {
+                                                      const float* __restrict__ invstd, DyFromG gg) {
   const int cg = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
@@ -401,11 +414,60 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
   const long long b = ut2 / (unsigned)TH;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 c1 = zero, c2 = zero, c3 = zero, mu = zero, is = zero;
-  if constexpr (BN) {
+  if constexpr (BN != 0) {
     c1 = ld4(coef + g * 4); c2 = ld4(coef + C + g * 4); c3 = ld4(coef + 2 * C + g * 4);
     mu = ld4(mean + g * 4); is = ld4(invstd + g * 4);
   }
   f32x4 q[4][4];
+  if constexpr (BN == 2) {
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+    const f32x4 sc = gg.scale ? ld4(gg.scale + g * 4) : one, sh = gg.shift ? ld4(gg.shift + g * 4) : zero;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int cj = 0; cj < 2; ++cj) {
+        const int cy = 2 * ty + ci, cx = 2 * tx + cj;            // pooling cell of the image
+        f32x4 yv[4], tv[4];
+        bool in[4];
+        int best[4] = {0, 0, 0, 0};
+        f32x4 bv = zero;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int oy = 2 * cy + (w >> 1), ox = 2 * cx + (w & 1);
+          in[w] = oy < H && ox < W;
+          yv[w] = in[w] ? ld4(y + ((b * H + oy) * (long long)W + ox) * y_ld + g * 4) : zero;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            tv[w][k] = yv[w][k] * sc[k] + sh[k];
+            const float a = tv[w][k] > 0.f ? tv[w][k] : tv[w][k] * gg.slope;
+            if (w == 0 || a > bv[k]) { bv[k] = a; best[k] = w; }
+          }
+        }
+        const bool win = gg.pool == 1 && cy < gg.OH && cx < gg.OW;
+        const f32x4 gz = win ? ld4(gg.dz + ((b * gg.OH + cy) * (long long)gg.OW + cx) * gg.dz_ld + g * 4) : zero;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int i = 2 * ci + (w >> 1), j = 2 * cj + (w & 1);
+          if (!in[w]) { q[i][j] = zero; continue; }
+          const long long pix = (b * H + (4 * ty + i)) * (long long)W + 4 * tx + j;
+          f32x4 gin = gg.pool == 0 ? ld4(gg.dz + pix * gg.dz_ld + g * 4) : zero;
+          if (gg.dz_full) {
+            const f32x4 gf = ld4(gg.dz_full + pix * gg.dzf_ld + g * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gin[k] += gf[k];
+          }
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (win && best[k] == w) gin[k] += gz[k];
+            const float d = tv[w][k] > 0.f ? gin[k] : gin[k] * gg.slope;
+            v[k] = c1[k] * (d - c2[k] - (yv[w][k] - mu[k]) * is[k] * c3[k]);
+          }
+          st4(dy + pix * dy_ld + g * 4, v);
+          q[i][j] = v;
+        }
+      }
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -414,7 +476,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
       if (oy < H && ox < W) {
         const long long pix = (b * H + oy) * (long long)W + ox;
         f32x4 v = ld4(dy + pix * dy_ld + g * 4);
-        if constexpr (BN) {
+        if constexpr (BN == 1) {
           const f32x4 yv = ld4(y + pix * y_ld + g * 4);
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = c1[k] * (v[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);   // == bn_bwd_apply
@@ -425,6 +487,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
         q[i][j] = zero;
       }
     }
+  }
   f32x4 t[6][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -891,9 +954,9 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
       hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
                          height, width, TH, TW, cout, T);
     else
-      hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
+      hipLaunchKernelGGL(wino4_dy_kernel<0>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
                          const_cast<float*>(dy), dy_ld, Wt, height, width, TH, TW, cout, T, (const float*)nullptr, 0LL,
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, DyFromG{});
     Wg = Wt;
   }
   int splits = 0;
@@ -935,7 +998,31 @@ extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float*
   const long long n = T * (channels / 4);
   // reads dt and y, writes dy (in place) and the 36 transformed positions
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (3.0 * batch * height * width + 36.0 * T), stream);
-  hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
-                     height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd);
+  hipLaunchKernelGGL(wino4_dy_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
+                     height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, DyFromG{});
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_wino_dy_bn_transform_g(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld,
+                                          const float* y, long long y_ld, const float* scale, const float* shift, float slope,
+                                          int pool, const float* coef, const float* mean, const float* invstd, float* dy,
+                                          float* wt_out, int batch, int height, int width, int channels, int tile,
+                                          hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dz || !y || !coef || !mean || !invstd || !dy || !wt_out || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (tile != 4 || (channels & 3) || (dz_ld & 3) || (y_ld & 3) || y_ld < channels || (dz_full && (dz_full_ld & 3)))
+    return FSD_ERR_UNSUPPORTED;
+  if (pool != 0 && pool != 1) return FSD_ERR_UNSUPPORTED;
+  const int TH = (height + 3) / 4, TW = (width + 3) / 4;
+  const long long T = tiles_of(batch, height, width, 4);
+  if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
+  DyFromG gg;
+  gg.dz = dz; gg.dz_full = dz_full; gg.scale = scale; gg.shift = shift; gg.dz_ld = dz_ld; gg.dzf_ld = dz_full_ld;
+  gg.slope = slope; gg.pool = pool; gg.OH = pool ? height / 2 : height; gg.OW = pool ? width / 2 : width;
+  const long long n = T * (channels / 4);
+  // reads dz (+ dz_full) and y, writes dy and the 36 transformed positions
+  fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * ((double)batch * gg.OH * gg.OW + (dz_full ? 3.0 : 2.0) * batch * height * width + 36.0 * T), stream);
+  hipLaunchKernelGGL(wino4_dy_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
+                     wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);
   return (int)hipGetLastError();
 }

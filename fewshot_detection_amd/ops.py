@@ -548,11 +548,18 @@ def first_layer_bwd(dz, yv, scale, shift, mean, invstd, slope, xv, cin, cout, bn
     return dw, dbeta, dgamma
 
 
-def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
-    """-> (dt View dense (pixels, C), partial [rows][C][2])."""
+# fp32 BatchNorm layers: the first backward pass only takes the statistics, the second one re-forms dt from the block-output
+# gradient (bn_bwd_apply_g / wino_dy_bn_transform_g) -- dt is never written or read back.  FSD_DEFER_DT=0: the two-pass form.
+DEFER_DT = os.environ.get("FSD_DEFER_DT", "1") != "0"
+
+
+def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool, want_dt=True):
+    """-> (dt View dense (pixels, C), partial [rows][C][2]).  want_dt=False (fp32): statistics only, dt is None."""
     L = lib()
     dev = yv.t.device
-    dt = like_view(yv)
+    if not want_dt and yv.bf16:
+        raise ValueError("the statistics-only first pass exists for fp32 storage")
+    dt = like_view(yv) if want_dt else None
     partial = torch.empty((L.fsd_bn_act_pool_bwd_rows(yv.B, yv.H, yv.W, pool), yv.C, 2), dtype=torch.float32,
                           device=dev)
     if dz.bf16 != yv.bf16 or (dz_full is not None and dz_full.bf16 != yv.bf16):
@@ -560,9 +567,32 @@ def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool):
     fn = L.fsd_bn_act_pool_bwd_h if yv.bf16 else L.fsd_bn_act_pool_bwd
     check(fn(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
              0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift),
-             _ptr(mean), _ptr(invstd), slope, pool, dt.ptr, partial.data_ptr(), yv.B, yv.H, yv.W,
+             _ptr(mean), _ptr(invstd), slope, pool, dt.ptr if want_dt else 0, partial.data_ptr(), yv.B, yv.H, yv.W,
              yv.C, _stream()), "fsd_bn_act_pool_bwd")
     return dt, partial
+
+
+def bn_bwd_apply_g(dz, dz_full, yv, scale, shift, slope, pool, coef, mean, invstd):
+    """Second pass after bn_act_pool_bwd(want_dt=False): -> dy View dense (pixels, C); bit-identical to
+    bn_bwd_apply(bn_act_pool_bwd(...)[0], ...)."""
+    dy = like_view(yv)
+    check(lib().fsd_bn_bwd_apply_g(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr, 0 if dz_full is None else dz_full.ld,
+                                   yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, coef.data_ptr(), mean.data_ptr(),
+                                   invstd.data_ptr(), dy.ptr, yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_bwd_apply_g")
+    return dy
+
+
+def wino_dy_bn_transform_g(dz, dz_full, yv, scale, shift, slope, pool, coef, mean, invstd):
+    """Second pass after bn_act_pool_bwd(want_dt=False) of a Winograd(tile 4) layer: -> (dy View, Wt); bit-identical to
+    wino_dy_bn_transform on the dt of the two-pass form."""
+    L = lib()
+    dy = like_view(yv)
+    wt = torch.empty(L.fsd_wino_v_elems(yv.B, yv.H, yv.W, yv.C, 4), dtype=torch.float32, device=yv.t.device)
+    check(L.fsd_wino_dy_bn_transform_g(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr,
+                                       0 if dz_full is None else dz_full.ld, yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope,
+                                       pool, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dy.ptr, wt.data_ptr(),
+                                       yv.B, yv.H, yv.W, yv.C, 4, _stream()), "fsd_wino_dy_bn_transform_g")
+    return dy, wt
 
 
 def reduce_partials(partial, count, channels, scale=None, want_coef=False, param0=None, param1=None):

@@ -219,6 +219,13 @@ int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, lon
 int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float* y, long long y_ld, const float* coef,
                              const float* mean, const float* invstd, float* wt_out, int batch, int height, int width,
                              int channels, int tile, hipStream_t stream);
+/* The same after a statistics-only first pass (fsd_bn_act_pool_bwd with dt == NULL): dt is re-formed from dz (+ dz_full)
+ * through the maxpool (pool 0 / 1) and the leaky activation, dy (dense (pixels, channels)) and wt_out are written.
+ * Bit-identical to fsd_bn_act_pool_bwd + fsd_wino_dy_bn_transform. */
+int fsd_wino_dy_bn_transform_g(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld, const float* y,
+                               long long y_ld, const float* scale, const float* shift, float slope, int pool,
+                               const float* coef, const float* mean, const float* invstd, float* dy, float* wt_out,
+                               int batch, int height, int width, int channels, int tile, hipStream_t stream);
 
 /* Backward of a BatchNorm + Winograd(tile 4) layer in one pass over the gradient: forms dy = c1*(dt - c2 - xhat*c3)
  * (what fsd_bn_bwd_apply computes; coef from fsd_bn_bwd_finalize) in registers and writes both transformed operands the
@@ -301,7 +308,10 @@ int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long
 /* Gradient through pool(act(y*scale+shift)): dt = d loss / d (y*scale+shift), dense (pixels, C),
  * plus per-block partial sums [fsd_bn_act_pool_bwd_rows(...)][C][2] of (dt, dt*xhat) for the BatchNorm
  * backward.  dz: grad of the block output (pooled grid if pool != 0); dz_full: optional grad of the
- * un-pooled activation.  The max-pool argmax is recomputed from y (first maximum in scan order). */
+ * un-pooled activation.  The max-pool argmax is recomputed from y (first maximum in scan order).
+ * dt == NULL (fp32 entry): statistics only -- the partial sums are produced, dt is not written; the second pass then forms
+ * dt again itself (fsd_bn_bwd_apply_g / fsd_wino_dy_bn_transform_g), which saves one write and one read of a full-resolution
+ * tensor per layer. */
 int fsd_act_bwd_rows(long long pixels);
 int fsd_bn_act_pool_bwd_rows(int batch, int height, int width, int pool);   /* rows of `partial` below */
 size_t fsd_reduce_workspace_bytes(int channels);
@@ -316,6 +326,13 @@ int fsd_bn_bwd_finalize(const float* partial, int rows, long long count, int cha
 /* In place: dt <- dy = scale * (dt - mean(dt) - xhat * mean(dt*xhat))  (training-mode BatchNorm). */
 int fsd_bn_bwd_apply(float* dt, const float* y, long long y_ld, const float* coef, const float* mean,
                      const float* invstd, long long pixels, int channels, hipStream_t stream);
+/* The second pass after a statistics-only first pass: dy (dense (pixels, C), written once) = scale * (dt - mean(dt) - xhat *
+ * mean(dt*xhat)) with dt re-formed from dz (+ dz_full) through the 2x2 / stride-2 maxpool (pool == 1; pool == 0: none) and the
+ * leaky activation exactly as fsd_bn_act_pool_bwd forms it.  Bit-identical to fsd_bn_act_pool_bwd + fsd_bn_bwd_apply. */
+int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float* dz_full, long long dz_full_ld, const float* y,
+                       long long y_ld, const float* scale, const float* shift, float slope, int pool, const float* coef,
+                       const float* mean, const float* invstd, float* dy, int batch, int height, int width, int channels,
+                       hipStream_t stream);
 /* Column sums of a (rows, ld) matrix as partials [fsd_act_bwd_rows(rows)][C][2] (any C). */
 int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
                         hipStream_t stream);

@@ -174,6 +174,36 @@ def test_conv_bn_leaky_pool_block_backward(dev, pool, B, H, W, cin, cout):
     assert torch.allclose(ops.nhwc_to_nchw(dx).cpu(), x.grad.float(), **tol)
 
 
+@pytest.mark.parametrize("pool,full,B,H,W,C", [(0, False, 2, 13, 13, 1024), (1, False, 3, 104, 104, 128), (1, True, 2, 26, 26, 512),
+                                               (0, True, 2, 26, 26, 64), (1, False, 2, 13, 13, 32), (1, False, 1, 7, 9, 16)])
+def test_statistics_only_first_pass_and_recomputing_second_pass_are_bit_identical(dev, pool, full, B, H, W, C):
+    """fp32 BatchNorm backward without a materialised dt (ops.DEFER_DT): bn_act_pool_bwd(want_dt=False) returns the same
+    partial sums, and bn_bwd_apply_g / wino_dy_bn_transform_g write the same dy (and Winograd operand) as the two-pass form,
+    bit for bit -- with and without the 2x2 / stride-2 pool (odd sizes: border cells without a pooling window), with and
+    without a gradient on the un-pooled tap."""
+    from fewshot_detection_amd import ops
+    torch.manual_seed(pool * 7 + C)
+    yv = ops.nchw_to_nhwc(torch.randn(B, C, H, W, device=dev))
+    OH, OW = (H // 2, W // 2) if pool else (H, W)
+    gz = ops.nchw_to_nhwc(torch.randn(B, C, OH, OW, device=dev))
+    gzf = ops.nchw_to_nhwc(torch.randn(B, C, H, W, device=dev)) if full else None
+    scale = torch.rand(C, device=dev) + 0.5
+    shift = torch.randn(C, device=dev) * 0.3
+    mean = torch.randn(C, device=dev) * 0.1
+    invstd = torch.rand(C, device=dev) + 0.5
+    dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, scale, shift, mean, invstd, 0.1, pool)
+    none, partial2 = ops.bn_act_pool_bwd(gz, gzf, yv, scale, shift, mean, invstd, 0.1, pool, want_dt=False)
+    assert none is None and torch.equal(partial, partial2)
+    _, _, coef = ops.reduce_partials(partial, yv.pixels, C, scale=scale, want_coef=True)
+    dy_g = ops.bn_bwd_apply_g(gz, gzf, yv, scale, shift, 0.1, pool, coef, mean, invstd)
+    dy_w, wt_g = ops.wino_dy_bn_transform_g(gz, gzf, yv, scale, shift, 0.1, pool, coef, mean, invstd)
+    wt = ops.wino_dy_bn_transform(dt, yv, coef, mean, invstd)            # dt -> dy in place
+    assert torch.equal(dy_g.t, dt.t) and torch.equal(dy_w.t, dt.t) and torch.equal(wt_g, wt)
+    dt2, _ = ops.bn_act_pool_bwd(gz, gzf, yv, scale, shift, mean, invstd, 0.1, pool)
+    ops.bn_bwd_apply(dt2, yv, coef, mean, invstd)
+    assert torch.equal(dt2.t, dy_g.t)
+
+
 def _load_pair(dev, seed=0, randomize_bn=True):
     from fewshot_detection_amd.darknet_meta import Darknet
     from oracle.net import OracleDarknet
