@@ -156,9 +156,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       retap();
     }
   };
+  unsigned a_ch = 0;       // first input channel of this thread's staged float4 (activation on load)
   auto gload = [&](int kc) {
     if constexpr (FASTK) {
       const unsigned coff = (unsigned)f_cc * kBK;
+      a_ch = coff + (unsigned)kq * 4u;
 #pragma unroll
       for (int j = 0; j < A_PER_T; ++j) ra[j] = *reinterpret_cast<const f32x4*>(p.x + (a_off[j] + coff));
       a_mask = tap_mask;
@@ -192,13 +194,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         rb[j] = *reinterpret_cast<const f32x4*>(wrow + (long long)j * RPP * p.Kpad + kc * kBK);
     }
   };
+  // activation on load (p.in_scale): every staged float4 of a chunk holds the same 4 input channels (a_ch); padding stays 0
+  f32x4 in_sc = {1.f, 1.f, 1.f, 1.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+  auto act_in = [&](const f32x4& v) -> f32x4 { return p.in_scale ? affine_act4(v, in_sc, in_sh, p.in_slope) : v; };
   auto sstore = [&](float* st) {
+    if constexpr (FASTK) {
+      if (p.in_scale) {
+        in_sc = *reinterpret_cast<const f32x4*>(p.in_scale + a_ch);
+        in_sh = *reinterpret_cast<const f32x4*>(p.in_shift + a_ch);
+      }
+    }
     if constexpr (SPLIT) {
       unsigned short* sp = reinterpret_cast<unsigned short*>(st);
 #pragma unroll
       for (int j = 0; j < A_PER_T + B_PER_T; ++j) {
         const bool is_a = j < A_PER_T;
-        const f32x4 v = is_a ? ((a_mask >> j) & 1u ? ra[is_a ? j : 0] : f32x4{0.f, 0.f, 0.f, 0.f}) : rb[is_a ? 0 : j - A_PER_T];
+        const f32x4 v = is_a ? ((a_mask >> j) & 1u ? act_in(ra[is_a ? j : 0]) : f32x4{0.f, 0.f, 0.f, 0.f}) : rb[is_a ? 0 : j - A_PER_T];
         const int row = is_a ? r0 + RPP * j : BM + r0 + RPP * (j - A_PER_T);
         uint2 h, m, l;
         split3(v, h, m, l);
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     }
 #pragma unroll
     for (int j = 0; j < A_PER_T; ++j) {
-      const f32x4 v = (a_mask >> j) & 1u ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = (a_mask >> j) & 1u ? act_in(ra[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(st + (r0 + RPP * j) * kLd + kq * 4) = v;
     }
 #pragma unroll
@@ -451,7 +462,7 @@ int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
                 : launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, false, SS, false, false, true>, a, lds_s, NT, stream);
   }
   if constexpr (GLDS) {
-    if (fast) {      // the DMA path needs the per-tap fast path; other layers fall through to register staging
+    if (fast && !a.in_scale) {   // the DMA path needs the per-tap fast path (and an input that needs no work on the way in)
       size_t lds_g = STAGES * (size_t)(BM + BN) * kBK * sizeof(float);
       if (lds_g < tile_bytes) lds_g = tile_bytes;
       return nchw ? launch_kernel(conv_gemm_kernel<BM, BN, WM, WN, true, STAGES, true, true>, a, lds_g, NT, stream)
@@ -571,6 +582,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.wide = wide_ok(y, y_ld, cout) && y_bs % 4 == 0;
   static const char* flat_env = getenv("FSD_CONV_FLAT_XCD");        // tuning aid: 0 / 1 force the order
   a.flat_xcd = flat_env ? (flat_env[0] == '1') : (fsd_conv::f32_split_on() ? 1 : 0);
+  a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
   if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages
@@ -612,7 +624,17 @@ extern "C" int fsd_conv2d_fwd(const float* x, long long x_ld, const float* w_pac
 extern "C" int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w_packed, const float* bias,
                                   float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
                                   int cin, int cout, int ksize, int out_nchw, float slope, hipStream_t stream) {
+  return fsd_conv2d_fwd_ex(x, x_ld, w_packed, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, ksize, out_nchw, slope,
+                           nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_packed, const float* bias,
+                                 float* y, long long y_ld, float* bn_partial, int batch, int height, int width,
+                                 int cin, int cout, int ksize, int out_nchw, float slope, const float* in_scale,
+                                 const float* in_shift, float in_slope, hipStream_t stream) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return FSD_ERR_ARG;
+  if (in_scale && cin % kBK != 0) return FSD_ERR_UNSUPPORTED;      // activation on load: whole 32-channel chunks per tap
   if (!x || !w_packed || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
   if (slope != 1.f && (out_nchw || bn_partial)) return FSD_ERR_UNSUPPORTED;   // activation: NHWC store, no statistics
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
@@ -645,6 +667,7 @@ extern "C" int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w
   a.slope = slope;
   a.wide = !out_nchw && wide_ok(y, y_ld, cout);
   a.flat_xcd = 0;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
   a.x_bs = a.w_bs = a.y_bs = 0;
   if (plan.tail_m_tiles > 0) {
     ConvArgs t = a;

@@ -32,7 +32,25 @@ struct ConvArgs {
   float slope;   // leaky slope applied to (acc + bias) in the NHWC epilogue; 1 = linear (fsd_conv2d_fwd_act)
   int wide;      // NHWC epilogue through LDS with float4 stores (needs y 16-byte aligned, y_ld % 4 == 0, Cout % 4 == 0)
   int flat_xcd;  // batched launches: XCD-aware order over the flat (batch, tile) space instead of per batch (conv.hip)
+  // activation on load (fsd_conv2d_fwd_ex): the input is the RAW output y of the producing conv and x = leaky(y * in_scale +
+  // in_shift) (per input channel) is formed in the staging registers -- the producer's BatchNorm + leaky pass is never
+  // run, its result never written or read.  null = the input is used as it is.
+  const float* in_scale;
+  const float* in_shift;
+  float in_slope;
 };
+
+// leaky(v * sc + sh), the expression of bn_act_pool_kernel (elementwise.hip): consumers that apply it on load produce the
+// bits the materialised activation would have held
+__device__ __forceinline__ f32x4 affine_act4(f32x4 v, f32x4 sc, f32x4 sh, float slope) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = __builtin_fmaf(v[k], sc[k], sh[k]);
+    r[k] = t > 0.f ? t : t * slope;
+  }
+  return r;
+}
 
 // fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)
 int conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs, float* y,

@@ -117,8 +117,8 @@ __device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 sc, f32x4 sh, float s
   f32x4 r;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float t = v[k] * sc[k] + sh[k];
-    r[k] = t > 0.f ? t : t * slope;
+    const float t = __builtin_fmaf(v[k], sc[k], sh[k]);      // one rounding, spelled out: the consumers that form this
+    r[k] = t > 0.f ? t : t * slope;                          // activation on load (conv_common.hpp affine_act4) must match
   }
   return r;
 }

@@ -38,6 +38,11 @@ struct WgradArgs {
   int Cout, cin4, ks, pad, ncols;
   int m_tiles, n_tiles, pix_per_split;
   long long dy_bs, x_bs, ws_bs;   // batched (gridDim.z > 1, Winograd weight gradient): strides between batches
+  // activation on load (fsd_conv2d_wgrad_ex, ks == 1): x holds the raw output of the producing convolution and the operand is
+  // leaky(x * x_scale[ci] + x_shift[ci]); null = x as it is
+  const float* x_scale;
+  const float* x_shift;
+  float x_slope;
 };
 
 // TILE x TILE outputs per workgroup (2x2 waves), STAGES LDS buffers.
@@ -109,6 +114,11 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
     }
   }
   f32x4 ra[PASSES], rb[PASSES];
+  f32x4 xs = {1.f, 1.f, 1.f, 1.f}, xh = {0.f, 0.f, 0.f, 0.f};
+  if (p.x_scale && b_colok) {          // this thread's four x channels never change (ks == 1: column = channel)
+    xs = *reinterpret_cast<const f32x4*>(p.x_scale + ci);
+    xh = *reinterpret_cast<const f32x4*>(p.x_shift + ci);
+  }
   unsigned okmask = 0;
   auto gload = [&](int kc) {
     okmask = 0;
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
         *reinterpret_cast<uint2*>(sp + off) = h;
         *reinterpret_cast<uint2*>(sp + PT + off) = m;
         *reinterpret_cast<uint2*>(sp + 2 * PT + off) = l;
-        fsd_conv::split3((okmask >> (8 + j)) & 1u ? rb[j] : zero, h, m, l);
+        fsd_conv::split3((okmask >> (8 + j)) & 1u ? (p.x_scale ? fsd_conv::affine_act4(rb[j], xs, xh, p.x_slope) : rb[j]) : zero, h, m, l);
         *reinterpret_cast<uint2*>(sp + 3 * PT + off) = h;
         *reinterpret_cast<uint2*>(sp + 4 * PT + off) = m;
         *reinterpret_cast<uint2*>(sp + 5 * PT + off) = l;
@@ -162,7 +172,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
       put(st + (kr + RPP * j) * LDT + cq * 4, ra[j], (okmask >> j) & 1u);
-      put(st + (kBK + kr + RPP * j) * LDT + cq * 4, rb[j], (okmask >> (8 + j)) & 1u);
+      put(st + (kBK + kr + RPP * j) * LDT + cq * 4, p.x_scale ? fsd_conv::affine_act4(rb[j], xs, xh, p.x_slope) : rb[j],
+          (okmask >> (8 + j)) & 1u);
     }
   };
 
@@ -562,8 +573,10 @@ int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream, in
 
 int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw, void* workspace,
                size_t workspace_bytes, int batch, int height, int width, int cin, int cout, int ksize, int bf16,
-               hipStream_t stream) {
+               hipStream_t stream, const float* x_scale = nullptr, const float* x_shift = nullptr, float x_slope = 1.f) {
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
+  if ((x_scale == nullptr) != (x_shift == nullptr)) return FSD_ERR_ARG;
+  if (x_scale && (ksize != 1 || (cin & 3))) return FSD_ERR_UNSUPPORTED;
   if (!dy || !x || !dw_oihw || !workspace || batch < 1 || height < 1 || width < 1 || cin < 1 || cout < 1) return FSD_ERR_ARG;
   if (ksize != 1 && ksize != 3) return FSD_ERR_UNSUPPORTED;
   const int cin4 = round_up(cin, 4);
@@ -583,6 +596,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   if (workspace_bytes < (size_t)splits * cout * a.ncols * sizeof(float)) return FSD_ERR_WORKSPACE;
   a.pix_per_split = round_up((int)((pixels + splits - 1) / splits), kBK);
   a.dy_bs = a.x_bs = a.ws_bs = 0;
+  a.x_scale = x_scale; a.x_shift = x_shift; a.x_slope = x_slope;
   const dim3 grid(a.m_tiles * a.n_tiles, splits);
   if (int rc = launch_wgrad(a, bf16, grid, stream, tile)) return rc;
   if (splits <= 8)
@@ -642,6 +656,7 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
   a.Cout = cout; a.cin4 = cin; a.ks = 1; a.pad = 0;
   a.ncols = cin;
   a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)pl.slots * cout * cin;
+  a.x_scale = a.x_shift = nullptr; a.x_slope = 1.f;
   *splits_out = pl.slots;
   if (pl.dma) {
     const long long full = rows - pl.tail_rows;
@@ -761,6 +776,14 @@ extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int wi
     splits = s > splits ? s : splits;
   }
   return (size_t)splits * cout * ncols * sizeof(float);
+}
+
+extern "C" int fsd_conv2d_wgrad_ex(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,
+                                   void* workspace, size_t workspace_bytes, int batch, int height, int width, int cin,
+                                   int cout, int ksize, const float* x_scale, const float* x_shift, float x_slope,
+                                   hipStream_t stream) {
+  return wgrad_impl(dy, dy_ld, x, x_ld, dw_oihw, workspace, workspace_bytes, batch, height, width, cin, cout, ksize, 0, stream,
+                    x_scale, x_shift, x_slope);
 }
 
 extern "C" int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw,

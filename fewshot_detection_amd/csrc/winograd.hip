@@ -283,14 +283,19 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 // Weight gradient F(3x3, 4x4) shares B^T:  G4 = [1/4 0 0 0; -1/6(1 1 1 1); -1/6(1 -1 1 -1); 1/24(1 2 4 8);
 //   1/24(1 -2 4 -8); 0 0 0 1],  A3^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1].
 // fp32 round-off of this variant is ~1.5e-5 of the output magnitude (F(2x2): ~1e-6), see DESIGN.md.
+// a * b + c with ONE rounding, spelled out (vector types): the contraction of `a * b + c` is the compiler's choice per
+// instantiation, and the two instantiations of the input transform (plain / activation on load) must produce the same bits
+template <typename T>
+__device__ __forceinline__ T fma_s(float a, const T& b, const T& c) { return __builtin_elementwise_fma((T)(a), b, c); }
+
 template <typename T>
 __device__ __forceinline__ void bt6(const T& d0, const T& d1, const T& d2, const T& d3, const T& d4, const T& d5, T (&r)[6]) {
-  r[0] = 4.f * d0 - 5.f * d2 + d4;
-  r[1] = d4 + d3 - 4.f * (d1 + d2);
-  r[2] = d4 - d3 + 4.f * (d1 - d2);
-  r[3] = d4 - d2 + 2.f * (d3 - d1);
-  r[4] = d4 - d2 - 2.f * (d3 - d1);
-  r[5] = 4.f * d1 - 5.f * d3 + d5;
+  r[0] = fma_s(4.f, d0, fma_s(-5.f, d2, d4));
+  r[1] = fma_s(-4.f, d1 + d2, d4 + d3);
+  r[2] = fma_s(4.f, d1 - d2, d4 - d3);
+  r[3] = fma_s(2.f, d3 - d1, d4 - d2);
+  r[4] = fma_s(-2.f, d3 - d1, d4 - d2);
+  r[5] = fma_s(4.f, d1, fma_s(-5.f, d3, d5));
 }
 template <typename T>
 __device__ __forceinline__ void at4(const T& m0, const T& m1, const T& m2, const T& m3, const T& m4, const T& m5, T (&o)[4]) {
@@ -334,8 +339,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
 __device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
 
+// ACT: x is the raw output of the producing convolution; leaky(x * in_scale + in_shift) is formed on load (padding stays 0)
+template <bool ACT>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
-                                                         int H, int W, int TH, int TW, int C, long long T) {
+                                                         int H, int W, int TH, int TW, int C, long long T,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                         float in_slope) {
   const int cg = C >> 1;
   // neighbouring tiles re-read 2 of their 6 patch rows/columns: keep runs of consecutive tiles on one XCD (own L2)
   const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
@@ -349,6 +358,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   const int ty = (int)(ut2 % (unsigned)TH);
   const long long b = ut2 / (unsigned)TH;
   const f32x2 zero = {0.f, 0.f};
+  f32x2 isc = {1.f, 1.f}, ish = zero;
+  if constexpr (ACT) { isc = ld2(in_scale + g * 2); ish = ld2(in_shift + g * 2); }
   f32x2 d[6][6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -357,7 +368,17 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     for (int j = 0; j < 6; ++j) {
       const int ix = 4 * tx - 1 + j;
       const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      d[i][j] = ok ? ld2(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 2) : zero;
+      f32x2 v = ok ? ld2(x + ((b * H + iy) * (long long)W + ix) * x_ld + g * 2) : zero;
+      if constexpr (ACT) {
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {                    // the expression of bn_act_pool_kernel (elementwise.hip)
+            const float t = __builtin_fmaf(v[k], isc[k], ish[k]);
+            v[k] = t > 0.f ? t : t * in_slope;
+          }
+        }
+      }
+      d[i][j] = v;
     }
   }
 #pragma unroll
@@ -842,7 +863,18 @@ extern "C" int fsd_wino_conv3x3_fwd_act(const float* x, long long x_ld, const fl
                                         long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
                                         float* v_keep, const float* v_in, int batch, int height, int width, int cin,
                                         int cout, int tile, float slope, hipStream_t stream) {
+  return fsd_wino_conv3x3_fwd_ex(x, x_ld, u_packed, bias, y, y_ld, bn_partial, workspace, workspace_bytes, v_keep, v_in, batch,
+                                 height, width, cin, cout, tile, slope, nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                                       long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes,
+                                       float* v_keep, const float* v_in, int batch, int height, int width, int cin,
+                                       int cout, int tile, float slope, const float* in_scale, const float* in_shift,
+                                       float in_slope, hipStream_t stream) {
   (void)hipGetLastError();
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return FSD_ERR_ARG;
+  if (in_scale && (tile != 4 || v_in)) return FSD_ERR_UNSUPPORTED;
   if (slope != 1.f && bn_partial) return FSD_ERR_UNSUPPORTED;       // statistics are taken from the linear output
   if ((!x && !v_in) || !u_packed || !y || !workspace || batch < 1 || height < 1 || width < 1 || !tile_ok(tile))
     return FSD_ERR_ARG;
@@ -863,9 +895,12 @@ extern "C" int fsd_wino_conv3x3_fwd_act(const float* x, long long x_ld, const fl
     if (tile == 2)
       hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
+    else if (in_scale)
+      hipLaunchKernelGGL(wino4_input_kernel<true>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T, in_scale, in_shift, in_slope);
     else
-      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
-                         height, width, TH, TW, cin, T);
+      hipLaunchKernelGGL(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
     V = Vw;
   }
   const int rows_pad = round_up(cout, 128);
@@ -943,8 +978,8 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
       hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
     else
-      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
-                         height, width, TH, TW, cin, T);
+      hipLaunchKernelGGL(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
     V = Vw;
   }
   const float* Wg = wt_in;                                   // already transformed (fsd_wino_grad_transforms)

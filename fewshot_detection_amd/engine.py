@@ -13,6 +13,8 @@ Here the same walk drives a small set of fused device ops:
 
 A forward pass records a tape (views + per-channel statistics) that `backward` replays in reverse.
 """
+import os
+
 import torch
 
 from . import ops, streams
@@ -82,6 +84,9 @@ class _WeightCache(object):
 
 
 FOLD_EVAL_BN = True     # inference: BatchNorm folded into the conv operands, leaky in the conv epilogue (Network._conv_eval)
+# fp32 training: a conv + BatchNorm + leaky layer whose only reader is the next convolution hands over its raw output and the
+# reader forms the activation on load (Network._defers_to_consumer).  FSD_DEFER_ACT=0: every activation is materialised.
+DEFER_ACTIVATION = os.environ.get("FSD_DEFER_ACT", "1") != "0"
 
 
 class Network(object):
@@ -143,6 +148,24 @@ class Network(object):
                 raise NotImplementedError("route over feature maps of different size (maybe_repeat)")
             return View(big.t, B, H, W, C, off)
         return ops.new_view(B, H, W, C, dev, dtype=self.act_dtype)
+
+    def _defers_to_consumer(self, ind, y, cout, training):
+        """fp32 training pass: may layer `ind` (conv + BatchNorm + leaky, no pool) hand its RAW output on, the activation being
+        formed by the consumer on load?  Only when the consumer is exactly one convolution that takes a deferred view: the
+        next layer, an F(4x4) Winograd conv or a direct fp32 conv over whole 32-channel chunks, and nothing else (no route)
+        reads this layer."""
+        if not DEFER_ACTIVATION or self.compute_dtype != "f32" or not (training or self._record) or y.bf16:
+            return False
+        if ind in self.tapped or ind in self.concat_of or ind + 1 >= len(self.layers):
+            return False
+        nxt = self.layers[ind + 1]
+        if nxt["type"] != "convolutional" or is_dynamic(nxt) or int(nxt.get("stride", 1)) != 1:
+            return False
+        k2, cout2 = int(nxt["size"]), int(nxt["filters"])
+        if k2 not in (1, 3) or (k2 == 3 and not int(nxt.get("pad", 0))) or cout % 32:
+            return False
+        wino = ops.wino_tile(cout, cout2, k2, y.H, y.W)
+        return wino == 4 or (wino == 0 and k2 == 1)       # (the direct 3x3 weight gradient reads a materialised x)
 
     def _conv_any(self, xv, conv, cout, k, bias, out, bn_partial):
         """One non-Winograd, non-first-layer convolution in the network's storage mode -> (y view, partial sums)."""
@@ -268,6 +291,12 @@ class Network(object):
         scale = shift = mean = invstd = None
         if bn is not None:
             scale, shift, mean, invstd = ops.bn_finalize(partial, xv.pixels, bn, training)
+        if bn is not None and pool == 0 and self._defers_to_consumer(ind, y, cout, training):
+            # the single consumer forms leaky(y * scale + shift) on load: no BatchNorm + leaky pass, no activation tensor
+            z = View(y.t, y.B, y.H, y.W, y.C, y.c0, lazy=(scale, shift, slope))
+            rec.update(x=xv, y=y, z=z, z_full=None, scale=scale, shift=shift, mean=mean, invstd=invstd, training=training)
+            tape.append(rec)
+            return z, None
         z_full = None
         if pool and ind in self.tapped:      # a [route] reads the activation before its maxpool
             z_full = ops.bn_act_pool(y, scale, shift, slope, 0,

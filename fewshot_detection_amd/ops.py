@@ -24,11 +24,14 @@ def require_device(*tensors):
 
 class View(object):
     """NHWC activation: `t` is a 2-D (pixels, ld) buffer, channels [c0, c0+C) of each pixel.  The buffer is float32
-    (fp32 mode) or bfloat16 (bf16 storage mode); `ld` and `c0` count ELEMENTS."""
-    __slots__ = ("t", "B", "H", "W", "C", "c0")
+    (fp32 mode) or bfloat16 (bf16 storage mode); `ld` and `c0` count ELEMENTS.
+    `lazy` = (scale, shift, slope) marks a DEFERRED activation (fp32): the buffer holds the raw output y of a conv and the
+    view stands for leaky(y * scale + shift); consumers that can form it on load do (conv2d, conv3x3_wino tile 4, the 1x1
+    weight gradient), everybody else calls materialise() first."""
+    __slots__ = ("t", "B", "H", "W", "C", "c0", "lazy")
 
-    def __init__(self, t, B, H, W, C, c0=0):
-        self.t, self.B, self.H, self.W, self.C, self.c0 = t, B, H, W, C, c0
+    def __init__(self, t, B, H, W, C, c0=0, lazy=None):
+        self.t, self.B, self.H, self.W, self.C, self.c0, self.lazy = t, B, H, W, C, c0, lazy
 
     @property
     def ld(self):
@@ -48,6 +51,19 @@ class View(object):
 
     def dense(self):
         return self.t[:, self.c0:self.c0 + self.C]
+
+
+def materialise(v, out=None):
+    """The activation a deferred view stands for, as a plain view (one BatchNorm + leaky pass); plain views pass through."""
+    if v.lazy is None:
+        return v
+    scale, shift, slope = v.lazy
+    return bn_act_pool(View(v.t, v.B, v.H, v.W, v.C, v.c0), scale, shift, slope, 0, out=out)
+
+
+def lazy_ok_direct(v, ksize):
+    """Can conv2d / the 1x1 weight gradient form this deferred activation on load?  (whole 32-channel chunks per tap)"""
+    return v.lazy is not None and not v.bf16 and v.C % 32 == 0 and ksize in (1, 3)
 
 
 def new_view(B, H, W, C, device, ld=None, dtype=torch.float32):
@@ -188,9 +204,18 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     if keep_v is not None:
         v = torch.empty(L.fsd_wino_v_elems(xv.B, xv.H, xv.W, xv.C, tile), dtype=torch.float32, device=dev)
         keep_v.append(v)
-    check(L.fsd_wino_conv3x3_fwd_act(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
-                                     ws.data_ptr(), ws_bytes, _ptr(v), _ptr(v_in), xv.B, xv.H, xv.W, xv.C, cout, tile,
-                                     float(slope), _stream()), "fsd_wino_conv3x3_fwd")
+    if xv.lazy is not None and v_in is None:
+        if tile != 4:
+            raise ValueError("a deferred activation needs the F(4x4) input transform (materialise() it first)")
+        sc, sh, sl = xv.lazy
+        check(L.fsd_wino_conv3x3_fwd_ex(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+                                        ws.data_ptr(), ws_bytes, _ptr(v), 0, xv.B, xv.H, xv.W, xv.C, cout, tile,
+                                        float(slope), sc.data_ptr(), sh.data_ptr(), float(sl), _stream()),
+              "fsd_wino_conv3x3_fwd_ex")
+    else:
+        check(L.fsd_wino_conv3x3_fwd_act(xv.ptr, xv.ld, u_packed.data_ptr(), _ptr(bias), y.ptr, y.ld, _ptr(partial),
+                                         ws.data_ptr(), ws_bytes, _ptr(v), _ptr(v_in), xv.B, xv.H, xv.W, xv.C, cout, tile,
+                                         float(slope), _stream()), "fsd_wino_conv3x3_fwd")
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
@@ -251,9 +276,17 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().fsd_conv2d_fwd_act(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
-                                   xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()),
-          "fsd_conv2d_fwd")
+    if xv.lazy is not None:
+        if not lazy_ok_direct(xv, ksize):
+            raise ValueError("this convolution cannot form a deferred activation on load (materialise() it first)")
+        sc, sh, sl = xv.lazy
+        check(lib().fsd_conv2d_fwd_ex(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+                                      xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, float(slope),
+                                      sc.data_ptr(), sh.data_ptr(), float(sl), _stream()), "fsd_conv2d_fwd_ex")
+    else:
+        check(lib().fsd_conv2d_fwd_act(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial),
+                                       xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()),
+              "fsd_conv2d_fwd")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
@@ -456,6 +489,9 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
         return _conv2d_wgrad_h(dyv, cout, xv, cin, ksize, param)
     if tile is None:
         tile = wino_tile(cin, cout, ksize, xv.H, xv.W) if dtype == "f32" else 0
+    if xv.lazy is not None and not (dtype == "f32" and ((tile and cin == xv.C and wino_v is not None)
+                                                         or (not tile and ksize == 1 and lazy_ok_direct(xv, 1)))):
+        raise ValueError("this weight gradient cannot form a deferred activation on load (materialise() x first)")
     if dtype == "f32" and tile and cin == xv.C:
         ws_bytes = L.fsd_wino_wgrad_workspace_bytes(xv.B, xv.H, xv.W, cin, cout, tile)
         ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
@@ -469,8 +505,14 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
     dw = grad_dst(param, (cout, cin, ksize, ksize), dev)
     if dtype != "f32":
         raise ValueError("fp32 views take the fp32 weight-gradient kernel (bf16 mode: bf16 views)")
-    check(L.fsd_conv2d_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
-                             xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
+    if xv.lazy is not None:
+        sc, sh, sl = xv.lazy
+        check(L.fsd_conv2d_wgrad_ex(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
+                                    xv.W, cin, cout, ksize, sc.data_ptr(), sh.data_ptr(), float(sl), _stream()),
+              "fsd_conv2d_wgrad_ex")
+    else:
+        check(L.fsd_conv2d_wgrad(dyv.ptr, dyv.ld, xv.ptr, xv.ld, dw.data_ptr(), ws.data_ptr(), ws_bytes, xv.B, xv.H,
+                                 xv.W, cin, cout, ksize, _stream()), "fsd_conv2d_wgrad")
     return dw
 
 

@@ -170,6 +170,23 @@ int fsd_conv3x3_wgrad_c4_bnfused(const float* dt, long long dt_ld, const float* 
 int fsd_conv2d_fwd_act(const float* x, long long x_ld, const float* w_packed, const float* bias, float* y, long long y_ld,
                        float* bn_partial, int batch, int height, int width, int cin, int cout, int ksize, int out_nchw,
                        float slope, hipStream_t stream);
+/* Activation on load (fp32): the input x is the RAW output of the producing convolution and the kernel forms
+ * leaky(x * in_scale[c] + in_shift[c]) (per input channel, slope in_slope) in its staging registers -- the producer's
+ * BatchNorm + leaky pass (fsd_bn_act_pool_fwd, pool 0) is then never run and its result never written or read.  Bit-identical
+ * to running that pass and the plain entry point.  in_scale == in_shift == NULL: the plain entry point.
+ *   fsd_conv2d_fwd_ex:        cin % 32 == 0 (else FSD_ERR_UNSUPPORTED).
+ *   fsd_wino_conv3x3_fwd_ex:  tile == 4, only when the input transform runs (v_in == NULL).
+ *   fsd_conv2d_wgrad_ex:      ksize == 1: the x operand of the weight gradient of a 1x1 convolution. */
+int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_packed, const float* bias, float* y, long long y_ld,
+                      float* bn_partial, int batch, int height, int width, int cin, int cout, int ksize, int out_nchw,
+                      float slope, const float* in_scale, const float* in_shift, float in_slope, hipStream_t stream);
+int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
+                            long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
+                            const float* v_in, int batch, int height, int width, int cin, int cout, int tile, float slope,
+                            const float* in_scale, const float* in_shift, float in_slope, hipStream_t stream);
+int fsd_conv2d_wgrad_ex(const float* dy, long long dy_ld, const float* x, long long x_ld, float* dw_oihw, void* workspace,
+                        size_t workspace_bytes, int batch, int height, int width, int cin, int cout, int ksize,
+                        const float* x_scale, const float* x_shift, float x_slope, hipStream_t stream);
 int fsd_wino_conv3x3_fwd_act(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
                              long long y_ld, float* bn_partial, void* workspace, size_t workspace_bytes, float* v_keep,
                              const float* v_in, int batch, int height, int width, int cin, int cout, int tile, float slope,

@@ -204,6 +204,71 @@ def test_statistics_only_first_pass_and_recomputing_second_pass_are_bit_identica
     assert torch.equal(dt2.t, dy_g.t)
 
 
+@pytest.mark.parametrize("gemm", ["split", "native"])
+def test_activation_formed_on_load_is_bit_identical_to_the_materialised_one(dev, gemm):
+    """Deferred activations (ops.View.lazy): conv2d (1x1), conv3x3_wino (F(4x4)) and the 1x1 weight gradient form
+    leaky(y * scale + shift) in their staging registers; results equal those on the materialised activation bit for bit."""
+    from fewshot_detection_amd import ops
+    before = ops.f32_gemm_mode(gemm)
+    try:
+        torch.manual_seed(21)
+        B, H, W, C, cout = 3, 13, 13, 256, 128
+        yv = ops.nchw_to_nhwc(torch.randn(B, C, H, W, device=dev))
+        scale = torch.rand(C, device=dev) + 0.5
+        shift = torch.randn(C, device=dev) * 0.3
+        lazy = ops.View(yv.t, B, H, W, C, 0, lazy=(scale, shift, 0.1))
+        act = ops.materialise(lazy)
+        assert act.lazy is None and act.t.data_ptr() != yv.t.data_ptr()
+        w1 = torch.randn(cout, C, 1, 1, device=dev) * 0.05
+        w3 = torch.randn(cout, C, 3, 3, device=dev) * 0.05
+        a, pa = ops.conv2d(act, ops.pack_weight(w1), cout, 1, bn_partial=True)
+        b, pb = ops.conv2d(lazy, ops.pack_weight(w1), cout, 1, bn_partial=True)
+        assert torch.equal(a.t, b.t) and torch.equal(pa, pb)
+        u = ops.pack_weight_wino(w3, 0, 4)
+        ka, kb = [], []
+        a, pa = ops.conv3x3_wino(act, u, cout, bn_partial=True, keep_v=ka, tile=4)
+        b, pb = ops.conv3x3_wino(lazy, u, cout, bn_partial=True, keep_v=kb, tile=4)
+        assert torch.equal(a.t, b.t) and torch.equal(pa, pb) and torch.equal(ka[0], kb[0])
+        dy = ops.nchw_to_nhwc(torch.randn(B, cout, H, W, device=dev))
+        assert torch.equal(ops.conv2d_wgrad(dy, cout, act, C, 1), ops.conv2d_wgrad(dy, cout, lazy, C, 1))
+        assert torch.equal(ops.conv2d_wgrad(dy, cout, act, C, 3, wino_v=ka[0], tile=4),
+                           ops.conv2d_wgrad(dy, cout, lazy, C, 3, wino_v=kb[0], tile=4))
+        with pytest.raises(ValueError):
+            ops.conv2d_wgrad(dy, cout, lazy, C, 3, tile=0)          # a direct 3x3 weight gradient reads a materialised x
+    finally:
+        ops.f32_gemm_mode(before)
+
+
+def test_training_step_with_deferred_activations_equals_the_materialised_step(dev, tmp_path, monkeypatch):
+    """engine.DEFER_ACTIVATION: the step that hands raw conv outputs to their single consumer (1x1 convs and F(4x4) layers
+    of the standard detector) computes, bit for bit, the output and every gradient of the step that runs each BatchNorm +
+    leaky pass -- with fewer passes."""
+    from fewshot_detection_amd import cfgs, engine, ops
+    from fewshot_detection_amd.darknet_meta import Darknet
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    calls = []
+    real = ops.bn_act_pool
+    monkeypatch.setattr(ops, "bn_act_pool", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    results = []
+    for on in (False, True):
+        monkeypatch.setattr(engine, "DEFER_ACTIVATION", on)
+        torch.manual_seed(17)
+        net = Darknet(dyn_cfg, rw_cfg).to(dev).train()
+        x = torch.rand(2, 3, 160, 160, device=dev)
+        metax = torch.rand(4, 3, 160, 160, device=dev)
+        mask = (torch.rand(4, 1, 160, 160, device=dev) > 0.5).float()
+        del calls[:]
+        out = net(x, metax, mask)
+        n_passes = len(calls)
+        out.float().pow(2).sum().backward()
+        results.append((out.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None], n_passes))
+    (o0, g0, n0), (o1, g1, n1) = results
+    assert n1 <= n0 - 8, (n0, n1)                       # the 1x1 layers and the F(4x4) layers behind no-pool convs
+    assert torch.equal(o0, o1) and len(g0) == len(g1)
+    for a_, b_ in zip(g0, g1):
+        assert torch.equal(a_, b_)
+
+
 def _load_pair(dev, seed=0, randomize_bn=True):
     from fewshot_detection_amd.darknet_meta import Darknet
     from oracle.net import OracleDarknet
