@@ -12,6 +12,7 @@
 // Transforms are pure adds in fp32; the result differs from the direct convolution by ~1e-6 relative.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
@@ -681,6 +682,85 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   }
 }
 
+// The same with FOUR channels per thread (16-byte loads of M and 16-byte stores of y; 64 accumulator registers): for layers
+// with >= 128 output channels.  FSD_WINO_OUT4=0 keeps the two-channel kernel everywhere.
+template <int GL>
+__global__ __launch_bounds__(256) void wino4_output4_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long long y_ld, float* __restrict__ partial,
+                                                           int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
+  constexpr int NPL = 256 / GL;
+  __shared__ float s_red[NPL][GL][8];
+  const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
+  const int g = blockIdx.y * GL + gl;
+  const int cg = C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
+  f32x4 s1 = zero, s2 = zero;
+  const long long t0 = (long long)blockIdx.x * tpb;
+  const long long ps = T * C;
+  if (g_ok) {
+    for (int it = pl; it < tpb; it += NPL) {
+      const long long tile = t0 + it;
+      if (tile >= T) break;
+      const unsigned utile = (unsigned)tile;             // < 2^31: 32-bit divisions
+      const int tx = (int)(utile % (unsigned)TW);
+      const unsigned ut2 = utile / (unsigned)TW;
+      const int ty = (int)(ut2 % (unsigned)TH);
+      const long long b = ut2 / (unsigned)TH;
+      const float* src = Mb + tile * C + g * 4;
+      f32x4 o[4][4];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        f32x4 u[4];
+        at4(ld4(src + (r * 6 + 0) * ps), ld4(src + (r * 6 + 1) * ps), ld4(src + (r * 6 + 2) * ps),
+            ld4(src + (r * 6 + 3) * ps), ld4(src + (r * 6 + 4) * ps), ld4(src + (r * 6 + 5) * ps), u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (r == 0) { o[0][j] = u[j]; }
+          else if (r == 1) { o[0][j] += u[j]; o[1][j] = u[j]; o[2][j] = u[j]; o[3][j] = u[j]; }
+          else if (r == 2) { o[0][j] += u[j]; o[1][j] -= u[j]; o[2][j] += u[j]; o[3][j] -= u[j]; }
+          else if (r == 3) { o[0][j] += u[j]; o[1][j] += 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] += 8.f * u[j]; }
+          else if (r == 4) { o[0][j] += u[j]; o[1][j] -= 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] -= 8.f * u[j]; }
+          else { o[3][j] += u[j]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = 4 * ty + i;
+        if (oy >= H) continue;
+        float* dst = y + ((b * H + oy) * (long long)W + 4 * tx) * y_ld + g * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (4 * tx + j >= W) continue;
+          f32x4 v = o[i][j] + bv;
+          if (slope != 1.f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * slope;
+          }
+          st4(dst + j * y_ld, v);
+          s1 += o[i][j];
+          s2 += o[i][j] * o[i][j];
+        }
+      }
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s_red[pl][gl][k] = s1[k]; s_red[pl][gl][4 + k] = s2[k]; }
+  __syncthreads();
+  if (pl == 0 && g_ok) {
+    float* dst = partial + ((long long)blockIdx.x * C + g * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int l = 0; l < NPL; ++l) { a += s_red[l][gl][k]; q += s_red[l][gl][4 + k]; }
+      dst[2 * k] = a; dst[2 * k + 1] = q;
+    }
+  }
+}
+
 // U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
 // rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
 // row -> for each of the 36 positions the workgroup writes RB runs of KB * 4 bytes (512 for KB = 128).  (Rounds 1-2: one
@@ -915,7 +995,11 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                        bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
-    if (cg <= 32)
+    static const char* out4_env = getenv("FSD_WINO_OUT4");
+    if (cout >= 128 && !(out4_env && out4_env[0] == '0'))
+      hipLaunchKernelGGL(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope);
+    else if (cg <= 32)
       hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);
     else
