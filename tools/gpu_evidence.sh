@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-3 evidence (second half, r03h -> profiles/r03b_*): the default bench line, rocprofv3 kernel-trace stats (one stream = kernel durations in isolation, and
+# Round-3 evidence (second half, gpurun_out/r03m -> profiles/r03c_*): the default bench line, rocprofv3 kernel-trace stats (one stream = kernel durations in isolation, and
 # with the side streams), PMC passes (separate runs per counter group, never combined with trace domains other than
-# --kernel-trace), a B = 2 inference trace.  Everything lands under gpurun_out/r03e/; the summaries to be judged are then
+# --kernel-trace), a B = 2 inference trace.  Everything lands under gpurun_out/r03m/; the summaries to be judged are then
 # copied to profiles/ by hand (tools/pmc_traffic.py, tools/pmc_kernels.py).
 set -u
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r03m"; rm -rf "$O"; mkdir -p "$O"
