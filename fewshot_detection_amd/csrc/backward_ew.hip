@@ -263,7 +263,9 @@ inline void launch_reduce_partials(const float* partial, double* slots, int rows
 }
 
 // dgamma/dbeta (or dbias) and the per-channel coefficients of  dy = c1 * (dt - c2 - xhat * c3)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+// S = double: `slots` from reduce_partials_kernel; S = float: the partial rows themselves (rows <= slots: one row per slot)
+template <typename S>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const S* __restrict__ slots, int n_slots, double count, int channels,
                                        const float* __restrict__ scale, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef) {
   // block = 32 channels x 8 slot lanes (coalesced along channels); lanes folded through LDS in a fixed order
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   if (c < channels) {
 #pragma unroll 4
     for (int k = sl; k < n_slots; k += 8) {
-      s1 += slots[((long long)k * channels + c) * 2 + 0];
-      s2 += slots[((long long)k * channels + c) * 2 + 1];
+      s1 += (double)slots[((long long)k * channels + c) * 2 + 0];
+      s2 += (double)slots[((long long)k * channels + c) * 2 + 1];
     }
   }
   s_part[sl][cl][0] = s1;
@@ -603,9 +605,14 @@ extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long cou
   (void)hipGetLastError();
   if (!partial || !workspace || rows < 1 || channels < 1 || count < 1) return FSD_ERR_ARG;
   const int n_slots = rows < kSlots ? rows : kSlots;
+  if (rows <= kSlots) {                 // one row per slot: finalize reads the partial sums directly
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, partial, n_slots,
+                       (double)count, channels, scale, dgamma, dbeta, coef);
+    return (int)hipGetLastError();
+  }
   const int two_c = 2 * channels;
   launch_reduce_partials(partial, reinterpret_cast<double*>(workspace), rows, two_c, n_slots, stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((channels + 31) / 32), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, scale, dgamma, dbeta,
                      coef);
   return (int)hipGetLastError();

@@ -67,7 +67,10 @@ inline void launch_bn_reduce(const float* partial, double* slots, int tiles, int
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ slots, int n_slots, double count, int channels,
+// S = double: `slots` from bn_reduce_kernel.  S = float: the per-tile partial sums themselves, when there are no more rows
+// than slots (a slot would hold exactly one row: same values, same order of summation, one launch less).
+template <typename S>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const S* __restrict__ slots, int n_slots, double count, int channels,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    int training, float* __restrict__ scale, float* __restrict__ shift,
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (c < channels) {
 #pragma unroll 4
       for (int k = sl; k < n_slots; k += 8) {
-        s += slots[((long long)k * channels + c) * 2 + 0];
-        q += slots[((long long)k * channels + c) * 2 + 1];
+        s += (double)slots[((long long)k * channels + c) * 2 + 0];
+        q += (double)slots[((long long)k * channels + c) * 2 + 1];
       }
     }
     s_part[sl][cl][0] = s;
@@ -327,10 +330,16 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
   if (training) {
     if (!bn_partial || !workspace || row_tiles < 1 || count < 1) return FSD_ERR_ARG;
     n_slots = row_tiles < kBnSlots ? row_tiles : kBnSlots;
+    if (row_tiles <= kBnSlots) {          // one row per slot: finalize reads the partial sums directly
+      hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, bn_partial, n_slots,
+                         (double)count, channels, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
+                         save_mean, save_invstd);
+      return (int)hipGetLastError();
+    }
     const int two_c = 2 * channels;
     launch_bn_reduce(bn_partial, reinterpret_cast<double*>(workspace), row_tiles, two_c, n_slots, stream);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((channels + 31) / 32), dim3(256), 0, stream,
+  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, gamma, beta,
                      running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_invstd);
   return (int)hipGetLastError();
