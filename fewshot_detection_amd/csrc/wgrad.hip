@@ -57,7 +57,9 @@ struct WgradArgs {
 //                 one per plane, 16-byte pieces XOR-permuted inside a row), the k-contiguous MFMA fragments come out
 //                 through the transposing read ds_read_b64_tr_b16, and a product is six MFMA terms.  One LDS stage.
 template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false, bool SPLIT = false>
-__global__ __launch_bounds__(kThreads) void wgrad_kernel(WgradArgs p) {
+// (at least 3 waves per SIMD: the split 128x128 variant then keeps its accumulators in VGPRs, 154 registers instead of 130 + 64
+// AGPRs = two waves per SIMD; its 48 KB of LDS allow three workgroups per CU: 26x26 256->512 0.205 -> 0.197 ms, 13x13 0.474 -> 0.456)
+__global__ __launch_bounds__(kThreads, 3) void wgrad_kernel(WgradArgs p) {
   static_assert(!BF16, "fp32 kernel");
   static_assert(!DMA || (PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
   static_assert(!SPLIT || (!DMA && STAGES == 1), "split operands: register staging, one LDS stage");
