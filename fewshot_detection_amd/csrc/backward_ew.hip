@@ -137,6 +137,57 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgsT<T> p) {
   }
 }
 
+// Statistics only, no pool, no un-pooled tap (the first pass of most fp32 BatchNorm layers since dt is not materialised):
+// the same sums in the same order as act_bwd_kernel, without its window / image-coordinate code (99 -> ~40 registers).
+template <int GL>
+__global__ __launch_bounds__(256) void act_stats_kernel(ActBwdArgsT<float> p) {
+  constexpr int NPL = 256 / GL;
+  __shared__ float s_red[NPL][GL][8];
+  const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
+  const int g = blockIdx.y * GL + gl;
+  const int cg = p.C >> 2;
+  const bool g_ok = g < cg;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc = (g_ok && p.scale) ? ld4(p.scale + g * 4) : one;
+  const f32x4 sh = (g_ok && p.shift) ? ld4(p.shift + g * 4) : zero;
+  const f32x4 mu = (g_ok && p.mean) ? ld4(p.mean + g * 4) : zero;
+  const f32x4 is = (g_ok && p.invstd) ? ld4(p.invstd + g * 4) : one;
+  f32x4 s1 = zero, s2 = zero;
+  const long long p0 = (long long)blockIdx.x * p.ppb;
+  if (g_ok) {
+    long long left = p.pixels - p0;
+    const int n = (int)(left < p.ppb ? left : p.ppb);
+#pragma unroll 4
+    for (int it = pl; it < n; it += NPL) {
+      const long long pix = p0 + it;
+      const f32x4 yv = ld4(p.y + pix * p.y_ld + g * 4);
+      const f32x4 gin = ld4(p.dz + pix * p.dz_ld + g * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tv = yv[k] * sc[k] + sh[k];
+        const float d = tv > 0.f ? gin[k] : gin[k] * p.slope;
+        s1[k] += d;
+        s2[k] += d * ((yv[k] - mu[k]) * is[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_red[pl][gl][k] = s1[k];
+    s_red[pl][gl][4 + k] = s2[k];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < GL * 8; t += 256) {
+    const int tg = t >> 3, k8 = t & 7;
+    const int gg = blockIdx.y * GL + tg;
+    if (gg >= cg) continue;
+    float a = 0.f;
+#pragma unroll 4
+    for (int l = 0; l < NPL; ++l) a += s_red[l][tg][k8];
+    p.partial[((long long)blockIdx.x * p.C + gg * 4 + (k8 & 3)) * 2 + (k8 >> 2)] = a;
+  }
+}
+
 // pool == 1 (2x2 stride 2) specialisation: one thread per 2x2 CELL and 4 channels, so every y is
 // read once, the argmax is decided once and the (up to) four dt values are written together.
 // Cells on the odd border (no pooling window) only carry the dz_full / zero gradient.
@@ -572,6 +623,15 @@ int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long lo
   }
   a.ppb = pix_per_block(a.pixels);
   const dim3 grid(blocks_for(a.pixels, a.ppb), (cg + gl - 1) / gl);
+  if constexpr (std::is_same<T, float>::value) {
+    if (!dt && pool == 0 && !dz_full) {
+      if (gl == 8) hipLaunchKernelGGL((act_stats_kernel<8>), grid, dim3(256), 0, stream, a);
+      else if (gl == 16) hipLaunchKernelGGL((act_stats_kernel<16>), grid, dim3(256), 0, stream, a);
+      else if (gl == 32) hipLaunchKernelGGL((act_stats_kernel<32>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((act_stats_kernel<64>), grid, dim3(256), 0, stream, a);
+      return (int)hipGetLastError();
+    }
+  }
   if (gl == 8) hipLaunchKernelGGL((act_bwd_kernel<T, 8>), grid, dim3(256), 0, stream, a);
   else if (gl == 16) hipLaunchKernelGGL((act_bwd_kernel<T, 16>), grid, dim3(256), 0, stream, a);
   else if (gl == 32) hipLaunchKernelGGL((act_bwd_kernel<T, 32>), grid, dim3(256), 0, stream, a);
