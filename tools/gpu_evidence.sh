@@ -4,7 +4,7 @@
 # --kernel-trace), a B = 2 inference trace.  Everything lands under gpurun_out/r03m/; the summaries to be judged are then
 # copied to profiles/ by hand (tools/pmc_traffic.py, tools/pmc_kernels.py).
 set -u
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r03m"; rm -rf "$O"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r03p"; rm -rf "$O"; mkdir -p "$O"
 export TMPDIR=/tmp; cd "$R"
 ( time timeout 900 python bench.py ) > "$O/bench_f32.json" 2> "$O/bench_f32.err"; echo "bench f32 rc=$?"
 ( time timeout 600 python bench.py --classes 15 --support 416 --no-cpu-baseline --no-extras ) > "$O/bench_c2cfg.json" 2> "$O/bench_c2cfg.err"; echo "bench c2 rc=$?"
