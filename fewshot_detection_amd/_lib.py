@@ -57,6 +57,7 @@ PROTOTYPES = {
     "fsd_wino_dy_bn_transform": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_wino_dy_bn_transform_g": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _f, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_bn_bwd_apply_g": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _f, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_bn_bwd_apply_g_h": (_i, [_p, _ll, _p, _ll, _p, _ll, _p, _p, _f, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_wino_grad_transforms": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_packed_weight_elems_bf16": (_sz, [_i, _i, _i]),
     "fsd_pack_conv_weight_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),

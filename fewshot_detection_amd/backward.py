@@ -100,8 +100,8 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
             gz, gzf, pool = gzf, None, 0
         kept = rec.get("wino_v")
         wino4 = bool(kept) and rec.get("wino_tile") == 4 and yv.C % 4 == 0
-        # fp32 BatchNorm layers: dt is not materialised -- the first pass takes the statistics, the second one re-forms it
-        defer = (ops.DEFER_DT and bn is not None and not yv.bf16 and pool in (0, 1)
+        # BatchNorm layers: dt is not materialised -- the first pass takes the statistics, the second one re-forms it
+        defer = (ops.DEFER_DT and bn is not None and pool in (0, 1) and ops.defer_dt_ok(yv, gz, gzf)
                  and not (xv is first_input and ops.c4_bnfused_eligible(xv, cout, k))
                  and not (ops.FUSE_WINO_GRAD and wino4))
         dt, partial = ops.bn_act_pool_bwd(gz, gzf, yv, rec.get("scale"), rec.get("shift"), rec.get("mean"),

@@ -447,6 +447,121 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const float* __rest
   }
 }
 
+// The bf16-storage form of bn_bwd_apply_g_kernel, 8 channels (16 bytes) per lane.  dt is formed in fp32 and never rounded to
+// the storage type on the way (the two-pass form stores it as bf16 in between), dy is rounded once when it is written.
+__device__ __forceinline__ void load8(const bf16_t* p, float (&a)[8]) {
+  const fsd_ew::f32x8 v = fsd_ew::ld8(p);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a[k] = v.lo[k]; a[4 + k] = v.hi[k]; }
+}
+__device__ __forceinline__ void load8f(const float* p, float (&a)[8]) {
+  const f32x4 lo = ld4(p), hi = ld4(p + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a[k] = lo[k]; a[4 + k] = hi[k]; }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&a)[8]) {
+  fsd_ew::f32x8 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v.lo[k] = a[k]; v.hi[k] = a[4 + k]; }
+  fsd_ew::st8(p, v);
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __restrict__ dz, long long dz_ld,
+                                                              const bf16_t* __restrict__ dz_full, long long dzf_ld,
+                                                              const bf16_t* __restrict__ y, long long y_ld,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float slope, const float* __restrict__ coef,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              bf16_t* __restrict__ dy, int H, int W, int OH, int OW, int C,
+                                                              long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = C >> 3;
+  const int g = (int)(idx % cg);
+  const long long unit = idx / cg;
+  float sc[8], sh[8], c1[8], c2[8], c3[8], mu[8], is[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
+  if (scale) load8f(scale + g * 8, sc);
+  if (shift) load8f(shift + g * 8, sh);
+  load8f(coef + g * 8, c1); load8f(coef + C + g * 8, c2); load8f(coef + 2 * C + g * 8, c3);
+  load8f(mean + g * 8, mu); load8f(invstd + g * 8, is);
+  if constexpr (POOL == 0) {
+    const long long pix = unit;
+    float yv[8], gin[8], o[8];
+    load8(y + pix * y_ld + g * 8, yv);
+    load8(dz + pix * dz_ld + g * 8, gin);
+    if (dz_full) {
+      float gf[8];
+      load8(dz_full + pix * dzf_ld + g * 8, gf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gin[k] += gf[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float tv = yv[k] * sc[k] + sh[k];
+      const float d = tv > 0.f ? gin[k] : gin[k] * slope;
+      o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
+    }
+    store8(dy + pix * C + g * 8, o);
+  } else {
+    const int CH = (H + 1) >> 1, CW = (W + 1) >> 1;
+    const int cx = (int)(unit % CW);
+    const long long t = unit / CW;
+    const int cy = (int)(t % CH);
+    const long long b = t / CH;
+    const bool win = cy < OH && cx < OW;
+    float yv[4][8], tv[4][8], bv[8], gz[8];
+    bool in[4];
+    int best[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+      in[q] = yy < H && xx < W;
+      if (in[q]) {
+        load8(y + ((b * H + yy) * (long long)W + xx) * y_ld + g * 8, yv[q]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[q][k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        tv[q][k] = yv[q][k] * sc[k] + sh[k];
+        const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * slope;
+        if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
+      }
+    }
+    if (win) {
+      load8(dz + ((b * OH + cy) * (long long)OW + cx) * dz_ld + g * 8, gz);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gz[k] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!in[q]) continue;
+      const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+      const long long pix = (b * H + yy) * (long long)W + xx;
+      float gin[8], o[8];
+      if (dz_full) {
+        load8(dz_full + pix * dzf_ld + g * 8, gin);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gin[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float gk = gin[k];
+        if (win && best[k] == q) gk += gz[k];
+        const float d = tv[q][k] > 0.f ? gk : gk * slope;
+        o[k] = c1[k] * (d - c2[k] - (yv[q][k] - mu[k]) * is[k] * c3[k]);
+      }
+      store8(dy + pix * C + g * 8, o);
+    }
+  }
+}
+
 // bf16 storage, 8 channels (16 bytes) per lane: with 4 channels a lane moves 8 bytes and a wave instruction 512 -- the bf16
 // twins of the HBM-bound kernels then reach 3.5-4.1 TB/s where their fp32 versions (16 bytes per lane) reach 5.1-5.4
 __global__ void bn_bwd_apply8_kernel(bf16_t* __restrict__ dt, const bf16_t* __restrict__ y, long long y_ld,
@@ -779,6 +894,36 @@ extern "C" int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float*
     const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
     hipLaunchKernelGGL(bn_bwd_apply_g_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
                        dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int fsd_bn_bwd_apply_g_h(const void* dz, long long dz_ld, const void* dz_full, long long dz_full_ld, const void* y,
+                                   long long y_ld, const float* scale, const float* shift, float slope, int pool,
+                                   const float* coef, const float* mean, const float* invstd, void* dy, int batch, int height,
+                                   int width, int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dz || !y || !coef || !mean || !invstd || !dy || batch < 1 || height < 1 || width < 1) return FSD_ERR_ARG;
+  if (channels < 8 || (channels & 7) || (dz_ld & 7) || (y_ld & 7) || (dz_full && (dz_full_ld & 7))) return FSD_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15) ||
+      (dz_full && (reinterpret_cast<uintptr_t>(dz_full) & 15)))
+    return FSD_ERR_UNSUPPORTED;
+  if (pool != 0 && pool != 1) return FSD_ERR_UNSUPPORTED;
+  const int OH = pool ? height / 2 : height, OW = pool ? width / 2 : width;
+  const long long pixels = (long long)batch * height * width;
+  fsd_prof::Scope prof(fsd_prof::kActBwd, 2.0 * channels * ((double)batch * OH * OW + (dz_full ? 3.0 : 2.0) * pixels), stream);
+  const bf16_t* dzh = static_cast<const bf16_t*>(dz);
+  const bf16_t* dfh = static_cast<const bf16_t*>(dz_full);
+  const bf16_t* yh = static_cast<const bf16_t*>(y);
+  bf16_t* dyh = static_cast<bf16_t*>(dy);
+  if (pool == 0) {
+    const long long total = pixels * (channels / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_g8_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
+  } else {
+    const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_g8_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
   }
   return (int)hipGetLastError();
 }

@@ -599,8 +599,6 @@ def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool, wa
     """-> (dt View dense (pixels, C), partial [rows][C][2]).  want_dt=False (fp32): statistics only, dt is None."""
     L = lib()
     dev = yv.t.device
-    if not want_dt and yv.bf16:
-        raise ValueError("the statistics-only first pass exists for fp32 storage")
     dt = like_view(yv) if want_dt else None
     partial = torch.empty((L.fsd_bn_act_pool_bwd_rows(yv.B, yv.H, yv.W, pool), yv.C, 2), dtype=torch.float32,
                           device=dev)
@@ -618,10 +616,19 @@ def bn_bwd_apply_g(dz, dz_full, yv, scale, shift, slope, pool, coef, mean, invst
     """Second pass after bn_act_pool_bwd(want_dt=False): -> dy View dense (pixels, C); bit-identical to
     bn_bwd_apply(bn_act_pool_bwd(...)[0], ...)."""
     dy = like_view(yv)
-    check(lib().fsd_bn_bwd_apply_g(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr, 0 if dz_full is None else dz_full.ld,
-                                   yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, coef.data_ptr(), mean.data_ptr(),
-                                   invstd.data_ptr(), dy.ptr, yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_bwd_apply_g")
+    fn = lib().fsd_bn_bwd_apply_g_h if yv.bf16 else lib().fsd_bn_bwd_apply_g
+    check(fn(dz.ptr, dz.ld, 0 if dz_full is None else dz_full.ptr, 0 if dz_full is None else dz_full.ld,
+             yv.ptr, yv.ld, _ptr(scale), _ptr(shift), slope, pool, coef.data_ptr(), mean.data_ptr(),
+             invstd.data_ptr(), dy.ptr, yv.B, yv.H, yv.W, yv.C, _stream()), "fsd_bn_bwd_apply_g")
     return dy
+
+
+def defer_dt_ok(yv, dz, dz_full):
+    """Can the second pass re-form dt for these views?  fp32: always; bf16: 8-channel lanes (16-byte rows)."""
+    if not yv.bf16:
+        return True
+    views = [yv, dz] + ([dz_full] if dz_full is not None else [])
+    return yv.C % 8 == 0 and all(v.ld % 8 == 0 and v.c0 % 8 == 0 and v.t.data_ptr() % 16 == 0 for v in views)
 
 
 def wino_dy_bn_transform_g(dz, dz_full, yv, scale, shift, slope, pool, coef, mean, invstd):

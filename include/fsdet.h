@@ -326,7 +326,7 @@ int fsd_conv2d_wgrad(const float* dy, long long dy_ld, const float* x, long long
  * plus per-block partial sums [fsd_bn_act_pool_bwd_rows(...)][C][2] of (dt, dt*xhat) for the BatchNorm
  * backward.  dz: grad of the block output (pooled grid if pool != 0); dz_full: optional grad of the
  * un-pooled activation.  The max-pool argmax is recomputed from y (first maximum in scan order).
- * dt == NULL (fp32 entry): statistics only -- the partial sums are produced, dt is not written; the second pass then forms
+ * dt == NULL: statistics only -- the partial sums are produced, dt is not written; the second pass then forms
  * dt again itself (fsd_bn_bwd_apply_g / fsd_wino_dy_bn_transform_g), which saves one write and one read of a full-resolution
  * tensor per layer. */
 int fsd_act_bwd_rows(long long pixels);
@@ -350,6 +350,12 @@ int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float* dz_full, l
                        long long y_ld, const float* scale, const float* shift, float slope, int pool, const float* coef,
                        const float* mean, const float* invstd, float* dy, int batch, int height, int width, int channels,
                        hipStream_t stream);
+/* bf16 storage (fsd_bn_act_pool_bwd_h with dt == NULL is the statistics-only first pass): channels % 8 == 0, 16-byte aligned
+ * rows.  dt is formed in fp32 and not rounded to bf16 on the way; dy is rounded once. */
+int fsd_bn_bwd_apply_g_h(const void* dz, long long dz_ld, const void* dz_full, long long dz_full_ld, const void* y,
+                         long long y_ld, const float* scale, const float* shift, float slope, int pool, const float* coef,
+                         const float* mean, const float* invstd, void* dy, int batch, int height, int width, int channels,
+                         hipStream_t stream);
 /* Column sums of a (rows, ld) matrix as partials [fsd_act_bwd_rows(rows)][C][2] (any C). */
 int fsd_colsum_partials(const float* m, long long ld, float* partial, long long rows, int channels,
                         hipStream_t stream);
