@@ -61,6 +61,14 @@ def materialise(v, out=None):
     return bn_act_pool(View(v.t, v.B, v.H, v.W, v.C, v.c0), scale, shift, slope, 0, out=out)
 
 
+def _plain(*views):
+    """Guard of the consumers that read a view's buffer as the activation itself: a deferred view holds the producing
+    convolution's RAW output (see View.lazy) -- materialise() it first."""
+    for v in views:
+        if v is not None and v.lazy is not None:
+            raise ValueError("this operation reads the activation itself; the view is deferred (ops.materialise() it first)")
+
+
 def lazy_ok_direct(v, ksize):
     """Can conv2d / the 1x1 weight gradient form this deferred activation on load?  (whole 32-channel chunks per tap)"""
     return v.lazy is not None and not v.bf16 and v.C % 32 == 0 and ksize in (1, 3)
@@ -79,6 +87,7 @@ def like_view(v, C=None, ld=None, H=None, W=None):
 def cast_view(v, dtype, out=None):
     """A dense copy of `v` in another storage type (float32 <-> bfloat16, round-to-nearest-even).  Plumbing for the few
     convolutions of non-standard cfgs whose channel counts the bf16 kernels do not take; the shipped cfgs never call it."""
+    _plain(v)
     src = v.t[:, v.c0:v.c0 + v.C]
     if out is None:
         return View(src.to(dtype).contiguous(), v.B, v.H, v.W, v.C)
@@ -131,6 +140,7 @@ def write_channels(x, view, c_off):
 
 
 def nhwc_to_nchw(v):
+    _plain(v)
     out = torch.empty((v.B, v.C, v.H, v.W), dtype=torch.float32, device=v.t.device)
     hw = v.H * v.W
     if v.bf16:
@@ -296,6 +306,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
 
 def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=1.0):
     """bf16 storage mode: bf16 NHWC activations x packed bf16 weights -> bf16 NHWC (or float NCHW for the head)."""
+    _plain(xv)
     L = lib()
     dev = xv.t.device
     if w_packed.dtype != torch.bfloat16:
@@ -327,6 +338,7 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=
 def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False, out_dtype=torch.float32):
     """First-layer 3x3 convolution of an NHWC4 view straight from the OIHW weights (HBM-bound direct-operand kernel).
     out_dtype = torch.bfloat16 stores the raw output in bf16 (bf16 mode); the arithmetic is fp32 either way."""
+    _plain(xv)
     L = lib()
     dev = xv.t.device
     y = out if out is not None else new_view(xv.B, xv.H, xv.W, cout, dev, dtype=out_dtype)
@@ -380,6 +392,7 @@ def flush_bn_counters(module):
 
 
 def bn_act_pool(yv, scale, shift, slope, pool, out=None):
+    _plain(yv)
     OH, OW = (yv.H // 2, yv.W // 2) if pool == 1 else (yv.H, yv.W)
     z = out if out is not None else like_view(yv, H=OH, W=OW)
     if z.bf16 != yv.bf16:
@@ -391,6 +404,7 @@ def bn_act_pool(yv, scale, shift, slope, pool, out=None):
 
 
 def reorg(xv, stride, out=None):
+    _plain(xv)
     z = out if out is not None else like_view(xv, C=xv.C * stride * stride, H=xv.H // stride, W=xv.W // stride)
     fn = lib().fsd_reorg_fwd_h if xv.bf16 else lib().fsd_reorg_fwd
     check(fn(xv.ptr, xv.ld, z.ptr, z.ld, xv.B, xv.H, xv.W, xv.C, stride, _stream()), "fsd_reorg_fwd")
@@ -398,6 +412,7 @@ def reorg(xv, stride, out=None):
 
 
 def global_maxpool(xv, want_argmax=False):
+    _plain(xv)
     out = torch.empty((xv.B, xv.C), dtype=torch.float32, device=xv.t.device)
     arg = torch.empty((xv.B, xv.C), dtype=torch.int32, device=xv.t.device) if want_argmax else None
     fn = lib().fsd_global_maxpool_fwd_h if xv.bf16 else lib().fsd_global_maxpool_fwd
@@ -518,6 +533,7 @@ def conv2d_wgrad(dyv, cout, xv, cin, ksize, dtype="f32", wino_v=None, param=None
 
 def _conv2d_wgrad_h(dyv, cout, xv, cin, ksize, param):
     """bf16 storage mode: dW (float, OIHW) from bf16 dy and bf16 x."""
+    _plain(xv, dyv)
     L = lib()
     dev = xv.t.device
     if not (xv.bf16 and dyv.bf16):
