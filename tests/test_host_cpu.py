@@ -262,3 +262,45 @@ def test_deferred_views_are_refused_by_operations_that_read_the_activation_itsel
                  lambda: ops.conv3x3_c4(lazy, torch.zeros(32, 4, 3, 3), 32)):
         with pytest.raises(ValueError, match="deferred"):
             call()
+
+
+def test_which_layers_defer_their_activation_to_the_consumer(tmp_path):
+    """engine.Network._defers_to_consumer on darknet_dynamic.cfg at 416x416 (fp32 training): the 14 no-pool conv + BatchNorm
+    layers whose only reader is a 1x1 convolution or an F(4x4) Winograd layer; pooled layers, route sources (16, 24), the
+    layer feeding the reorg branch's concat and the head's input stay materialised; nothing defers in the bf16 mode, in
+    plain inference, or in the reweighting net (every layer there is pooled)."""
+    import torch
+    from fewshot_detection_amd import cfgs, ops
+    from fewshot_detection_amd.darknet_meta import Darknet
+    dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(str(tmp_path))
+    net = Darknet(dyn_cfg, rw_cfg)
+    det = net._det
+
+    def deferring(network, size, training=True, record=True):
+        network._record = record
+        out, side = [], size
+        for ind, blk in enumerate(network.layers):
+            if blk["type"] == "maxpool" and int(blk["stride"]) == 2:
+                side //= 2
+            if blk["type"] == "reorg":
+                side //= int(blk["stride"])
+            if blk["type"] == "route":
+                side = 13 if size == 416 else side
+            if blk["type"] != "convolutional" or not int(blk.get("batch_normalize", 0)):
+                continue
+            nxt = network.layers[ind + 1] if ind + 1 < len(network.layers) else None
+            if nxt is not None and nxt["type"] == "maxpool":
+                continue
+            cout = int(blk["filters"])
+            side_here = 26 if ind == 26 else side            # layer 26 reads the 26x26 map of the route before it
+            y = ops.View(torch.zeros(1, cout), 2, side_here, side_here, cout)
+            if network._defers_to_consumer(ind, y, cout, training):
+                out.append(ind)
+        return out
+
+    assert deferring(det, 416) == [4, 5, 8, 9, 12, 13, 14, 15, 18, 19, 20, 21, 22, 23]
+    assert deferring(det, 416, training=False, record=False) == []
+    det.compute_dtype = "bf16"
+    assert deferring(det, 416) == []
+    det.compute_dtype = "f32"
+    assert deferring(net._meta, 224) == []
