@@ -229,7 +229,8 @@ def conv3x3_wino(xv, u_packed, cout, bias=None, out=None, bn_partial=False, keep
     if PROFILE is not None:
         e1.record()
         tiles = xv.B * ((xv.H + tile - 1) // tile) * ((xv.W + tile - 1) // tile)
-        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles))
+        PROFILE.append((e0, e1, 2.0 * 9 * xv.C * cout * xv.pixels, 2.0 * (tile + 2) ** 2 * xv.C * cout * tiles,
+                        4.0 * (xv.pixels * (xv.C + cout) + 9 * xv.C * cout)))
     return y, partial
 
 
@@ -261,7 +262,8 @@ WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where 
 FUSE_WINO_GRAD = os.environ.get("FSD_FUSE_WINO_GRAD", "0") == "1"
 WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
 PROFILE = None      # bench.py sets this to a list, one entry per conv launch (forward / data gradient; a Winograd launch =
-                    # transform + GEMM + transform): (start_event, end_event, algorithmic_flops, executed_mfma_flops).
+                    # transform + GEMM + transform): (start_event, end_event, algorithmic_flops, executed_mfma_flops,
+                    # algorithmic_hbm_bytes = input + output activation + weights, each once).
                     # Per-KERNEL timing is the library's job (fsd_profile_enable / fsd_profile_collect).
 
 
@@ -300,7 +302,8 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * ksize * ksize * (cin_true or xv.C) * cout * xv.pixels,
-                        2.0 * ksize * ksize * xv.C * cout * xv.pixels))
+                        2.0 * ksize * ksize * xv.C * cout * xv.pixels,
+                        4.0 * (xv.pixels * (xv.C + cout) + ksize * ksize * xv.C * cout)))
     return y, partial
 
 
@@ -331,7 +334,8 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=
     if PROFILE is not None:
         e1.record()
         fl = 2.0 * ksize * ksize * xv.C * cout * xv.pixels
-        PROFILE.append((e0, e1, fl, fl))
+        PROFILE.append((e0, e1, fl, fl, 2.0 * xv.pixels * xv.C + (4.0 if nchw_out else 2.0) * xv.pixels * cout
+                        + 2.0 * ksize * ksize * xv.C * cout))
     return y, partial
 
 
@@ -354,7 +358,8 @@ def conv3x3_c4(xv, w, cout, bias=None, out=None, bn_partial=False, out_dtype=tor
              xv.B, xv.H, xv.W, cin, cout, _stream()), "fsd_conv3x3_c4_fwd")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels))
+        PROFILE.append((e0, e1, 2.0 * 9 * cin * cout * xv.pixels, 2.0 * 9 * 4 * cout * xv.pixels,
+                        xv.pixels * (16.0 + y.t.element_size() * cout) + 4.0 * 9 * cin * cout))
     return y, partial
 
 
