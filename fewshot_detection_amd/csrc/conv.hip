@@ -379,6 +379,206 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, NCHW_OUT>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
+// ---- 8-wave split GEMM for the batched Winograd position GEMMs (round 4) ---------------------------------------------------
+// The 128x128 / 4-wave split kernel above issues 11.4 instructions per MFMA in its main loop (547 per 32-wide k-chunk for 48
+// MFMAs: every workgroup re-splits 64 operand values per thread and chunk), far above the ~5 that fit beside a 32-cycle
+// v_mfma_f32_32x32x16_bf16 -- PMC: MFMA-busy 0.42.  This kernel cuts the staging work per MFMA instead of re-arranging it:
+//   * 256 x 128 tile on 8 waves (4 x 2, wave tile 64 x 64 as before): a thread splits 16 A + 8 B values per chunk for the
+//     same 48 MFMAs per wave (2.4x less VALU, LDS-store and global-load work per MFMA);
+//   * plane rows are UNPADDED (64 bytes = 32 bf16) with the 16-byte pieces XOR-permuted inside a row (piece ^ ((row >> 2) & 3):
+//     the ds_read_b128 fragment reads of a 16-lane service group then cover all 16 slots of the 256-byte bank row, and the
+//     8-byte plane stores of 16 consecutive lanes tile 128 contiguous bytes), so TWO stages of all three planes fit: 2 x 3 x
+//     (256 + 128) x 64 B = 144 KB of the 160 KB -- one workgroup per CU, two waves per SIMD;
+//   * with two stages the split + LDS stores of chunk k+1 sit BETWEEN the two MFMA groups of chunk k (one barrier per chunk).
+// Plain GEMM rows only (the batched launches of conv_gemm_batched: 1x1 taps, Cin % 32 == 0, no activation on load); rows past
+// M are clamped on load and never stored.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_kernel(ConvArgs p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  static_assert(NT == 512, "8 waves");
+  constexpr int RPP = NT / 8;                       // tile rows staged per pass (8 threads x 16 B of fp32 per row)
+  constexpr int A_PER_T = BM / RPP, B_PER_T = BN / RPP;
+  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile shape");
+  constexpr int ROWB = 64;                          // bytes of one plane row (32 bf16)
+  constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+  constexpr int STAGE = 3 * (PLANE_A + PLANE_B);    // bytes
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+
+  int batch = blockIdx.y, L;
+  if (p.flat_xcd && gridDim.y > 1) {
+    const int Lf = xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    batch = Lf / (int)gridDim.x;
+    L = Lf - batch * (int)gridDim.x;
+  } else {
+    L = xcd_swizzle(blockIdx.x, gridDim.x);
+  }
+  p.x += (long long)batch * p.x_bs;
+  p.w = static_cast<const float*>(p.w) + (long long)batch * p.w_bs;
+  p.y += (long long)batch * p.y_bs;
+  const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int kq = tid & 7, g8 = tid >> 3;
+
+  const float* asrc[A_PER_T];
+#pragma unroll
+  for (int j = 0; j < A_PER_T; ++j) {
+    int row = m0 + g8 + RPP * j;
+    row = row < p.M ? row : p.M - 1;
+    asrc[j] = p.x + (unsigned)row * (unsigned)p.x_ld + kq * 4;
+  }
+  const float* bsrc = static_cast<const float*>(p.w) + (long long)(n0 + g8) * p.Kpad + kq * 4;
+  const long long b_step = (long long)RPP * p.Kpad;
+  // byte offset of this thread's 8-byte piece inside a plane: row g8 (+ RPP * j: multiples of 64 rows leave (row >> 2) & 3 alone)
+  const int st_off = g8 * ROWB + ((((kq >> 1) ^ ((g8 >> 2) & 3))) << 4) + (kq & 1) * 8;
+
+  f32x4 ra[A_PER_T], rb[B_PER_T];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) ra[j] = *reinterpret_cast<const f32x4*>(asrc[j] + kc * kBK);
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bsrc + j * b_step + kc * kBK);
+  };
+  auto sstore = [&](unsigned char* st) {
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+      uint2 h, m, l;
+      split3(ra[j], h, m, l);
+      unsigned char* d = st + st_off + j * RPP * ROWB;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + PLANE_A) = m;
+      *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      uint2 h, m, l;
+      split3(rb[j], h, m, l);
+      unsigned char* d = st + 3 * PLANE_A + st_off + j * RPP * ROWB;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + PLANE_B) = m;
+      *reinterpret_cast<uint2*>(d + 2 * PLANE_B) = l;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment reads: lane = tile row (lane & 31), k-half (lane >> 5) of the 16 k of one MFMA; logical 16-byte piece
+  // 2 * step + half sits at piece ^ ((row >> 2) & 3)
+  const int frow = lane & 31, fsw = (frow >> 2) & 3, fh = lane >> 5;
+  const int fa_off = (wm * TM * 32 + frow) * ROWB, fb_off = 3 * PLANE_A + (wn * TN * 32 + frow) * ROWB;
+  bf16x8 af[2][3][TM], bf[2][3][TN];
+  auto frags = [&](const unsigned char* st, int s) {
+    const int po = ((2 * s + fh) ^ fsw) << 4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[s][q][i] = *reinterpret_cast<const bf16x8*>(st + fa_off + q * PLANE_A + i * 32 * ROWB + po);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[s][q][j] = *reinterpret_cast<const bf16x8*>(st + fb_off + q * PLANE_B + j * 32 * ROWB + po);
+    }
+  };
+  auto mfmas = [&](int s) {
+    // the six terms, smallest first; each term sweeps the TM x TN independent accumulators
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][TA[t]][i], bf[s][TB[t]][j], acc[i][j], 0, 0, 0);
+  };
+
+  if constexpr (!ILV) {
+    gload(0);
+    sstore(sm);
+    __syncthreads();
+    for (int kc = 0; kc < p.nk; ++kc) {
+      unsigned char* cur = sm + (kc & 1) * STAGE;
+      unsigned char* nxt = sm + ((kc & 1) ^ 1) * STAGE;
+      const bool more = kc + 1 < p.nk;
+      if (more) gload(kc + 1);
+      frags(cur, 0);
+      frags(cur, 1);
+      mfmas(0);
+      if (more) sstore(nxt);          // stage `nxt` was last read before the previous barrier
+      mfmas(1);
+      __syncthreads();
+    }
+  } else {
+    // Software pipeline with a hand-dealt issue order.  At the top of iteration kc the raw fp32 values of chunk kc+1 are
+    // already in registers (loaded during iteration kc-1).  Their split + LDS stores are cut into 48 micro-steps of 2-4 VALU
+    // (+ one DS) instructions, ONE after each of the 48 MFMAs of chunk kc, pinned with sched_barrier: the wave keeps issuing
+    // while its MFMA runs (32 cycles; 64 with the SIMD's second wave contending), instead of running ~150 VALU instructions
+    // as one block during which neither wave of the SIMD has matrix work queued (both are in the same phase of the same
+    // barrier interval).  The loads of chunk kc+2 go out as soon as a staging register set is free.  Chunk indices past the
+    // end are clamped (redundant loads / stores keep the body branch-free).
+    static_assert(TM == 2 && TN == 2 && A_PER_T + B_PER_T == 6, "the micro-step schedule below is dealt for 48 MFMAs and 6 float4");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto cvt2 = [](float a, float b) -> unsigned {                     // one v_cvt_pk_bf16_f32
+      const f32x2 v = {a, b};
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    };
+    auto lo_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk << 16); };
+    auto hi_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk & 0xffff0000u); };
+    const int last = p.nk - 1;
+    gload(0);
+    sstore(sm);
+    gload(last < 1 ? last : 1);
+    __syncthreads();
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+    for (int kc = 0; kc < p.nk; ++kc) {
+      unsigned char* cur = sm + (kc & 1) * STAGE;
+      unsigned char* nxt = sm + ((kc & 1) ^ 1) * STAGE;
+      const int kn = kc + 2 < last ? kc + 2 : last;
+      frags(cur, 0);
+      unsigned h0, h1, m0_, m1_, l0, l1;
+      float r0, r1, r2, r3;
+      const int po1 = ((2 + fh) ^ fsw) << 4;
+#pragma unroll
+      for (int u = 0; u < 48; ++u) {
+        const int ks = u / 24, t = (u % 24) / 4, i = (u % 4) / 2, j = u % 2;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
+        if (u < 12) {                                                    // fragments of k-step 1: one per MFMA
+          const int q = u / 4, w = u % 4;
+          if (w < 2) af[1][q][w] = *reinterpret_cast<const bf16x8*>(cur + fa_off + q * PLANE_A + w * 32 * ROWB + po1);
+          else bf[1][q][w - 2] = *reinterpret_cast<const bf16x8*>(cur + fb_off + q * PLANE_B + (w - 2) * 32 * ROWB + po1);
+        }
+        const int f = u / 8, step = u % 8;                               // float4 f of this thread (0-3: A rows, 4-5: B rows)
+        const f32x4 v = f < A_PER_T ? ra[f < A_PER_T ? f : 0] : rb[f < A_PER_T ? 0 : f - A_PER_T];
+        unsigned char* d = f < A_PER_T ? nxt + st_off + f * RPP * ROWB : nxt + 3 * PLANE_A + st_off + (f - A_PER_T) * RPP * ROWB;
+        const int pl = f < A_PER_T ? PLANE_A : PLANE_B;
+        if (step == 0) { h0 = cvt2(v[0], v[1]); h1 = cvt2(v[2], v[3]); }
+        else if (step == 1) { r0 = v[0] - lo_f(h0); r1 = v[1] - hi_f(h0); }
+        else if (step == 2) { r2 = v[2] - lo_f(h1); r3 = v[3] - hi_f(h1); *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1); }
+        else if (step == 3) { m0_ = cvt2(r0, r1); m1_ = cvt2(r2, r3); }
+        else if (step == 4) { r0 -= lo_f(m0_); r1 -= hi_f(m0_); }
+        else if (step == 5) { r2 -= lo_f(m1_); r3 -= hi_f(m1_); *reinterpret_cast<uint2*>(d + pl) = make_uint2(m0_, m1_); }
+        else if (step == 6) { l0 = cvt2(r0, r1); l1 = cvt2(r2, r3); }
+        else {
+          *reinterpret_cast<uint2*>(d + 2 * pl) = make_uint2(l0, l1);
+          // this float4's registers are free: fetch its successor (chunk kc+2)
+          if (f < A_PER_T) ra[f < A_PER_T ? f : 0] = *reinterpret_cast<const f32x4*>(asrc[f < A_PER_T ? f : 0] + kn * kBK);
+          else rb[f < A_PER_T ? 0 : f - A_PER_T] = *reinterpret_cast<const f32x4*>(bsrc + (f - A_PER_T) * b_step + kn * kBK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  }
+  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, false>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn);
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
                                    int ks, int mode, int rows_pad, int red4, int kpad) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,10 +716,19 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
 // (measured round 3, gemm ms per launch, 64x64 / 128x128 / 128x64: 104x104 64->128 0.347 / 0.299 / 0.335, 52x52 0.252 /
 // 0.219 / 0.234, 26x26 0.243 / 0.221 / 0.234, 13x13 512->1024 0.303 / 0.251 / 0.274, 1024->1024 0.585 / 0.490 / 0.540):
 // the matrix work of a tile is a third of the native kernel's, so the operand traffic per MFMA decides.
+// 'k' (round 4, split arithmetic only): 256x128 on 8 waves, two LDS stages (conv_gemm_split8_kernel).
 inline char batched_pick(long long rows, int cin, int cout) {
   static const char* env = getenv("FSD_WINO_TILE");
-  if (env) return env[0];
-  if (fsd_conv::f32_split_on()) return rows >= 96 && cout > 64 ? 'c' : 'a';
+  if (env) {
+    if (env[0] == 'k' && !fsd_conv::f32_split_on()) return 'c';
+    return env[0];
+  }
+  if (fsd_conv::f32_split_on()) {
+    static const char* k_env = getenv("FSD_WINO_SPLIT8");      // tuning aid: 0 keeps the 4-wave tiles everywhere
+    // (K <= 128: those launches are bound by the V / M traffic, where two 4-wave workgroups per CU hide each other's epilogue)
+    if (!(k_env && k_env[0] == '0') && rows >= 512 && cout >= 128 && cout % 128 == 0 && cin >= 256) return 'k';
+    return rows >= 96 && cout > 64 ? 'c' : 'a';
+  }
   return cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a';
 }
 
@@ -547,8 +756,8 @@ extern "C" int fsd_f32_gemm_mode(int mode) {
 
 int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
   const char pick = batched_pick(rows, cin, cout);
-  const int big = pick == 'c' || pick == 'd';
-  const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
+  const int big = pick == 'c' || pick == 'd' || pick == 'k';
+  const int bm = pick == 'k' ? 256 : (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   if (bm_out) *bm_out = bm;
   if (bn_out) *bn_out = bn;
   if (dma_out) *dma_out = pick == 'd';
@@ -570,8 +779,8 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.nk = cin / kBK;
   a.cpt = cin / kBK;
   const char pick = batched_pick(rows, cin, cout);
-  const int big = pick == 'c' || pick == 'd';
-  const int bm = (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
+  const int big = pick == 'c' || pick == 'd' || pick == 'k';
+  const int bm = pick == 'k' ? 256 : (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
   a.m_tiles = (int)((rows + bm - 1) / bm);
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
@@ -583,6 +792,13 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   static const char* flat_env = getenv("FSD_CONV_FLAT_XCD");        // tuning aid: 0 / 1 force the order
   a.flat_xcd = flat_env ? (flat_env[0] == '1') : (fsd_conv::f32_split_on() ? 1 : 0);
   a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
+  if (pick == 'k') {
+    constexpr size_t lds_k = 2 * 3 * (size_t)(256 + 128) * 64;        // two stages of three planes; >= the 256x128 fp32 tile
+    static_assert(lds_k >= (size_t)256 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
+    static const char* ilv_env = getenv("FSD_SPLIT8_ILV");               // tuning aid: 0 = split + stores as one block between the MFMA groups
+    if (ilv_env && ilv_env[0] == '0') return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, false>, a, lds_k, 512, stream);
+    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true>, a, lds_k, 512, stream);
+  }
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
   if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages

@@ -324,6 +324,156 @@ __global__ __launch_bounds__(kThreads, 3) void wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ---- 8-wave split weight-gradient GEMM for the batched Winograd reductions (round 4) ----------------------------------------
+// The twin of conv_gemm_split8_kernel (conv.hip) for  ws[b][split][co][ci] = sum_rows dy[b][row][co] * x[b][row][ci]:
+// 256 (co) x 128 (ci) tile on 8 waves (4 x 2, wave tile 64 x 64), 32-row chunks, TWO LDS stages of three bf16 planes.  A
+// thread stages 6 float4 per chunk instead of 8 for the same 48 MFMAs per wave, and their split + LDS stores are dealt out one
+// micro-step behind each MFMA (the 4-wave kernel above issues 12 instructions per MFMA in its main loop).  The operand tiles
+// stay 128-channel SUB-tiles ([32 rows][128 channels] bf16, 16-byte pieces XOR-permuted by (row & 3) << 2): the swizzle and
+// the ds_read_b64_tr_b16 geometry of wgrad_kernel<128, ..., SPLIT> carry over unchanged.  Whole 32-row chunks only (the
+// launcher sends the last < 32 rows through the 64x64 kernel into an extra workspace slot, like the DMA variant).
+__global__ __launch_bounds__(512, 2) void wgrad_split8_kernel(WgradArgs p) {
+  constexpr int PT = kBK * 128;                    // bf16 elements of one plane of one sub-tile
+  constexpr int STAGE = 9 * PT;                    // 3 sub-tiles (A0, A1, B) x 3 planes, in elements (72 KB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u16* sm = reinterpret_cast<u16*>(smem_raw);
+  const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int logical = fsd_conv::xcd_swizzle(flat, gridDim.x * gridDim.y * gridDim.z);
+  const int tile = logical % gridDim.x;
+  const int rest = logical / gridDim.x;
+  const int split = rest % gridDim.y;
+  const int zb = rest / gridDim.y;
+  p.dy += (long long)zb * p.dy_bs;
+  p.x += (long long)zb * p.x_bs;
+  p.ws += (long long)zb * p.ws_bs;
+  const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+  const int m0 = mt * 256, n0 = nt * 128;
+  const int p_begin = split * p.pix_per_split;
+  const int p_end = min(p.M, p_begin + p.pix_per_split);
+  const int nk = (p_end - p_begin) / kBK;          // whole chunks (launcher)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int cq = tid & 31, kr = tid >> 5;          // 4-channel column group / first row (second: + 16)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    // float4 f = 2 * s + j of this thread: sub-tile s (0, 1: dy columns m0 + 128 s ...; 2: x columns n0 ...), row kr + 16 j
+    const float* src[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      const int sct = f >> 1, j = f & 1;
+      const long long row = (long long)p_begin + kr + 16 * j;
+      src[f] = sct < 2 ? p.dy + row * p.dy_ld + m0 + sct * 128 + cq * 4 : p.x + row * p.x_ld + n0 + cq * 4;
+    }
+    const long long a_step = (long long)kBK * p.dy_ld, b_step = (long long)kBK * p.x_ld;
+    const int st_off = kr * 128 + (((cq >> 1) ^ ((kr & 3) << 2)) << 3) + (cq & 1) * 4;     // elements; row + 16: + 2048
+    f32x4 rr[6];
+    auto gload = [&](int kc) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) rr[f] = *reinterpret_cast<const f32x4*>(src[f] + kc * (f < 4 ? a_step : b_step));
+    };
+    auto sstore = [&](u16* st) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        uint2 h, m, l;
+        fsd_conv::split3(rr[f], h, m, l);
+        u16* d = st + (f >> 1) * 3 * PT + st_off + (f & 1) * 2048;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + PT) = m;
+        *reinterpret_cast<uint2*>(d + 2 * PT) = l;
+      }
+    };
+    // transpose-read geometry of wgrad_kernel<128, ..., SPLIT>: 16-lane group G reads rows krow + (L >> 2), channels
+    // ch0 + 16 (G & 1) + 4 (L & 3); two reads (rows +0..3, +4..7) = the 8 consecutive rows of its channel one MFMA step wants
+    const int G = lane >> 4, Lq = lane & 15;
+    const int fmask = ((Lq >> 2) & 3) << 2;                       // swz(krow + (Lq >> 2)): krow is a multiple of 8
+    const int a_sub = (wm >> 1) * 3 * PT, a_ch = (wm & 1) * 64 + 16 * (G & 1) + 4 * (Lq & 3);
+    const int b_ch = wn * 64 + 16 * (G & 1) + 4 * (Lq & 3);
+    auto frag_at = [&](const u16* base, int ch, int krow) -> bf16x8 {
+      const u16* a = base + (krow + (Lq >> 2)) * 128 + (((ch >> 3) ^ fmask) << 3) + (ch & 7);
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a + 4 * 128));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 af[2][3][2], bf[2][3][2];
+    // fragment w (0, 1: A blocks i; 2, 3: B blocks j) of plane q, k-step ks
+    auto frag_one = [&](const u16* st, int ks, int q, int w) {
+      const int krow = ks * 16 + (G >> 1) * 8;
+      if (w < 2) af[ks][q][w] = frag_at(st + a_sub + q * PT, a_ch + w * 32, krow);
+      else bf[ks][q][w - 2] = frag_at(st + 6 * PT + q * PT, b_ch + (w - 2) * 32, krow);
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    auto cvt2 = [](float a, float b) -> unsigned {                     // one v_cvt_pk_bf16_f32
+      const f32x2 v = {a, b};
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    };
+    auto lo_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk << 16); };
+    auto hi_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk & 0xffff0000u); };
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};     // the six terms, smallest first
+
+    const int last = nk - 1;
+    gload(0);
+    sstore(sm);
+    gload(last < 1 ? last : 1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      u16* cur = sm + (kc & 1) * STAGE;
+      u16* nxt = sm + ((kc & 1) ^ 1) * STAGE;
+      const int kn = kc + 2 < last ? kc + 2 : last;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) frag_one(cur, 0, q, w);
+      unsigned h0, h1, m0_, m1_, l0, l1;
+      float r0, r1, r2, r3;
+#pragma unroll
+      for (int u = 0; u < 48; ++u) {
+        const int ks = u / 24, t = (u % 24) / 4, i = (u % 4) / 2, j = u % 2;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
+        if (u < 12) frag_one(cur, 1, u / 4, u % 4);                        // fragments of k-step 1: one (two reads) per MFMA
+        const int f = u / 8, step = u % 8;                               // split + store of float4 f of chunk kc+1, 8 micro-steps
+        const f32x4 v = rr[f];
+        u16* d = nxt + (f >> 1) * 3 * PT + st_off + (f & 1) * 2048;
+        if (step == 0) { h0 = cvt2(v[0], v[1]); h1 = cvt2(v[2], v[3]); }
+        else if (step == 1) { r0 = v[0] - lo_f(h0); r1 = v[1] - hi_f(h0); }
+        else if (step == 2) { r2 = v[2] - lo_f(h1); r3 = v[3] - hi_f(h1); *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1); }
+        else if (step == 3) { m0_ = cvt2(r0, r1); m1_ = cvt2(r2, r3); }
+        else if (step == 4) { r0 -= lo_f(m0_); r1 -= hi_f(m0_); }
+        else if (step == 5) { r2 -= lo_f(m1_); r3 -= hi_f(m1_); *reinterpret_cast<uint2*>(d + PT) = make_uint2(m0_, m1_); }
+        else if (step == 6) { l0 = cvt2(r0, r1); l1 = cvt2(r2, r3); }
+        else {
+          *reinterpret_cast<uint2*>(d + 2 * PT) = make_uint2(l0, l1);
+          rr[f] = *reinterpret_cast<const f32x4*>(src[f] + kn * (f < 4 ? a_step : b_step));   // its successor (chunk kc+2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* out = p.ws + (long long)split * p.Cout * p.ncols;
+  const int c_lane = lane & 31, r_lane = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + c_lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
+        if (m < p.Cout && n < p.ncols) out[(long long)m * p.ncols + n] = acc[i][j][r];
+      }
+    }
+}
+
 // dw[co][ci][ky][kx] = sum_s ws[s][co][tap*cin4 + ci].  Threads run along the workspace's fastest
 // dimension (coalesced reads); SY lanes share the split loop when there are many splits (small
 // layers) and are folded through LDS.  Fixed summation order -> deterministic.
@@ -616,12 +766,30 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
 // on the fp32 weight-gradient kernel (ks = 1).  Returns the number of splits through *splits_out.
 // Plan of a batched reduction GEMM: 128x128 DMA-staged tiles over the full 32-row chunks when both channel counts
 // are multiples of 128 (+ one extra workspace slot filled by the 64x64 kernel for the last < 32 rows), else 64x64.
-struct BatchedPlan { bool dma; int splits; int tail_rows; int slots; };
+struct BatchedPlan { bool dma; int splits; int tail_rows; int slots; bool s8; };
 inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) {
   static const char* env = getenv("FSD_WGRAD_DMA");         // tuning aid: 0 disables the DMA variant
   const bool allow = !(env && env[0] == '0') && f32_variant() == 0 && !fsd_conv::f32_split_on();
   BatchedPlan pl;
+  pl.s8 = false;
   const long long full = rows / kBK * kBK;
+  static const char* env8 = getenv("FSD_WGRAD_SPLIT8");     // tuning aid: 0 keeps the 4-wave split kernel
+  if (fsd_conv::f32_split_on() && f32_variant() == 0 && !(env8 && env8[0] == '0') && cout % 256 == 0 && cin % 128 == 0 &&
+      cin >= 256 && full >= 8 * kBK) {     // (cin = 128: measured equal or slower than the 4-wave kernel)
+    // split arithmetic: 256x128 tiles on 8 waves, one workgroup per CU (wgrad_split8_kernel); ~4 rounds of the 256 CUs
+    pl.s8 = true;
+    pl.dma = false;
+    const int tiles = (cout / 256) * (cin / 128) * batches;
+    const long long max_s = full / (8 * kBK);
+    static const char* env_t = getenv("FSD_WGRAD_S8_TARGET");
+    const int target = env_t && atoi(env_t) > 0 ? atoi(env_t) : 1024;
+    int sp = (target + tiles - 1) / tiles;
+    if (sp > max_s) sp = (int)max_s;
+    pl.splits = sp < 1 ? 1 : sp;
+    pl.tail_rows = (int)(rows - full);
+    pl.slots = pl.splits + (pl.tail_rows ? 1 : 0);
+    return pl;
+  }
   // measured (tools/layer_bench.py wgrad): +5-7 % on the 1024/1280-channel layers, +2 % at 512, -2 % at 128/256
   pl.dma = allow && cout % 128 == 0 && cin % 128 == 0 && cin >= 512 && cout >= 512 && full >= 8 * kBK;
   if (pl.dma) {
@@ -660,17 +828,24 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
   a.dy_bs = dy_bs; a.x_bs = x_bs; a.ws_bs = (long long)pl.slots * cout * cin;
   a.x_scale = a.x_shift = nullptr; a.x_slope = 1.f;
   *splits_out = pl.slots;
-  if (pl.dma) {
+  if (pl.dma || pl.s8) {
     const long long full = rows - pl.tail_rows;
     a.H = 1; a.W = (int)full; a.HW = (int)full; a.M = (int)full;
-    a.m_tiles = cout / 128;
+    a.m_tiles = cout / (pl.s8 ? 256 : 128);
     a.n_tiles = cin / 128;
     a.pix_per_split = round_up((int)((full + pl.splits - 1) / pl.splits), kBK);
-    const size_t lds = 2 * (size_t)(2 * kBK * 128) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    {
+    if (pl.s8) {
+      const size_t lds = 2 * (size_t)9 * kBK * 128 * sizeof(u16);       // two stages x 3 sub-tiles x 3 planes
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
+      hipLaunchKernelGGL(wgrad_split8_kernel, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), dim3(512), lds, stream, a);
+    } else {
+      const size_t lds = 2 * (size_t)(2 * kBK * 128) * sizeof(float);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
       fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
       hipLaunchKernelGGL((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
                          dim3(kThreads), lds, stream, a);

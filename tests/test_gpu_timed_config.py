@@ -55,7 +55,10 @@ def test_wgrad_dma128_variant_matches_fp64(dev, gemm_mode, B, H, W, cin, cout, t
     L = ops.lib()
     T = B * ((H + 3) // 4) * ((W + 3) // 4)
     dma, splits, tail_rows, slots = _plan(L.fsd_wino_wgrad_plan, B, H, W, cin, cout)
-    if gemm_mode == "split":
+    if gemm_mode == "split" and T >= 256 and cout % 256 == 0 and cin % 128 == 0 and cin >= 256:
+        # the 8-wave 256x128 split kernel: whole 32-row chunks + a 64x64 side launch for the rest (like the DMA variant)
+        assert dma == 0 and tail_rows == tail == T % 32 and slots == splits + (1 if tail else 0), (dma, splits, tail_rows)
+    elif gemm_mode == "split":
         assert dma == 0 and tail_rows == 0 and slots == splits >= 1      # one register-staged launch covers every row
     elif T >= 256:
         assert dma == 1 and tail_rows == tail == T % 32 and slots == splits + (1 if tail else 0), (dma, splits, tail_rows)
@@ -91,10 +94,13 @@ def test_wino_gemm_dma128_multi_tile_matches_fp64(dev, gemm_mode, B, H, W, cin, 
     from fewshot_detection_amd import ops
     L = ops.lib()
     want_dma = 1 if gemm_mode == "native" else 0
+    T = B * 16                                                        # 4x4 tiles of a 13x13 map
+    # split arithmetic, >= 512 tile rows: the 8-wave 256x128 kernel (conv_gemm_split8_kernel); below that 128x128
+    want = (256, 128, 0, (T + 255) // 256) if gemm_mode == "split" and T >= 512 else (128, 128, want_dma, m_tiles)
     bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cin, cout)
-    assert (bm, bn, dma, mt) == (128, 128, want_dma, m_tiles)
+    assert (bm, bn, dma, mt) == want
     bm, bn, dma, mt = _plan(L.fsd_wino_fwd_plan, B, H, W, cout, cin)      # the data gradient swaps the roles
-    assert (bm, bn, dma, mt) == (128, 128, want_dma, m_tiles)
+    assert (bm, bn, dma, mt) == want
     g = torch.Generator().manual_seed(cin + B)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
