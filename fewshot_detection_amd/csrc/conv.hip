@@ -392,7 +392,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 //   * with two stages the split + LDS stores of chunk k+1 sit BETWEEN the two MFMA groups of chunk k (one barrier per chunk).
 // Plain GEMM rows only (the batched launches of conv_gemm_batched: 1x1 taps, Cin % 32 == 0, no activation on load); rows past
 // M are clamped on load and never stored.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV>
+// ACT: activation on load (p.in_scale, see ConvArgs): x = leaky(y * scale[k] + shift[k]) is formed in the staging registers, one
+// value per micro-step, a chunk ahead of its split.  ACT = 1: 0 <= in_slope <= 1, leaky(t) = max(t, t * slope) (the bits of
+// affine_act4's select, one instruction less); ACT = 2: any slope, the select itself.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV, int ACT = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   static_assert(NT == 512, "8 waves");
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
   p.w = static_cast<const float*>(p.w) + (long long)batch * p.w_bs;
   p.y += (long long)batch * p.y_bs;
   const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = p.m_base + mt * BM, n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int kq = tid & 7, g8 = tid >> 3;
@@ -478,12 +481,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
   bf16x8 af[2][3][TM], bf[2][3][TN];
   auto frags = [&](const unsigned char* st, int s) {
     const int po = ((2 * s + fh) ^ fsw) << 4;
+    // in the order the six terms first use them (A plane 0 with B plane 2, A 2 with B 0, A 1 with B 1): the first MFMAs of a
+    // chunk wait for 4 reads, not 12
+    constexpr int QA[3] = {0, 2, 1}, QB[3] = {2, 0, 1};
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int o = 0; o < 3; ++o) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[s][q][i] = *reinterpret_cast<const bf16x8*>(st + fa_off + q * PLANE_A + i * 32 * ROWB + po);
+      for (int i = 0; i < TM; ++i) af[s][QA[o]][i] = *reinterpret_cast<const bf16x8*>(st + fa_off + QA[o] * PLANE_A + i * 32 * ROWB + po);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s][q][j] = *reinterpret_cast<const bf16x8*>(st + fb_off + q * PLANE_B + j * 32 * ROWB + po);
+      for (int j = 0; j < TN; ++j) bf[s][QB[o]][j] = *reinterpret_cast<const bf16x8*>(st + fb_off + QB[o] * PLANE_B + j * 32 * ROWB + po);
     }
   };
   auto mfmas = [&](int s) {
@@ -532,9 +538,33 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
     auto lo_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk << 16); };
     auto hi_f = [](unsigned pk) -> float { return __builtin_bit_cast(float, pk & 0xffff0000u); };
     const int last = p.nk - 1;
+    // ACT: scale / shift of this thread's four input channels (kq * 4 ...) of one chunk
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    const float slope = p.in_slope;
+    auto load_sc = [&](int kc) {
+      sc = *reinterpret_cast<const f32x4*>(p.in_scale + kc * kBK + kq * 4);
+      sh = *reinterpret_cast<const f32x4*>(p.in_shift + kc * kBK + kq * 4);
+    };
+    auto act1 = [&](float v, int e) -> float {
+      const float t = __builtin_fmaf(v, sc[e], sh[e]);
+      if constexpr (ACT == 2) return t > 0.f ? t : t * slope;
+      return __builtin_fmaxf(t, t * slope);
+    };
     gload(0);
+    if constexpr (ACT) {
+      load_sc(0);
+#pragma unroll
+      for (int j = 0; j < A_PER_T; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[j][e] = act1(ra[j][e], e);
+    }
     sstore(sm);
     gload(last < 1 ? last : 1);
+    if constexpr (ACT) {           // steady state at the top of an iteration: ra[0] activated, ra[1..] raw, (sc, sh) of that chunk
+      load_sc(last < 1 ? last : 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ra[0][e] = act1(ra[0][e], e);
+    }
     __syncthreads();
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
     for (int kc = 0; kc < p.nk; ++kc) {
@@ -555,6 +585,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
           else bf[1][q][w - 2] = *reinterpret_cast<const bf16x8*>(cur + fb_off + q * PLANE_B + (w - 2) * 32 * ROWB + po1);
         }
         const int f = u / 8, step = u % 8;                               // float4 f of this thread (0-3: A rows, 4-5: B rows)
+        if constexpr (ACT) {
+          // one value of the NEXT A float4 per even micro-step: ra[f + 1] (this chunk's successor, kc+1) under float4 0..2,
+          // ra[0] of chunk kc+2 (fetched at u = 7) under the last float4; (sc, sh) move on to chunk kc+2 in between (u = 32)
+          if (u == 32) load_sc(kn);
+          if (step % 2 == 0 && (f + 1 < A_PER_T || f == A_PER_T + B_PER_T - 1)) {
+            const int g = f + 1 < A_PER_T ? f + 1 : 0, e = step / 2;
+            ra[g][e] = act1(ra[g][e], e);
+          }
+        }
         const f32x4 v = f < A_PER_T ? ra[f < A_PER_T ? f : 0] : rb[f < A_PER_T ? 0 : f - A_PER_T];
         unsigned char* d = f < A_PER_T ? nxt + st_off + f * RPP * ROWB : nxt + 3 * PLANE_A + st_off + (f - A_PER_T) * RPP * ROWB;
         const int pl = f < A_PER_T ? PLANE_A : PLANE_B;
@@ -732,6 +771,20 @@ inline char batched_pick(long long rows, int cin, int cout) {
   return cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a';
 }
 
+// 1x1 convolutions on the 8-wave split kernel (K >= 256, whole 128-column tiles, >= 512 rows): OPT-IN, FSD_CONV1_SPLIT8=1.
+// Alone the kernel is 20-25 % faster than the 64x64 tiles on these launches (13x13 1024->512 0.104 -> 0.078 ms, 26x26 512->256
+// 0.098 -> 0.084, 52x52 256->128 0.106 -> 0.085) -- but a train step with the side streams on got SLOWER with it (27.0 -> 33.7 ms
+// on one box; 28.0 with one stream): a 144 KB workgroup needs a CU free of every other LDS user, and these launches run
+// beside the weight-gradient stream's small-LDS workgroups, which keep trickling onto every CU -- the critical-path launch
+// waits for the side kernel to drain instead of sharing the chip with it.  (The Winograd position GEMMs run beside the
+// weight-gradient stream's own 144 KB workgroups and LDS-free transforms: no such blocking.)  The row tiling (and with it the
+// number of BatchNorm partial rows, fsd_conv_row_tiles) does not depend on the activation arguments.
+inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw) {
+  static const char* env = getenv("FSD_CONV1_SPLIT8");
+  if (!(env && env[0] == '1')) return false;
+  return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 && pixels >= 512;
+}
+
 // -1: not decided yet (first use reads FSD_F32_SPLIT; default 1 = split arithmetic, FSD_F32_SPLIT=0 = native fp32 MFMA)
 std::atomic<int> g_f32_split{-1};
 
@@ -797,7 +850,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
     static_assert(lds_k >= (size_t)256 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
     static const char* ilv_env = getenv("FSD_SPLIT8_ILV");               // tuning aid: 0 = split + stores as one block between the MFMA groups
     if (ilv_env && ilv_env[0] == '0') return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, false>, a, lds_k, 512, stream);
-    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true>, a, lds_k, 512, stream);
+    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
   }
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
@@ -826,6 +879,7 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
 }
 
 extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize) {
+  if (split8_1x1(pixels, cin, cout, ksize, false)) return (int)(pixels / 256 + (pixels % 256 + 63) / 64);
   const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize, cout));
   return r.main_m_tiles + r.tail_m_tiles;
 }
@@ -872,6 +926,33 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
   a.nk = a.Kpad / kBK;
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
   const bool nchw = out_nchw != 0;
+  if (split8_1x1(pixels, cin, cout, ksize, nchw)) {
+    // 1x1 convolution = a plain GEMM over the pixel rows: the 8-wave 256x128 split kernel on the WHOLE 256-row tiles (its
+    // clamped rows past M would enter the BatchNorm sums), 64x64 tiles for the remaining < 256 rows
+    const int full_tiles = (int)(pixels / 256);
+    a.n_tiles = (cout + 127) / 128;
+    a.m_base = 0; a.part_base = 0; a.batches = 1; a.slope = slope;
+    a.wide = wide_ok(y, y_ld, cout);
+    a.flat_xcd = 0;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
+    a.x_bs = a.w_bs = a.y_bs = 0;
+    if (pixels % 256) {
+      ConvArgs t = a;
+      t.m_base = full_tiles * 256;
+      t.part_base = full_tiles;
+      t.m_tiles = (int)((pixels - t.m_base + 63) / 64);
+      t.n_tiles = (cout + 63) / 64;
+      const int rc = launch<64, 64, 2, 2, 1>(t, false, stream);
+      if (rc != 0) return rc;
+    }
+    a.m_tiles = full_tiles;
+    a.M = full_tiles * 256;            // the main launch sees whole tiles only
+    constexpr size_t lds_k = 2 * 3 * (size_t)(256 + 128) * 64;
+    if (in_scale && in_slope >= 0.f && in_slope <= 1.f)
+      return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 1>, a, lds_k, 512, stream);
+    if (in_scale) return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 2>, a, lds_k, 512, stream);
+    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
+  }
   const int cfg = tile_cfg(cin, ksize, cout, nchw);
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   const RowPlan plan = nchw ? RowPlan{(int)((pixels + bm - 1) / bm), 0} : plan_rows(pixels, cout, cfg);

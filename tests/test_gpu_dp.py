@@ -137,8 +137,13 @@ def _run_bench(extra, env_extra, nproc=2):
         sys.stderr.write("bench.py attempt %d failed:\n%s\n" % (attempt, out.stderr[-3000:]))
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count('{"metric"') == 1, out.stdout
-    start = out.stdout.index('{"metric"')
-    return json.loads(out.stdout[start:].splitlines()[0])
+    compact = json.loads(out.stdout.strip().splitlines()[-1])         # the LAST stdout line is the compact record ...
+    assert len(out.stdout.strip().splitlines()[-1]) < 4096 and compact["n_gpus"] == nproc and "roofline" in compact
+    full = [ln for ln in out.stderr.splitlines() if ln.startswith("bench_full ")]
+    assert len(full) == 1                                             # ... the verbose one goes to stderr (and a file)
+    res = json.loads(full[0][len("bench_full "):])
+    assert abs(res["value"] - compact["value"]) < 1e-3 * res["value"] + 1e-4
+    return res
 
 
 def test_bench_strong_scaling_two_ranks_on_one_gpu():

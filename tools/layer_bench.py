@@ -51,6 +51,9 @@ def main():
     batch = int(os.environ.get("FSD_LB_BATCH", "64"))
     global SHAPES
     SHAPES = [(batch,) + s[1:] for s in SHAPES]
+    if os.environ.get("FSD_LB_ONLY"):                 # "H,cin,cout" filters the shape list (PMC runs on one layer)
+        h, ci, co = (int(v) for v in os.environ["FSD_LB_ONLY"].split(","))
+        SHAPES = [s for s in SHAPES if (s[1], s[3], s[4]) == (h, ci, co)]
     if os.environ.get("FSD_LB_SWAP") == "1":       # the data-gradient shapes: channel counts swapped
         SHAPES = [(b, h, w, co, ci, k) for b, h, w, ci, co, k in SHAPES if k == 3 and ci >= 64]
     if os.environ.get("FSD_WINO4") == "0":
