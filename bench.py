@@ -660,7 +660,7 @@ def backbone_forward(dyn_cfg, dtype, dev, B, S):
 def inference_latency(leg, dev, S):
     """valid_ensemble.py's shape: 2 query images per batch through the eval-mode detect_forward with fixed (ensembled)
     reweighting vectors; eager with the unfolded BatchNorm, the inference form (folded), and its hipGraph replay."""
-    from fewshot_detection_amd import engine
+    from fewshot_detection_amd import engine, ops
     net = leg.net
     was_training = net.training
     net.eval()
@@ -677,6 +677,12 @@ def inference_latency(leg, dev, S):
                     with torch.no_grad():
                         return net.detect_forward(x, vec)
                 res[name] = timed(f, n=50 if b == 2 else 10, w=5) * 1e3
+                if name == "eager_folded":          # kernels of ONE forward in the inference form (the graph replays the same ones)
+                    torch.cuda.synchronize()
+                    ops.launch_count(reset=True)
+                    f()
+                    torch.cuda.synchronize()
+                    res["kernels"] = ops.launch_count(reset=True)
             res["img_per_s_graph"] = b / (res["graph_folded"] * 1e-3)
             out["batch_%d" % b] = res
     finally:

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "fsd_profile_enable": (None, [_i]),
     "fsd_profile_num_classes": (_i, []),
     "fsd_profile_collect": (_i, [_p, _p, _p, _i]),
+    "fsd_launch_count": (_ll, [_i]),
     "fsd_clock_probe": (_i, [_p, _i, _p, _p]),
     "fsd_f32_gemm_mode": (_i, [_i]),
     "fsd_version": (C.c_char_p, []),

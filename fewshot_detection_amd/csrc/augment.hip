@@ -118,6 +118,6 @@ extern "C" int fsd_augment_batch(const unsigned char* src, const long long* img_
   if (blocks > 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   // algorithmic bytes: 3 source bytes gathered + 12 / 16 bytes written per output pixel
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)a.total * (3.0 + (layout ? 16.0 : 12.0)), stream);
-  hipLaunchKernelGGL(augment_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  FSD_LAUNCH(augment_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -306,11 +306,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 inline void launch_reduce_partials(const float* partial, double* slots, int rows, int two_c, int n_slots, hipStream_t stream) {
   if (two_c <= 64)
-    hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
+    FSD_LAUNCH(reduce_partials_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
   else if (two_c <= 128)
-    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
+    FSD_LAUNCH(reduce_partials_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
   else
-    hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
+    FSD_LAUNCH(reduce_partials_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, rows, two_c, n_slots);
 }
 
 // dgamma/dbeta (or dbias) and the per-channel coefficients of  dy = c1 * (dt - c2 - xhat * c3)
@@ -730,27 +730,27 @@ int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long lo
     const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
     a.ppb = 4 * cells_per_block(cells);
     const dim3 grid(blocks_for(cells, a.ppb / 4), (cg + gl - 1) / gl);
-    if (gl == 8) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 8>), grid, dim3(256), 0, stream, a);
-    else if (gl == 16) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 16>), grid, dim3(256), 0, stream, a);
-    else if (gl == 32) hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 32>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((act_bwd_pool2_kernel<T, 64>), grid, dim3(256), 0, stream, a);
+    if (gl == 8) FSD_LAUNCH((act_bwd_pool2_kernel<T, 8>), grid, dim3(256), 0, stream, a);
+    else if (gl == 16) FSD_LAUNCH((act_bwd_pool2_kernel<T, 16>), grid, dim3(256), 0, stream, a);
+    else if (gl == 32) FSD_LAUNCH((act_bwd_pool2_kernel<T, 32>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((act_bwd_pool2_kernel<T, 64>), grid, dim3(256), 0, stream, a);
     return (int)hipGetLastError();
   }
   a.ppb = pix_per_block(a.pixels);
   const dim3 grid(blocks_for(a.pixels, a.ppb), (cg + gl - 1) / gl);
   if constexpr (std::is_same<T, float>::value) {
     if (!dt && pool == 0 && !dz_full) {
-      if (gl == 8) hipLaunchKernelGGL((act_stats_kernel<8>), grid, dim3(256), 0, stream, a);
-      else if (gl == 16) hipLaunchKernelGGL((act_stats_kernel<16>), grid, dim3(256), 0, stream, a);
-      else if (gl == 32) hipLaunchKernelGGL((act_stats_kernel<32>), grid, dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL((act_stats_kernel<64>), grid, dim3(256), 0, stream, a);
+      if (gl == 8) FSD_LAUNCH((act_stats_kernel<8>), grid, dim3(256), 0, stream, a);
+      else if (gl == 16) FSD_LAUNCH((act_stats_kernel<16>), grid, dim3(256), 0, stream, a);
+      else if (gl == 32) FSD_LAUNCH((act_stats_kernel<32>), grid, dim3(256), 0, stream, a);
+      else FSD_LAUNCH((act_stats_kernel<64>), grid, dim3(256), 0, stream, a);
       return (int)hipGetLastError();
     }
   }
-  if (gl == 8) hipLaunchKernelGGL((act_bwd_kernel<T, 8>), grid, dim3(256), 0, stream, a);
-  else if (gl == 16) hipLaunchKernelGGL((act_bwd_kernel<T, 16>), grid, dim3(256), 0, stream, a);
-  else if (gl == 32) hipLaunchKernelGGL((act_bwd_kernel<T, 32>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((act_bwd_kernel<T, 64>), grid, dim3(256), 0, stream, a);
+  if (gl == 8) FSD_LAUNCH((act_bwd_kernel<T, 8>), grid, dim3(256), 0, stream, a);
+  else if (gl == 16) FSD_LAUNCH((act_bwd_kernel<T, 16>), grid, dim3(256), 0, stream, a);
+  else if (gl == 32) FSD_LAUNCH((act_bwd_kernel<T, 32>), grid, dim3(256), 0, stream, a);
+  else FSD_LAUNCH((act_bwd_kernel<T, 64>), grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -781,13 +781,13 @@ extern "C" int fsd_bn_bwd_finalize(const float* partial, int rows, long long cou
   if (!partial || !workspace || rows < 1 || channels < 1 || count < 1) return FSD_ERR_ARG;
   const int n_slots = rows < kSlots ? rows : kSlots;
   if (rows <= kSlots) {                 // one row per slot: finalize reads the partial sums directly
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, partial, n_slots,
+    FSD_LAUNCH(bn_bwd_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, partial, n_slots,
                        (double)count, channels, scale, dgamma, dbeta, coef);
     return (int)hipGetLastError();
   }
   const int two_c = 2 * channels;
   launch_reduce_partials(partial, reinterpret_cast<double*>(workspace), rows, two_c, n_slots, stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
+  FSD_LAUNCH(bn_bwd_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, scale, dgamma, dbeta,
                      coef);
   return (int)hipGetLastError();
@@ -806,13 +806,13 @@ int bn_bwd_apply_impl(T* dt, const T* y, long long y_ld, const float* coef, cons
     if (channels % 8 == 0 && y_ld % 8 == 0 && !(reinterpret_cast<uintptr_t>(dt) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
         !(env && env[0] == '0')) {
       const long long total8 = pixels * (channels / 8);
-      hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(blocks_for(total8, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
+      FSD_LAUNCH(bn_bwd_apply8_kernel, dim3(blocks_for(total8, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
                          invstd, channels, total8);
       return (int)hipGetLastError();
     }
   }
   const long long total = pixels * (channels / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
+  FSD_LAUNCH(bn_bwd_apply_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dt, y, y_ld, coef, mean,
                      invstd, channels, total);
   return (int)hipGetLastError();
 }
@@ -822,7 +822,7 @@ int colsum_impl(const T* m, long long ld, float* partial, long long rows, int ch
   (void)hipGetLastError();
   if (!m || !partial || rows < 1 || channels < 1) return FSD_ERR_ARG;
   const int ppb = pix_per_block(rows);      // partial rows = fsd_act_bwd_rows(rows)
-  hipLaunchKernelGGL(colsum_kernel<T>, dim3(blocks_for(rows, ppb), (channels + 255) / 256), dim3(256), 0, stream, m,
+  FSD_LAUNCH(colsum_kernel<T>, dim3(blocks_for(rows, ppb), (channels + 255) / 256), dim3(256), 0, stream, m,
                      ld, partial, channels, rows, ppb);
   return (int)hipGetLastError();
 }
@@ -834,7 +834,7 @@ int reorg_bwd_impl(const T* dout, long long dout_ld, T* dx, long long dx_ld, int
   if (!dout || !dx || stride < 1 || height % stride || width % stride || (channels & 3) || (dout_ld & 3) || (dx_ld & 3))
     return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * (channels / 4);
-  hipLaunchKernelGGL(reorg_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, dout_ld, dx, dx_ld,
+  FSD_LAUNCH(reorg_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, dout_ld, dx, dx_ld,
                      height, width, channels, stride, total);
   return (int)hipGetLastError();
 }
@@ -845,7 +845,7 @@ int global_maxpool_bwd_impl(const float* dout, const int* argmax, T* dx, long lo
   (void)hipGetLastError();
   if (!dout || !argmax || !dx) return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * channels;
-  hipLaunchKernelGGL(global_max_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, argmax, dx, dx_ld,
+  FSD_LAUNCH(global_max_bwd_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, argmax, dx, dx_ld,
                      height * width, channels, total);
   return (int)hipGetLastError();
 }
@@ -856,7 +856,7 @@ int add_inplace_impl(T* dst, long long dst_ld, const T* src, long long src_ld, l
   (void)hipGetLastError();
   if (!dst || !src || rows < 1 || channels < 1) return FSD_ERR_ARG;
   const long long total = rows * channels;
-  hipLaunchKernelGGL(add_inplace_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dst, dst_ld, src, src_ld,
+  FSD_LAUNCH(add_inplace_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dst, dst_ld, src, src_ld,
                      channels, total);
   return (int)hipGetLastError();
 }
@@ -888,11 +888,11 @@ extern "C" int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float*
   fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * ((double)batch * OH * OW + (dz_full ? 3.0 : 2.0) * pixels), stream);
   if (pool == 0) {
     const long long total = pixels * (channels / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
+    FSD_LAUNCH(bn_bwd_apply_g_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
                        dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
   } else {
     const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_g_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
+    FSD_LAUNCH(bn_bwd_apply_g_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
                        dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
   }
   return (int)hipGetLastError();
@@ -918,11 +918,11 @@ extern "C" int fsd_bn_bwd_apply_g_h(const void* dz, long long dz_ld, const void*
   bf16_t* dyh = static_cast<bf16_t*>(dy);
   if (pool == 0) {
     const long long total = pixels * (channels / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_g8_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+    FSD_LAUNCH(bn_bwd_apply_g8_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
                        yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
   } else {
     const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_g8_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+    FSD_LAUNCH(bn_bwd_apply_g8_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
                        yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
   }
   return (int)hipGetLastError();
@@ -970,7 +970,7 @@ extern "C" int fsd_head_unfold_bwd(const float* dweff, const float* head_w, cons
                                    float* d_dyn, int n_cls, int out_ch, int channels, hipStream_t stream) {
   (void)hipGetLastError();
   if (!dweff || !head_w || !dyn || !d_head_w || !d_dyn) return FSD_ERR_ARG;
-  hipLaunchKernelGGL(head_unfold_kernel, dim3((channels + 255) / 256, out_ch + n_cls), dim3(256), 0, stream, dweff,
+  FSD_LAUNCH(head_unfold_kernel, dim3((channels + 255) / 256, out_ch + n_cls), dim3(256), 0, stream, dweff,
                      head_w, dyn, d_head_w, d_dyn, n_cls, out_ch, channels);
   return (int)hipGetLastError();
 }
@@ -983,7 +983,7 @@ extern "C" int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, fl
   long long blocks = (count + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   fsd_prof::Scope prof(fsd_prof::kSgd, 20.0 * count, stream);          // w, g, m read; w, m written
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, grad, momentum_buf, lr, momentum,
+  FSD_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, grad, momentum_buf, lr, momentum,
                      weight_decay, first_step, count);
   return (int)hipGetLastError();
 }

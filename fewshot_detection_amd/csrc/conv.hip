@@ -678,7 +678,7 @@ int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t s
   // issued MFMA work of this launch: every output row x column x (padded) reduction element, all batches
   const double rows = (double)a.M - (double)a.m_base;
   fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * rows * a.Cout * ((double)a.nk * kBK) * a.batches, stream);
-  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, a.batches), dim3(threads), lds, stream, a);
+  FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, a.batches), dim3(threads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -873,7 +873,7 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   const int rows_pad = round_up(rows, 128), red4 = round_up(red, 4);
   const int kpad = round_up(ksize * ksize * red4, kBK);
   const long long total = (long long)rows_pad * kpad;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw,
+  FSD_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw,
                      w_packed, cout, cin, ksize, mode, rows_pad, red4, kpad);
   return (int)hipGetLastError();
 }

@@ -132,9 +132,9 @@ extern "C" int fsd_pack_conv_weight_bf16_pair(const float* w_oihw, void* w_fwd_b
   unsigned short* o0 = static_cast<unsigned short*>(w_fwd_bf16);
   unsigned short* o1 = static_cast<unsigned short*>(w_dgrad_bf16);
   if (taps == 9)
-    hipLaunchKernelGGL(pack_weight_bf16_pair_kernel<9>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
+    FSD_LAUNCH(pack_weight_bf16_pair_kernel<9>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
   else
-    hipLaunchKernelGGL(pack_weight_bf16_pair_kernel<1>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
+    FSD_LAUNCH(pack_weight_bf16_pair_kernel<1>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
   return (int)hipGetLastError();
 }
 
@@ -151,7 +151,7 @@ extern "C" int fsd_pack_conv_weight_bf16(const float* w_oihw, void* w_packed_bf1
   const int rows_pad = round_up(rows, 128), red4 = round_up(red, 4);
   const int kpad = round_up(ksize * ksize * red4, kBKh);
   const long long total = (long long)rows_pad * kpad;
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw,
+  FSD_LAUNCH(pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw,
                      static_cast<unsigned short*>(w_packed_bf16), cout, cin, ksize, mode, rows_pad, red4, kpad);
   return (int)hipGetLastError();
 }

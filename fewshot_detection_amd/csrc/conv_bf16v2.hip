@@ -418,7 +418,7 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
       auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true, ILV, NS>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+      FSD_LAUNCH(k, grid, block, lds, stream, a);
     } else {
       return FSD_ERR_UNSUPPORTED;
     }
@@ -426,7 +426,7 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
     auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+    FSD_LAUNCH(k, grid, block, lds, stream, a);
   }
   return (int)hipGetLastError();
 }
@@ -838,17 +838,17 @@ int launch_wgrad_h_fold(float* ws, float* dw, int splits, int cout, int cin, int
   float* dst = ws + (long long)splits * total;          // ping: behind the slices; pong: over the (consumed) first slices
   while (splits > kFoldDirect) {
     const int groups = (splits + kFoldGroup - 1) / kFoldGroup;
-    hipLaunchKernelGGL(wgrad_h_partial_kernel, dim3((unsigned)((total + 255) / 256), groups), dim3(256), 0, stream, src, dst,
+    FSD_LAUNCH(wgrad_h_partial_kernel, dim3((unsigned)((total + 255) / 256), groups), dim3(256), 0, stream, src, dst,
                        splits, total);
     float* t = src; src = dst; dst = t;
     splits = groups;
   }
   if (taps == 9) {
     const unsigned wgs = (unsigned)cout * ((cin + 63) / 64);
-    hipLaunchKernelGGL((wgrad_h_fold_kernel<9, 64>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
+    FSD_LAUNCH((wgrad_h_fold_kernel<9, 64>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
   } else {
     const unsigned wgs = (unsigned)cout * ((cin + 255) / 256);
-    hipLaunchKernelGGL((wgrad_h_fold_kernel<1, 256>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
+    FSD_LAUNCH((wgrad_h_fold_kernel<1, 256>), dim3(wgs), dim3(256), 0, stream, src, dw, splits, cout, cin);
   }
   return (int)hipGetLastError();
 }
@@ -1103,7 +1103,7 @@ int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
+  FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1161,7 +1161,7 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
     auto k = wgrad_bf16_tr8_kernel<64>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(512), lds, stream, a);
+    FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(512), lds, stream, a);
     rc = (int)hipGetLastError();
   }
   else if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);

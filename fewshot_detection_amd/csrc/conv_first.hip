@@ -155,7 +155,7 @@ int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const f
   const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
   a.ppw = (int)((per + 63) / 64 * 64);
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + (double)sizeof(TO) * cout), stream);
-  hipLaunchKernelGGL(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+  FSD_LAUNCH(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 
 inline void launch_bn_reduce(const float* partial, double* slots, int tiles, int two_c, int n_slots, hipStream_t stream) {
   if (two_c <= 64)
-    hipLaunchKernelGGL(bn_reduce_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
+    FSD_LAUNCH(bn_reduce_kernel<4>, dim3(n_slots, (two_c + 63) / 64), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
   else if (two_c <= 128)
-    hipLaunchKernelGGL(bn_reduce_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
+    FSD_LAUNCH(bn_reduce_kernel<2>, dim3(n_slots, (two_c + 127) / 128), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
   else
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
+    FSD_LAUNCH(bn_reduce_kernel<1>, dim3(n_slots, (two_c + 255) / 256), dim3(256), 0, stream, partial, slots, tiles, two_c, n_slots);
 }
 
 // S = double: `slots` from bn_reduce_kernel.  S = float: the per-tile partial sums themselves, when there are no more rows
@@ -331,7 +331,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
     if (!bn_partial || !workspace || row_tiles < 1 || count < 1) return FSD_ERR_ARG;
     n_slots = row_tiles < kBnSlots ? row_tiles : kBnSlots;
     if (row_tiles <= kBnSlots) {          // one row per slot: finalize reads the partial sums directly
-      hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, bn_partial, n_slots,
+      FSD_LAUNCH(bn_finalize_kernel<float>, dim3((channels + 31) / 32), dim3(256), 0, stream, bn_partial, n_slots,
                          (double)count, channels, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift,
                          save_mean, save_invstd);
       return (int)hipGetLastError();
@@ -339,7 +339,7 @@ extern "C" int fsd_bn_finalize(const float* bn_partial, int row_tiles, long long
     const int two_c = 2 * channels;
     launch_bn_reduce(bn_partial, reinterpret_cast<double*>(workspace), row_tiles, two_c, n_slots, stream);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
+  FSD_LAUNCH(bn_finalize_kernel<double>, dim3((channels + 31) / 32), dim3(256), 0, stream,
                      reinterpret_cast<const double*>(workspace), n_slots, (double)count, channels, gamma, beta,
                      running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_invstd);
   return (int)hipGetLastError();
@@ -365,11 +365,11 @@ int bn_act_pool_impl(const T* y, long long y_ld, const float* scale, const float
       const long long total8 = (long long)batch * OH * OW * cg8;
       const dim3 grid8(blocks_for(total8, 256)), block8(256);
       if (pool == 0)
-        hipLaunchKernelGGL((bn_act_pool8_kernel<0>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+        FSD_LAUNCH((bn_act_pool8_kernel<0>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
       else if (pool == 1)
-        hipLaunchKernelGGL((bn_act_pool8_kernel<1>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+        FSD_LAUNCH((bn_act_pool8_kernel<1>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
       else
-        hipLaunchKernelGGL((bn_act_pool8_kernel<2>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
+        FSD_LAUNCH((bn_act_pool8_kernel<2>), grid8, block8, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg8, total8);
       return (int)hipGetLastError();
     }
   }
@@ -377,11 +377,11 @@ int bn_act_pool_impl(const T* y, long long y_ld, const float* scale, const float
   const long long total = (long long)batch * OH * OW * cg;
   const dim3 grid(blocks_for(total, 256)), block(256);
   if (pool == 0)
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, 0>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    FSD_LAUNCH((bn_act_pool_kernel<T, 0>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else if (pool == 1)
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, 1>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    FSD_LAUNCH((bn_act_pool_kernel<T, 1>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   else
-    hipLaunchKernelGGL((bn_act_pool_kernel<T, 2>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
+    FSD_LAUNCH((bn_act_pool_kernel<T, 2>), grid, block, 0, stream, y, y_ld, scale, shift, slope, z, z_ld, height, width, OH, OW, cg, total);
   return (int)hipGetLastError();
 }
 
@@ -409,7 +409,7 @@ int transpose_impl(const TS* src, long long src_batch_stride, long long src_row_
   if (!src || !dst || batch < 1 || rows < 1 || cols < 1 || batch > 65535) return FSD_ERR_ARG;
   const dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   if (grid.y > 65535) return FSD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((transpose_kernel<TS, TD>), grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
+  FSD_LAUNCH((transpose_kernel<TS, TD>), grid, dim3(256), 0, stream, src, src_batch_stride, src_row_stride, dst,
                      dst_batch_stride, dst_row_stride, rows, cols);
   return (int)hipGetLastError();
 }
@@ -444,7 +444,7 @@ extern "C" int fsd_nchw_to_nhwc4(const float* src, float* dst, int batch, int ch
   if (!src || !dst || batch < 1 || channels < 1 || channels > 4 || hw < 1) return FSD_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(dst) & 15)) return FSD_ERR_ARG;
   const long long total = (long long)batch * hw;
-  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, src, dst, channels, hw, total);
+  FSD_LAUNCH(nchw_to_nhwc4_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, src, dst, channels, hw, total);
   return (int)hipGetLastError();
 }
 
@@ -454,7 +454,7 @@ extern "C" int fsd_fill(float* dst, float value, long long count, hipStream_t st
   if (count == 0) return FSD_OK;
   long long blocks = (count + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, value, count);
+  FSD_LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, value, count);
   return (int)hipGetLastError();
 }
 
@@ -467,7 +467,7 @@ int reorg_impl(const T* x, long long x_ld, T* out, long long out_ld, int batch, 
   if (!x || !out || stride < 1 || height % stride || width % stride || (channels & 3) || (x_ld & 3) || (out_ld & 3))
     return FSD_ERR_ARG;
   const long long total = (long long)batch * height * width * (channels / 4);
-  hipLaunchKernelGGL(reorg_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, out_ld, height,
+  FSD_LAUNCH(reorg_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, out_ld, height,
                      width, channels, stride, total);
   return (int)hipGetLastError();
 }
@@ -479,7 +479,7 @@ int global_maxpool_impl(const T* x, long long x_ld, float* out, int* argmax, int
   if (!x || !out || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
   if (height != width) return FSD_ERR_UNSUPPORTED;   // pooling.py:23-27 assumes a square map
   const long long total = (long long)batch * channels;
-  hipLaunchKernelGGL(global_max_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, argmax,
+  FSD_LAUNCH(global_max_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, x_ld, out, argmax,
                      height * width, channels, total);
   return (int)hipGetLastError();
 }
@@ -512,7 +512,7 @@ extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, 
   (void)hipGetLastError();   // drop a stale error left by someone else's earlier call
   if (!x || !w || !out || batch < 1 || n_cls < 1 || channels < 1 || hw < 1) return FSD_ERR_ARG;
   const long long total = (long long)batch * n_cls * channels * hw;
-  hipLaunchKernelGGL(dynamic_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, w, out, n_cls,
+  FSD_LAUNCH(dynamic_conv_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, w, out, n_cls,
                      channels, hw, total);
   return (int)hipGetLastError();
 }
@@ -525,7 +525,7 @@ extern "C" int fsd_fold_reweight_head(const float* head_w, const float* head_b, 
   const int rows_pad = (n_cls * out_ch + 127) / 128 * 128;
   const int kpad = (channels + 31) / 32 * 32;
   const long long total = (long long)rows_pad * kpad;
-  hipLaunchKernelGGL(fold_head_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, head_w, head_b, dyn,
+  FSD_LAUNCH(fold_head_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, head_w, head_b, dyn,
                      w_eff_packed, bias_eff, n_cls, out_ch, channels, rows_pad, kpad);
   return (int)hipGetLastError();
 }

@@ -310,13 +310,13 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (sizeof(T) * cout * 1.25 + 16.0), stream);
   const dim3 grid(blocks, cout / 32);
   if (cin == 4) {
-    if (cpg == 1) hipLaunchKernelGGL((first_bwd_kernel<true, T, 1>), grid, dim3(256), 0, stream, a);
-    else if (cpg == 4) hipLaunchKernelGGL((first_bwd_kernel<true, T, 4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((first_bwd_kernel<true, T, 2>), grid, dim3(256), 0, stream, a);
+    if (cpg == 1) FSD_LAUNCH((first_bwd_kernel<true, T, 1>), grid, dim3(256), 0, stream, a);
+    else if (cpg == 4) FSD_LAUNCH((first_bwd_kernel<true, T, 4>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((first_bwd_kernel<true, T, 2>), grid, dim3(256), 0, stream, a);
   } else {
-    if (cpg == 1) hipLaunchKernelGGL((first_bwd_kernel<false, T, 1>), grid, dim3(256), 0, stream, a);
-    else if (cpg == 4) hipLaunchKernelGGL((first_bwd_kernel<false, T, 4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((first_bwd_kernel<false, T, 2>), grid, dim3(256), 0, stream, a);
+    if (cpg == 1) FSD_LAUNCH((first_bwd_kernel<false, T, 1>), grid, dim3(256), 0, stream, a);
+    else if (cpg == 4) FSD_LAUNCH((first_bwd_kernel<false, T, 4>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((first_bwd_kernel<false, T, 2>), grid, dim3(256), 0, stream, a);
   }
   return (int)hipGetLastError();
 }
@@ -358,7 +358,7 @@ extern "C" int fsd_first_layer_bwd_fold(const void* workspace, size_t workspace_
   if (workspace_bytes < fsd_first_layer_bwd_workspace_bytes(batch, height, width, cout)) return FSD_ERR_WORKSPACE;
   const int blocks = fb_blocks((long long)batch * height * width / 4);
   const float* ws = reinterpret_cast<const float*>(workspace);
-  hipLaunchKernelGGL(first_bwd_fold_kernel, dim3(cout, 36 / kFoldCols), dim3(256), 0, stream, ws, ws + (size_t)blocks * 2 * cout * 36, coef,
+  FSD_LAUNCH(first_bwd_fold_kernel, dim3(cout, 36 / kFoldCols), dim3(256), 0, stream, ws, ws + (size_t)blocks * 2 * cout * 36, coef,
                      dw_oihw, blocks, cout, cin);
   return (int)hipGetLastError();
 }

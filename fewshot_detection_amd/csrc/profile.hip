@@ -10,10 +10,17 @@ namespace {
 
 struct Rec { hipEvent_t e0, e1; int cls; double work; };
 std::atomic<int> g_on{0};
+std::atomic<long long> g_launches{0};
 std::mutex g_mu;
 std::vector<Rec*> g_recs;
 
 }  // namespace
+
+void fsd_prof::count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+
+extern "C" long long fsd_launch_count(int reset) {
+  return reset ? g_launches.exchange(0, std::memory_order_relaxed) : g_launches.load(std::memory_order_relaxed);
+}
 
 bool fsd_prof::enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
 

@@ -22,6 +22,7 @@ enum Class {
 };
 
 bool enabled();
+void count_launch();     // one relaxed increment per kernel launch of the library (fsd_launch_count)
 void begin(int cls, double work, hipStream_t stream, void** token);
 void end(void* token, hipStream_t stream);
 
@@ -39,4 +40,7 @@ struct Scope {
 };
 
 }  // namespace fsd_prof
+
+// every kernel launch of the library goes through this: the launch counter behind fsd_launch_count (include/fsdet.h)
+#define FSD_LAUNCH(...) do { fsd_prof::count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #endif  // FSD_PROFILE_HPP_

@@ -363,7 +363,7 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
   // algorithmic bytes of the loss: head output read once, its gradient written once, the float64 targets read once
   const double io_bytes = 2.0 * 4.0 * rows * (double)num_anchors * (5 + num_classes) * height * width + 8.0 * rows * (double)target_len;
   fsd_prof::Scope prof(fsd_prof::kRegion, io_bytes, stream);
-  hipLaunchKernelGGL(region_rows_kernel<false>, dim3(rows), dim3(kThreads), lds, stream, p);
+  FSD_LAUNCH(region_rows_kernel<false>, dim3(rows), dim3(kThreads), lds, stream, p);
 
   int groups, n_logits;
   long long stride;
@@ -374,9 +374,9 @@ extern "C" int fsd_region_loss_fwd_bwd(const float* output, const double* target
     groups = rows * cells; n_logits = num_classes;
     stride = (long long)height * width;
   }
-  hipLaunchKernelGGL(region_class_kernel, dim3((groups + kThreads - 1) / kThreads), dim3(kThreads), 0,
+  FSD_LAUNCH(region_class_kernel, dim3((groups + kThreads - 1) / kThreads), dim3(kThreads), 0,
                      stream, p, groups, n_logits, stride);
-  hipLaunchKernelGGL(region_finalize_kernel, dim3(1), dim3(1), 0, stream, p.stats, loss_out);
+  FSD_LAUNCH(region_finalize_kernel, dim3(1), dim3(1), 0, stream, p.stats, loss_out);
   return (int)hipGetLastError();
 }
 
@@ -404,7 +404,7 @@ extern "C" int fsd_region_build_targets(const float* pred_boxes, const double* t
                9 * (kThreads / 64) * sizeof(double);
   lds = (lds + 15) & ~(size_t)15;
   if (lds > 64 * 1024) return FSD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(region_rows_kernel<true>, dim3(rows), dim3(kThreads), lds, stream, p);
+  FSD_LAUNCH(region_rows_kernel<true>, dim3(rows), dim3(kThreads), lds, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -488,7 +488,7 @@ extern "C" int fsd_region_decode(const float* output, float* boxes, int* counts,
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * rows, stream);
   if (e != hipSuccess) return (int)e;
   const long long total = (long long)rows * num_anchors * height * width;
-  hipLaunchKernelGGL(region_decode_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, p);
+  FSD_LAUNCH(region_decode_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -572,7 +572,7 @@ extern "C" int fsd_region_nms(const float* boxes, const int* counts, int rows, i
   (void)hipGetLastError();
   if (!boxes || !counts || !keep_idx || !keep_counts || rows < 1 || cap < 1) return FSD_ERR_ARG;
   if (cap > kNmsMax) return FSD_ERR_UNSUPPORTED;          // also keeps slot and visiting order inside 16 bits
-  hipLaunchKernelGGL(region_nms_kernel, dim3(rows), dim3(kThreads), 0, stream, boxes, counts, cap, nms_thresh, keep_idx,
+  FSD_LAUNCH(region_nms_kernel, dim3(rows), dim3(kThreads), 0, stream, boxes, counts, cap, nms_thresh, keep_idx,
                      keep_counts);
   return (int)hipGetLastError();
 }

@@ -692,33 +692,33 @@ int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream, in
       if (a.ks == 1) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 1, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((wgrad_kernel<128, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
+        FSD_LAUNCH((wgrad_kernel<128, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
       } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 1, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((wgrad_kernel<128, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
+        FSD_LAUNCH((wgrad_kernel<128, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
       }
     } else {
       const size_t lds = 6 * (size_t)kBK * 64 * sizeof(u16);
-      if (a.ks == 1) hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
-      else hipLaunchKernelGGL((wgrad_kernel<64, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
+      if (a.ks == 1) FSD_LAUNCH((wgrad_kernel<64, 1, false, true, false, true>), grid, dim3(kThreads), lds, stream, a);
+      else FSD_LAUNCH((wgrad_kernel<64, 1, false, false, false, true>), grid, dim3(kThreads), lds, stream, a);
     }
   } else if (f32_variant() == 1) {
     const size_t lds = 2 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((wgrad_kernel<128, 2, false>), grid, dim3(kThreads), lds, stream, a);
+    FSD_LAUNCH((wgrad_kernel<128, 2, false>), grid, dim3(kThreads), lds, stream, a);
   } else if (f32_variant() == 2) {
     const size_t lds = 1 * (size_t)(2 * kBK * (128 + 4)) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_kernel<128, 1, false>), grid, dim3(kThreads), lds, stream, a);
+    FSD_LAUNCH((wgrad_kernel<128, 1, false>), grid, dim3(kThreads), lds, stream, a);
   } else if (f32_variant() == 3) {
     const size_t lds = 2 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
-    if (a.ks == 1) hipLaunchKernelGGL((wgrad_kernel<64, 2, false, true>), grid, dim3(kThreads), lds, stream, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 2, false>), grid, dim3(kThreads), lds, stream, a);
+    if (a.ks == 1) FSD_LAUNCH((wgrad_kernel<64, 2, false, true>), grid, dim3(kThreads), lds, stream, a);
+    else FSD_LAUNCH((wgrad_kernel<64, 2, false>), grid, dim3(kThreads), lds, stream, a);
   } else {
     const size_t lds = 1 * (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
-    if (a.ks == 1 && f32_variant() != 4) hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true>), grid, dim3(kThreads), lds, stream, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
+    if (a.ks == 1 && f32_variant() != 4) FSD_LAUNCH((wgrad_kernel<64, 1, false, true>), grid, dim3(kThreads), lds, stream, a);
+    else FSD_LAUNCH((wgrad_kernel<64, 1, false>), grid, dim3(kThreads), lds, stream, a);
   }
   return 0;
 }
@@ -752,10 +752,10 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   const dim3 grid(a.m_tiles * a.n_tiles, splits);
   if (int rc = launch_wgrad(a, bf16, grid, stream, tile)) return rc;
   if (splits <= 8)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
+    FSD_LAUNCH(wgrad_reduce_kernel<1>, dim3((a.ncols + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((a.ncols + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw,
+    FSD_LAUNCH(wgrad_reduce_kernel<8>, dim3((a.ncols + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw,
                        splits, cout, cin, cin4, ksize * ksize, a.ncols);
   return (int)hipGetLastError();
 }
@@ -840,14 +840,14 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
-      hipLaunchKernelGGL(wgrad_split8_kernel, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), dim3(512), lds, stream, a);
+      FSD_LAUNCH(wgrad_split8_kernel, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), dim3(512), lds, stream, a);
     } else {
       const size_t lds = 2 * (size_t)(2 * kBK * 128) * sizeof(float);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
-      hipLaunchKernelGGL((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
+      FSD_LAUNCH((wgrad_kernel<128, 2, false, true, true>), dim3(a.m_tiles * a.n_tiles, pl.splits, batches),
                          dim3(kThreads), lds, stream, a);
     }
     if (pl.tail_rows) {                                      // the last < 32 rows -> workspace slot `splits`
@@ -859,7 +859,7 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
       t.pix_per_split = kBK;
       const size_t lds1 = (size_t)(2 * kBK * (64 + 4)) * sizeof(float);
       fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * t.M * (double)cout * cin * batches, stream);
-      hipLaunchKernelGGL((wgrad_kernel<64, 1, false, true>), dim3(t.m_tiles * t.n_tiles, 1, batches), dim3(kThreads), lds1,
+      FSD_LAUNCH((wgrad_kernel<64, 1, false, true>), dim3(t.m_tiles * t.n_tiles, 1, batches), dim3(kThreads), lds1,
                          stream, t);
     }
     return (int)hipGetLastError();
@@ -913,13 +913,13 @@ int wgrad_first_impl(const T* dt, long long dt_ld, const T* y, long long y_ld, c
   a.ppw = round_up((int)((pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 16);
   {
     fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (2.0 * sizeof(T) * cout + 16.0), stream);
-    if (cin == 4) hipLaunchKernelGGL((wgrad_first_kernel<true, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((wgrad_first_kernel<false, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    if (cin == 4) FSD_LAUNCH((wgrad_first_kernel<true, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    else FSD_LAUNCH((wgrad_first_kernel<false, T>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   }
   if (blocks <= 8)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(1, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
+    FSD_LAUNCH(wgrad_reduce_kernel<1>, dim3(1, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(2, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
+    FSD_LAUNCH(wgrad_reduce_kernel<8>, dim3(2, cout), dim3(256), 0, stream, a.ws, dw_oihw, blocks, cout, cin, 4, 9, 36);
   return (int)hipGetLastError();
 }
 

@@ -906,13 +906,13 @@ extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int co
   const int rows_pad = round_up(rows, 128);
   const long long total = (long long)rows_pad * red;
   if (tile == 2)
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
+    FSD_LAUNCH(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, u_packed,
                        cout, cin, mode, rows, red, rows_pad);
   else if (red % 128 == 0)                 // rows_pad is a multiple of 128: whole blocks of 8 rows
-    hipLaunchKernelGGL(wino4_weight_wide_kernel<128>, dim3(red / 128, rows_pad / 8), dim3(256), 0, stream, w_oihw, u_packed, cout,
+    FSD_LAUNCH(wino4_weight_wide_kernel<128>, dim3(red / 128, rows_pad / 8), dim3(256), 0, stream, w_oihw, u_packed, cout,
                        cin, mode, rows, red, rows_pad);
   else                                     // red % 32 == 0 (checked above)
-    hipLaunchKernelGGL(wino4_weight_wide_kernel<32>, dim3(red / 32, rows_pad / 32), dim3(256), 0, stream, w_oihw, u_packed, cout,
+    FSD_LAUNCH(wino4_weight_wide_kernel<32>, dim3(red / 32, rows_pad / 32), dim3(256), 0, stream, w_oihw, u_packed, cout,
                        cin, mode, rows, red, rows_pad);
   return (int)hipGetLastError();
 }
@@ -973,13 +973,13 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
-      hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      FSD_LAUNCH(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
     else if (in_scale)
-      hipLaunchKernelGGL(wino4_input_kernel<true>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      FSD_LAUNCH(wino4_input_kernel<true>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T, in_scale, in_shift, in_slope);
     else
-      hipLaunchKernelGGL(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      FSD_LAUNCH(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
     V = Vw;
   }
@@ -991,19 +991,19 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   const unsigned bx = (unsigned)((T + tpb - 1) / tpb);
   fsd_prof::Scope prof_out(fsd_prof::kWinoXform, 4.0 * cout * ((double)batch * height * width + (double)P * T), stream);
   if (tile == 2) {
-    hipLaunchKernelGGL(wino_output_kernel, dim3(bx, (cout / 4 + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
+    FSD_LAUNCH(wino_output_kernel, dim3(bx, (cout / 4 + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
                        bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
     static const char* out4_env = getenv("FSD_WINO_OUT4");
     if (cout >= 128 && !(out4_env && out4_env[0] == '0'))
-      hipLaunchKernelGGL(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
+      FSD_LAUNCH(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);
     else if (cg <= 32)
-      hipLaunchKernelGGL(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
+      FSD_LAUNCH(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);
     else
-      hipLaunchKernelGGL(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
+      FSD_LAUNCH(wino4_output_kernel<64>, dim3(bx, (cg + 63) / 64), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   }
   return (int)hipGetLastError();
@@ -1059,10 +1059,10 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
     // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
-      hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      FSD_LAUNCH(wino_input_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T);
     else
-      hipLaunchKernelGGL(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
+      FSD_LAUNCH(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
     V = Vw;
   }
@@ -1070,10 +1070,10 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (!Wg) {
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cout * ((double)batch * height * width + (double)P * T), stream);
     if (tile == 2)
-      hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
+      FSD_LAUNCH(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
                          height, width, TH, TW, cout, T);
     else
-      hipLaunchKernelGGL(wino4_dy_kernel<0>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
+      FSD_LAUNCH(wino4_dy_kernel<0>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
                          const_cast<float*>(dy), dy_ld, Wt, height, width, TH, TW, cout, T, (const float*)nullptr, 0LL,
                          (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, DyFromG{});
     Wg = Wt;
@@ -1083,9 +1083,9 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (rc != 0) return rc;
   const long long n = (long long)cout * cin;
   if (tile == 2)
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
+    FSD_LAUNCH(wino_dw_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw_oihw, splits, cout, cin);
   else
-    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(192), 0, stream, ws, dw_oihw, splits, cout, cin);
+    FSD_LAUNCH(wino4_dw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(192), 0, stream, ws, dw_oihw, splits, cout, cin);
   return (int)hipGetLastError();
 }
 
@@ -1100,7 +1100,7 @@ extern "C" int fsd_wino_grad_transforms(const float* dt, long long dt_ld, const 
   if (T * (long long)channels >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
   const long long n = T * (channels / 2);
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (2.0 * batch * height * width + 2.0 * 36 * T), stream);
-  hipLaunchKernelGGL(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
+  FSD_LAUNCH(wino4_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, y, y_ld, coef,
                      mean, invstd, v_out, wt_out, height, width, TH, TW, channels, T);
   return (int)hipGetLastError();
 }
@@ -1117,7 +1117,7 @@ extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float*
   const long long n = T * (channels / 4);
   // reads dt and y, writes dy (in place) and the 36 transformed positions
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (3.0 * batch * height * width + 36.0 * T), stream);
-  hipLaunchKernelGGL(wino4_dy_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
+  FSD_LAUNCH(wino4_dy_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
                      height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, DyFromG{});
   return (int)hipGetLastError();
 }
@@ -1141,7 +1141,7 @@ extern "C" int fsd_wino_dy_bn_transform_g(const float* dz, long long dz_ld, cons
   const long long n = T * (channels / 4);
   // reads dz (+ dz_full) and y, writes dy and the 36 transformed positions
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * ((double)batch * gg.OH * gg.OW + (dz_full ? 3.0 : 2.0) * batch * height * width + 36.0 * T), stream);
-  hipLaunchKernelGGL(wino4_dy_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
+  FSD_LAUNCH(wino4_dy_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
                      wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);
   return (int)hipGetLastError();
 }

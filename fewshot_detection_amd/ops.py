@@ -750,6 +750,11 @@ def kernel_profile_collect():
     return {PROFILE_CLASSES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n)}
 
 
+def launch_count(reset=False):
+    """Kernel launches the library has issued so far (since the last reset); include/fsdet.h fsd_launch_count."""
+    return int(lib().fsd_launch_count(1 if reset else 0))
+
+
 def clock_probe_mhz(device, iters=2000):
     """Shader clock (MHz) the GPU sustains under matrix-core load (a dependent-MFMA chain on every SIMD, ~1 ms)."""
     import ctypes as C

@@ -464,6 +464,10 @@ int fsd_augment_batch(const unsigned char* src, const long long* img_off, const 
 void fsd_profile_enable(int on);
 int fsd_profile_num_classes(void);
 int fsd_profile_collect(double* ms, double* work, long long* launches, int n_classes);
+/* Number of kernel launches the library has issued since the process started (or since the last call with reset != 0, which
+ * also zeroes the counter): every launch, whatever its class, recording on or off.  How many kernels one eval-mode
+ * detect_forward takes (reference shape: valid_ensemble.py:137-148) is read off this. */
+long long fsd_launch_count(int reset);
 /* Shader clock (MHz) sustained under matrix-core load: one wave per SIMD runs iters x 16 dependent 64-cycle fp32 MFMAs;
  * synchronises.  scratch: any device buffer of >= 4 bytes (never written). */
 int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stream);
