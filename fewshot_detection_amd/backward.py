@@ -182,7 +182,8 @@ def run_early(ctx, grad_out):
         streams.keep_alive(s, grad_out)
     else:
         grads = run(ctx.net, ctx.tape, grad_out, ctx.params)
-    ctx.early_result = (grad_out.data_ptr(), tuple(grad_out.shape), grads)
+    # the gradient tensor itself is kept (not its bare address: the allocator could hand the address to another tensor)
+    ctx.early_result = (grad_out, grads)
 
 
 def run(net, tape, grad_out, params, wgrad_stream=True):

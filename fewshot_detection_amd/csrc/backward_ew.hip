@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgsT<T> p) {
       const f32x4 yv = ld4(p.y + pix * p.y_ld + g * 4);
       f32x4 tv, gin = zero;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tv[k] = yv[k] * sc[k] + sh[k];
+      for (int k = 0; k < 4; ++k) tv[k] = __builtin_fmaf(yv[k], sc[k], sh[k]);
       if (p.pool == 0) {
         gin = ld4(p.dz + pix * p.dz_ld + g * 4);
       } else {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(ActBwdArgsT<T> p) {
               const f32x4 v = ld4(p.y + ((b * p.H + wy) * (long long)p.W + wx) * p.y_ld + g * 4);
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
-                float a = v[k] * sc[k] + sh[k];
+                float a = __builtin_fmaf(v[k], sc[k], sh[k]);
                 a = a > 0.f ? a : a * p.slope;
                 if (q == 0 || a > best[k]) { best[k] = a; by[k] = wy; bx[k] = wx; }
               }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void act_stats_kernel(ActBwdArgsT<float> p) {
       const f32x4 gin = ld4(p.dz + pix * p.dz_ld + g * 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float tv = yv[k] * sc[k] + sh[k];
+        const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
         const float d = tv > 0.f ? gin[k] : gin[k] * p.slope;
         s1[k] += d;
         s2[k] += d * ((yv[k] - mu[k]) * is[k]);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void act_bwd_pool2_kernel(ActBwdArgsT<T> p) {
         yv[q] = in[q] ? ld4(p.y + ((b * p.H + yy) * (long long)p.W + xx) * p.y_ld + g * 4) : zero;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          tv[q][k] = yv[q][k] * sc[k] + sh[k];
+          tv[q][k] = __builtin_fmaf(yv[q][k], sc[k], sh[k]);
           const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * p.slope;
           if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
         }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const float* __rest
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float tv = yv[k] * sc[k] + sh[k];
+      const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
       const float d = tv > 0.f ? gin[k] : gin[k] * slope;
       o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
     }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const float* __rest
       yv[q] = in[q] ? ld4(y + ((b * H + yy) * (long long)W + xx) * y_ld + g * 4) : zero;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        tv[q][k] = yv[q][k] * sc[k] + sh[k];
+        tv[q][k] = __builtin_fmaf(yv[q][k], sc[k], sh[k]);
         const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * slope;
         if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
       }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float tv = yv[k] * sc[k] + sh[k];
+      const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
       const float d = tv > 0.f ? gin[k] : gin[k] * slope;
       o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
     }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        tv[q][k] = yv[q][k] * sc[k] + sh[k];
+        tv[q][k] = __builtin_fmaf(yv[q][k], sc[k], sh[k]);
         const float a = tv[q][k] > 0.f ? tv[q][k] : tv[q][k] * slope;
         if (q == 0 || a > bv[k]) { bv[k] = a; best[k] = q; }
       }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
         const bool valid = (g.mask >> s) & 1u;
         const float yt = g.yt[s], yb = g.yb[s];
         const float gz = valid ? g.gz[s] : 0.f;
-        const float tt = yt * sc + sh, tb = yb * sc + sh;
+        const float tt = __builtin_fmaf(yt, sc, sh), tb = __builtin_fmaf(yb, sc, sh);
         const float at = tt > 0.f ? tt : tt * p.slope, ab = tb > 0.f ? tb : tb * p.slope;
         const float pt = __shfl_xor(at, 32, 64), pb = __shfl_xor(ab, 32, 64);
         // the window in scan order (first maximum wins, like torch and fsd_bn_act_pool_bwd)

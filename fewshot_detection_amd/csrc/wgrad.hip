@@ -59,7 +59,7 @@ struct WgradArgs {
 template <int TILE, int STAGES, bool BF16, bool PLAIN = false, bool DMA = false, bool SPLIT = false>
 // (at least 3 waves per SIMD: the split 128x128 variant then keeps its accumulators in VGPRs, 154 registers instead of 130 + 64
 // AGPRs = two waves per SIMD; its 48 KB of LDS allow three workgroups per CU: 26x26 256->512 0.205 -> 0.197 ms, 13x13 0.474 -> 0.456)
-__global__ __launch_bounds__(kThreads, 3) void wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(kThreads, SPLIT ? 3 : 1) void wgrad_kernel(WgradArgs p) {
   static_assert(!BF16, "fp32 kernel");
   static_assert(!DMA || (PLAIN && STAGES == 2), "DMA staging: fp32 plain GEMM, two LDS stages");
   static_assert(!SPLIT || (!DMA && STAGES == 1), "split operands: register staging, one LDS stage");
@@ -947,7 +947,7 @@ extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int wi
   const long long pixels = (long long)batch * height * width;
   const int ncols = ksize * ksize * round_up(cin, 4);
   int splits = 0;
-  for (int tile : {tile_of(0), 128}) {
+  for (int tile : {64, 128, tile_of(0)}) {       // every tiling f32_tile() can return, whatever FSD_WGRAD_F32 says
     const int tiles = ((cout + tile - 1) / tile) * ((ncols + tile - 1) / tile);
     const int s = pick_splits(pixels, tiles, tile);
     splits = s > splits ? s : splits;

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
           yv[w] = in[w] ? ld4(y + ((b * H + oy) * (long long)W + ox) * y_ld + g * 4) : zero;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            tv[w][k] = yv[w][k] * sc[k] + sh[k];
+            tv[w][k] = __builtin_fmaf(yv[w][k], sc[k], sh[k]);   // one rounding, like the forward pass that picked the sign / the pool winner
             const float a = tv[w][k] > 0.f ? tv[w][k] : tv[w][k] * gg.slope;
             if (w == 0 || a > bv[k]) { bv[k] = a; best[k] = w; }
           }

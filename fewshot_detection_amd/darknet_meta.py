@@ -208,6 +208,7 @@ def build_modules(blocks, region_cls):
         else:
             raise NotImplementedError("block type %r is outside the MI355X hot path" % kind)
         out_filters.append(prev_filters)
+    ops.install_bn_counter_hooks(models)       # BatchNorm batch counters live on the host between looks (ops.bn_finalize)
     return models
 
 
@@ -236,6 +237,8 @@ class _NetFn(torch.autograd.Function):
         # and under torch.no_grad() needs_input_grad still reports the parameters)
         record = any(ctx.needs_input_grad) and _GRAD_MODE[0]
         ctx.side = None
+        if not has_dyn and inputs[0].is_cuda:
+            streams.clear_early(inputs[0].device)      # a producer of vectors starts: entries of earlier forwards are stale
         if side is not None and streams.ENABLED and streams.META and inputs[0].is_cuda:
             main = torch.cuda.current_stream()
             s = streams.side(inputs[0].device, side)
@@ -265,9 +268,9 @@ class _NetFn(torch.autograd.Function):
         from . import backward as bw
         grad_out = grad_out.contiguous()
         early = ctx.early_result
-        if early is not None and early[0] == grad_out.data_ptr() and early[1] == tuple(grad_out.shape):
+        if early is not None and early[0].data_ptr() == grad_out.data_ptr() and tuple(early[0].shape) == tuple(grad_out.shape):
             # the detector's sweep already ran this network's backward on this very gradient (backward.run_early)
-            grads = early[2]
+            grads = early[1]
             ctx.early_result = None
             if ctx.side is not None:
                 main = torch.cuda.current_stream()
@@ -353,9 +356,12 @@ class Darknet(nn.Module):
         # the vectors may still be in flight on the "meta" side stream (forward() defers the wait to the first reader,
         # which on the eager path is the fused head): every read below is on the current stream, so wait here
         streams.await_tensor(vec)
-        versions = tuple(p._version for p in self.models.parameters()) + tuple(b._version for b in self.models.buffers())
+        # (the BatchNorm batch counters are host bookkeeping the kernels never read: their flush must not invalidate a graph)
+        versions = tuple(p._version for p in self.models.parameters()) + \
+            tuple(b._version for n, b in self.models.named_buffers() if not n.endswith("num_batches_tracked"))
+        # the arithmetic of the fp32 GEMMs is a process-wide launch-time switch: a graph replays the one it was captured in
         key = (tuple(x.shape), x.device.index, tuple(vec.shape), _WEIGHT_EPOCH[0], _STATS_EPOCH[0], self._det.compute_dtype,
-               hash(versions))
+               ops.f32_gemm_mode(), hash(versions))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 8:                 # each entry pins its activations: keep a handful of shapes
@@ -393,7 +399,7 @@ class Darknet(nn.Module):
         return self.detect_forward(x, self.meta_forward(metax, mask, _defer=True))
 
     def state_dict(self, *args, **kwargs):
-        ops.flush_bn_counters(self)        # BatchNorm batch counters are kept on the host between looks
+        ops.flush_bn_counters(self)        # (the per-BatchNorm hooks of ops.install_bn_counter_hooks cover submodule calls)
         return super(Darknet, self).state_dict(*args, **kwargs)
 
     def print_network(self):

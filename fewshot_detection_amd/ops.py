@@ -387,6 +387,26 @@ def bn_finalize(partial, count, bn, training):
     return buf[0], buf[1], buf[2], buf[3]
 
 
+def install_bn_counter_hooks(module):
+    """Every BatchNorm of `module` flushes its host-side batch count whenever ITS state is gathered (state_dict() of the
+    module itself or of any parent, torch.save(model.models.state_dict()) included), and drops the pending count when a state
+    is loaded into it (load_state_dict: the loaded counter is the truth, batches run before the load must not be added on
+    top; load_weights does not touch the counter -- a .weights file has none -- so the pending count stays, as in the reference)."""
+    def pre(m, prefix, keep_vars):
+        n = getattr(m, "_fsd_pending_batches", 0)
+        if n and getattr(m, "num_batches_tracked", None) is not None:
+            m.num_batches_tracked += n
+        m._fsd_pending_batches = 0
+
+    def post(m, incompatible):
+        m._fsd_pending_batches = 0
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and not getattr(m, "_fsd_counter_hooks", False):
+            m.register_state_dict_pre_hook(pre)
+            m.register_load_state_dict_post_hook(post)
+            m._fsd_counter_hooks = True
+
+
 def flush_bn_counters(module):
     """Bring every BatchNorm's `num_batches_tracked` up to date with the training batches the HIP path ran."""
     for m in module.modules():

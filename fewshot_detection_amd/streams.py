@@ -85,22 +85,34 @@ def from_side(t):
         return _key(t) in _FROM_SIDE
 
 
-_EARLY = {}       # (device index, data_ptr) of reweighting vectors -> the autograd context of the network that made them
+_EARLY = {}       # device index -> (data_ptr, shape, weakref to the autograd context of the network that made the vectors)
 
 
 def register_early(t, ctx):
     """`t` = vectors that go straight into the detector of the same forward() call (single consumer): the detector's
-    backward may run the producer's backward sweep itself as soon as d(t) exists (backward.run_early)."""
+    backward may run the producer's backward sweep itself as soon as d(t) exists (backward.run_early).
+    ONE pending entry per device, held by a weak reference: a forward() that is never followed by a backward (the loss raised,
+    an evaluation in grad mode) neither pins its tape nor survives the next forward of a reweighting net (clear_early)."""
+    import weakref
     with _LOCK:
-        _EARLY.pop(_key(t), None)
-        _EARLY[_key(t)] = ctx
-        while len(_EARLY) > 2:          # (an entry pins its network's tape until it is taken or evicted)
-            _EARLY.pop(next(iter(_EARLY)))
+        _EARLY[_key(t)[0]] = (t.data_ptr(), tuple(t.shape), weakref.ref(ctx))
+
+
+def clear_early(device):
+    """A new reweighting-net forward starts on `device`: whatever an earlier forward registered is stale."""
+    idx = torch.device(device).index
+    with _LOCK:
+        _EARLY.pop(idx if idx is not None else (torch.cuda.current_device() if torch.cuda.is_available() else -1), None)
 
 
 def take_early(t):
+    """The context registered for exactly these vectors (same device, address AND shape), if it is still alive."""
     with _LOCK:
-        return _EARLY.pop(_key(t), None)
+        ent = _EARLY.get(_key(t)[0])
+        if ent is None or ent[0] != t.data_ptr() or ent[1] != tuple(t.shape):
+            return None
+        del _EARLY[_key(t)[0]]
+    return ent[2]()
 
 
 def keep_alive(stream, *tensors):

@@ -478,8 +478,13 @@ int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stre
  *         x = x1 + x2 + x3 (exact), and a product is accumulated in fp32 from the six cross terms down to 2^-16 relative on
  *         the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16).  Storage, accumulation and results stay fp32; the error
  *         against a float64 reference is at or below the native instruction's (tests/test_gpu_split.py).
- * Any other value only queries.  Returns the previous mode.  Takes effect for kernels launched afterwards; the first use
- * reads the environment variable FSD_F32_SPLIT (0 / 1). */
+ *         Non-finite and out-of-range operands differ from mode 0: an infinite operand element gives NaN (inf - bf16(inf)),
+ *         where the fp32 instruction gives +-inf or NaN depending on its partner, and finite fp32 values above bfloat16's
+ *         largest (|x| > 3.3895e38) round to inf the same way; NaN stays NaN.  Finite operands below that bound behave as in
+ *         mode 0 over the whole fp32 exponent range (bfloat16 has fp32's exponent).
+ * Any other value only queries.  Returns the previous mode.  Takes effect for kernels LAUNCHED afterwards -- a hipGraph
+ * captured earlier replays the arithmetic it was captured in (the Python layer keys its inference graphs on the mode); the
+ * first use reads the environment variable FSD_F32_SPLIT (0 / 1). */
 int fsd_f32_gemm_mode(int mode);
 
 const char* fsd_version(void);

@@ -304,3 +304,24 @@ def test_which_layers_defer_their_activation_to_the_consumer(tmp_path):
     assert deferring(det, 416) == []
     det.compute_dtype = "f32"
     assert deferring(net._meta, 224) == []
+
+
+def test_batchnorm_batch_counters_follow_state_dict_and_load_state_dict():
+    """the host-side BatchNorm batch counts are flushed by per-module hooks (submodule state_dict() calls and
+    torch.save(model.models.state_dict()) see them) and dropped when a state is loaded (no pre-load batches on top)."""
+    import torch
+    from fewshot_detection_amd import ops
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    ops.install_bn_counter_hooks(m)
+    ops.install_bn_counter_hooks(m)                         # idempotent
+    m[1]._fsd_pending_batches = 3
+    assert int(m[1].state_dict()["num_batches_tracked"]) == 3 and m[1]._fsd_pending_batches == 0     # the submodule alone
+    m[1]._fsd_pending_batches = 2
+    saved = {k: v.clone() for k, v in m.state_dict().items()}                                         # through the parent
+    assert int(saved["1.num_batches_tracked"]) == 5
+    m[1]._fsd_pending_batches = 7                            # batches run before the load do not belong to the loaded state
+    m.load_state_dict(saved)
+    assert int(m[1].num_batches_tracked) == 5 and m[1]._fsd_pending_batches == 0
+    m[1]._fsd_pending_batches = 1
+    ops.flush_bn_counters(m)
+    assert int(m[1].num_batches_tracked) == 6

@@ -57,19 +57,31 @@ def test_switches_follow_the_environment(monkeypatch):
     assert streams.ENABLED is True and streams.WGRAD is True
 
 
-def test_early_backward_registry_hands_a_context_out_once_and_stays_small():
-    """streams.register_early / take_early: the reweighting net's autograd context is parked under its output's address
-    until the detector's sweep takes it; an entry nobody takes (a forward pass without backward) is evicted, oldest first,
-    so that at most two tapes stay pinned."""
+def test_early_backward_registry_hands_a_context_out_once_and_never_a_stale_one():
+    """streams.register_early / take_early: ONE pending entry per device, held by a weak reference and matched
+    on address AND shape; a forward that is never followed by a backward neither pins its tape nor survives the next
+    forward of a reweighting net (clear_early), so a later step whose vectors land at the same address cannot take it."""
+    class Ctx(object):
+        pass
     streams._EARLY.clear()
     outs = [torch.zeros(3) for _ in range(5)]
-    ctxs = [object() for _ in outs]
+    ctxs = [Ctx() for _ in outs]
     for t, c in zip(outs, ctxs):
         streams.register_early(t, c)
-    assert len(streams._EARLY) <= 2
-    assert streams.take_early(outs[0]) is None                   # evicted
-    assert streams.take_early(outs[4]) is ctxs[4] and streams.take_early(outs[4]) is None
-    assert streams.take_early(outs[3][:2]) is ctxs[3]            # a view of the same storage address finds it
+    assert len(streams._EARLY) == 1                                # the newest forward replaced the older ones
+    assert streams.take_early(outs[0]) is None and streams.take_early(outs[3]) is None
+    assert streams.take_early(outs[4][:2]) is None                 # same address, another shape: not these vectors
+    assert streams.take_early(outs[4]) is ctxs[4] and streams.take_early(outs[4]) is None     # handed out once
+    # a context that died (its graph was freed without a backward) is not resurrected
+    streams.register_early(outs[1], ctxs[1])
+    ctxs[1] = None
+    import gc
+    gc.collect()
+    assert streams.take_early(outs[1]) is None
+    # a new producer forward on the device drops whatever is pending
+    streams.register_early(outs[2], ctxs[2])
+    streams.clear_early(outs[2].device)
+    assert streams.take_early(outs[2]) is None
 
 
 def test_side_output_marks_are_bounded_and_queryable():
