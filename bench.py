@@ -528,8 +528,10 @@ def compact_line(res, full_path=None):
                      "allreduce_dtype": dp.get("allreduce_dtype"),
                      "allreduce_wait_ms_per_step": sum(dp.get("allreduce_wait_ms_per_step") or [0.0])}
         ov = dp.get("overlap")
-        if isinstance(ov, dict) and "buckets_ready_before_backward_end" in ov:
-            out["dp"]["buckets_ready_before_backward_end"] = ov["buckets_ready_before_backward_end"]
+        if isinstance(ov, dict) and ov.get("gpu_ms_ready_before_backward_end"):
+            # buckets whose gradients were complete on the GPU before the backward pass ended (their all-reduce overlaps it)
+            out["dp"]["buckets_ready_before_backward_end"] = sum(1 for v in ov["gpu_ms_ready_before_backward_end"]
+                                                                 if v is not None and v > 0.0)
     a = res.get("also_measured") or {}
     if a:
         am = {}

@@ -926,6 +926,12 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
   a.nk = a.Kpad / kBK;
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
   const bool nchw = out_nchw != 0;
+  if (!in_scale && fsd_conv::halo_ok(height, width, cin, cout, ksize, nchw) && (y_ld & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+    // narrow 3x3 layers (32 / 64 channels): halo patch split once per workgroup (conv_halo.hip); one BatchNorm partial row
+    // per 128 pixels, the row count fsd_conv_row_tiles reports for these channel counts (128-row tiles)
+    return fsd_conv::conv3x3_halo(x, x_ld, w_packed, a.Kpad, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, slope,
+                                  stream);
   if (split8_1x1(pixels, cin, cout, ksize, nchw)) {
     // 1x1 convolution = a plain GEMM over the pixel rows: the 8-wave 256x128 split kernel on the WHOLE 256-row tiles (its
     // clamped rows past M would enter the BatchNorm sums), 64x64 tiles for the remaining < 256 rows

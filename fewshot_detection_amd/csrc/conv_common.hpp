@@ -206,6 +206,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   }
 }
 
+// halo-staged direct 3x3 convolution of the narrow layers under the split arithmetic (conv_halo.hip)
+bool halo_ok(int height, int width, int cin, int cout, int ksize, bool nchw);
+int conv3x3_halo(const float* x, long long x_ld, const float* w_packed, int kpad, const float* bias, float* y, long long y_ld,
+                 float* bn_partial, int batch, int height, int width, int cin, int cout, float slope, hipStream_t stream);
+
 // which tile the batched forward / data-gradient GEMM of conv_gemm_batched will use; returns the number of M tiles
 int conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out);
 

@@ -158,6 +158,22 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu():
     assert ov["buckets_launched_before_backward_enqueue_ended"] >= 1 and ov["gpu_ms_ready_before_backward_end"][0] > 0
 
 
+def test_every_bucket_but_the_last_is_ready_under_the_backward_at_the_headline_shape():
+    """on the GPU timeline of the HEADLINE episode (64 queries 416x416 + 20 supports 224x224 per rank, the
+    full darknet_dynamic / reweighting_net model, 6 gradient buckets in readiness order) the gradients of every bucket but
+    the last are complete BEFORE the backward pass ends -- there is backward work left to hide each all-reduce behind.  Run
+    in the bf16 storage mode, so the dry run also exercises the bfloat16 all-reduce (grad_dtype) under gloo."""
+    res = _run_bench(["--batch", "64", "--classes", "20", "--size", "416", "--support", "224", "--dtype", "bf16",
+                      "--steps", "2", "--warmup", "1"], {"FSD_BENCH_BACKEND": "gloo"})
+    assert res["n_gpus"] == 2 and res["dtype"] == "bf16" and res["config"]["global_batch"] == 128
+    dp = res["dp"]
+    assert dp["world_size"] == 2 and dp["allreduce_dtype"] == "bfloat16" and dp["gradient_buckets"] == 6
+    assert dp["bucket_launch_order"] == list(range(6))
+    ready = dp["overlap"]["gpu_ms_ready_before_backward_end"]
+    assert len(ready) == 6 and all(v > 0.0 for v in ready[:-1]), ready
+    assert ready == sorted(ready, reverse=True), ready          # readiness order = bucket order (reweighting net first)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: >= 2 GPUs")
 def test_bench_two_ranks_over_rccl():
     """The real transport: two ranks, one MI355X each, backend nccl (= RCCL over xGMI).  Self-skips on 1-GPU boxes."""

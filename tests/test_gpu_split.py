@@ -31,6 +31,8 @@ SHAPES = [  # B, H, W, cin, cout, k
     (4, 52, 52, 128, 256, 3),      # Winograd F(4x4)
     (8, 13, 13, 1024, 1024, 3),    # Winograd F(4x4), long reduction
     (2, 104, 104, 32, 64, 3),      # direct 3x3
+    (2, 112, 112, 32, 64, 3),      # direct 3x3, halo-staged under split (H % 8 == 0, W % 16 == 0): forward 32->64, data gradient 64->32
+    (3, 16, 32, 64, 64, 3),        # halo-staged, two 32-channel slices each way
     (4, 26, 26, 512, 256, 1),      # 1x1
     (3, 7, 7, 256, 512, 3),        # small map of the reweighting net
 ]
@@ -133,3 +135,35 @@ def test_training_step_in_both_modes_agrees_to_round_off(dev, tmp_path):
     (ln, gn), (ls, gs) = results["native"], results["split"]
     assert abs(ln - ls) <= 1e-5 * abs(ln)
     assert float((gn - gs).norm() / gn.norm()) < 3e-2
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 32, 64), (3, 24, 48, 64, 32), (1, 208, 208, 32, 64)])
+def test_halo_staged_narrow_conv_epilogue(dev, B, H, W, cin, cout):
+    """csrc/conv_halo.hip (split arithmetic, 32 / 64 channels, H % 8 == 0, W % 16 == 0): output, BatchNorm partial sums (one
+    row per 128 pixels), bias and the inference-form leaky epilogue against float64."""
+    from fewshot_detection_amd import ops
+    ops.f32_gemm_mode("split")
+    g = torch.Generator().manual_seed(B * H + cin)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    wp = ops.pack_weight(w.to(dev))
+    y, part = ops.conv2d(xv, wp, cout, 3, bn_partial=True)
+    assert part.shape[0] == B * H * W // 128
+    out = ops.nhwc_to_nchw(y).cpu().double()
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    p = part.double().sum(0).cpu()
+    flat = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+    assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=2e-4, atol=1e-2)
+    # bias + leaky epilogue (inference form), into a channel slice of a wider buffer
+    wide = ops.new_view(B, H, W, cout + 32, dev)
+    wide.t.fill_(7.0)
+    dst = ops.View(wide.t, B, H, W, cout, 32)
+    ops.conv2d(xv, wp, cout, 3, bias=bias.to(dev), out=dst, slope=0.1)
+    refb = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.1)
+    got = ops.nhwc_to_nchw(dst).cpu().double()
+    assert float((got - refb).abs().max()) < 2e-5 * float(refb.abs().max())
+    assert float((wide.t[:, :32] - 7.0).abs().max()) == 0.0          # the neighbouring channels are untouched
