@@ -528,7 +528,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
     // as one block during which neither wave of the SIMD has matrix work queued (both are in the same phase of the same
     // barrier interval).  The loads of chunk kc+2 go out as soon as a staging register set is free.  Chunk indices past the
     // end are clamped (redundant loads / stores keep the body branch-free).
-    static_assert(TM == 2 && TN == 2 && A_PER_T + B_PER_T == 6, "the micro-step schedule below is dealt for 48 MFMAs and 6 float4");
+    constexpr int NMF = 12 * TM * TN;                      // MFMAs per chunk and wave
+    constexpr int NFR = 3 * (TM + TN);                     // fragment reads of one k-step
+    constexpr int NST = 8 * (A_PER_T + B_PER_T);           // split micro-steps per chunk and thread
+    static_assert(NFR <= NMF / 2 && NST <= 2 * NMF, "the k-step-1 fragments fit behind the k-step-0 MFMAs, <= 2 micro-steps per MFMA");
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     auto cvt2 = [](float a, float b) -> unsigned {                     // one v_cvt_pk_bf16_f32
@@ -575,20 +578,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
       unsigned h0, h1, m0_, m1_, l0, l1;
       float r0, r1, r2, r3;
       const int po1 = ((2 + fh) ^ fsw) << 4;
-#pragma unroll
-      for (int u = 0; u < 48; ++u) {
-        const int ks = u / 24, t = (u % 24) / 4, i = (u % 4) / 2, j = u % 2;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
-        if (u < 12) {                                                    // fragments of k-step 1: one per MFMA
-          const int q = u / 4, w = u % 4;
-          if (w < 2) af[1][q][w] = *reinterpret_cast<const bf16x8*>(cur + fa_off + q * PLANE_A + w * 32 * ROWB + po1);
-          else bf[1][q][w - 2] = *reinterpret_cast<const bf16x8*>(cur + fb_off + q * PLANE_B + (w - 2) * 32 * ROWB + po1);
-        }
-        const int f = u / 8, step = u % 8;                               // float4 f of this thread (0-3: A rows, 4-5: B rows)
+      auto micro = [&](const int s) {
+        const int f = s / 8, step = s % 8;                               // float4 f of this thread (first the A rows, then the B rows)
         if constexpr (ACT) {
-          // one value of the NEXT A float4 per even micro-step: ra[f + 1] (this chunk's successor, kc+1) under float4 0..2,
-          // ra[0] of chunk kc+2 (fetched at u = 7) under the last float4; (sc, sh) move on to chunk kc+2 in between (u = 32)
-          if (u == 32) load_sc(kn);
+          // one value of the NEXT A float4 per even micro-step: ra[f + 1] (this chunk's successor, kc+1) under the A float4s
+          // before the last, ra[0] of chunk kc+2 (fetched at the end of float4 0) under the last float4 of all; (sc, sh) move on
+          // to chunk kc+2 in between (first B micro-step)
+          if (s == 8 * A_PER_T) load_sc(kn);
           if (step % 2 == 0 && (f + 1 < A_PER_T || f == A_PER_T + B_PER_T - 1)) {
             const int g = f + 1 < A_PER_T ? f + 1 : 0, e = step / 2;
             ra[g][e] = act1(ra[g][e], e);
@@ -610,6 +606,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
           if (f < A_PER_T) ra[f < A_PER_T ? f : 0] = *reinterpret_cast<const f32x4*>(asrc[f < A_PER_T ? f : 0] + kn * kBK);
           else rb[f < A_PER_T ? 0 : f - A_PER_T] = *reinterpret_cast<const f32x4*>(bsrc + (f - A_PER_T) * b_step + kn * kBK);
         }
+      };
+#pragma unroll
+      for (int u = 0; u < NMF; ++u) {
+        const int ks = u / (NMF / 2), t = (u % (NMF / 2)) / (TM * TN), i = (u % (TM * TN)) / TN, j = u % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
+        if (u < NFR) {                                                   // fragments of k-step 1: one per MFMA
+          const int q = u / (TM + TN), w = u % (TM + TN);
+          if (w < TM) af[1][q][w] = *reinterpret_cast<const bf16x8*>(cur + fa_off + q * PLANE_A + w * 32 * ROWB + po1);
+          else bf[1][q][w - TM] = *reinterpret_cast<const bf16x8*>(cur + fb_off + q * PLANE_B + (w - TM) * 32 * ROWB + po1);
+        }
+#pragma unroll
+        for (int sidx = u * NST / NMF; sidx < (u + 1) * NST / NMF; ++sidx) micro(sidx);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
@@ -785,6 +793,22 @@ inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw
   return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 && pixels >= 512;
 }
 
+// How many of the `batches` positions of a batched launch go to the 256-row tiles (the rest: 128-row tiles, second launch).
+// Cost model: rounds of 256 co-resident workgroups; a 128-row tile takes 0.55 of a 256-row one.  FSD_SPLIT8_TAIL=0: all 256.
+inline int split8_main_positions(long long rows, int cout, int batches) {
+  static const char* env = getenv("FSD_SPLIT8_TAIL");
+  if ((env && env[0] == '0') || batches < 2) return batches;
+  const long long nt = (cout + 127) / 128;
+  const long long tp256 = (rows + 255) / 256 * nt, tp128 = (rows + 127) / 128 * nt;
+  int best = batches;
+  double best_cost = (double)((batches * tp256 + 255) / 256);
+  for (int pm = batches - 1; pm >= 0; --pm) {
+    const double cost = (double)((pm * tp256 + 255) / 256) + 0.55 * (double)(((batches - pm) * tp128 + 255) / 256);
+    if (cost < best_cost - 0.2) { best_cost = cost; best = pm; }     // (a second launch has to buy at least a fifth of a round)
+  }
+  return best;
+}
+
 // -1: not decided yet (first use reads FSD_F32_SPLIT; default 1 = split arithmetic, FSD_F32_SPLIT=0 = native fp32 MFMA)
 std::atomic<int> g_f32_split{-1};
 
@@ -850,6 +874,26 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
     static_assert(lds_k >= (size_t)256 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
     static const char* ilv_env = getenv("FSD_SPLIT8_ILV");               // tuning aid: 0 = split + stores as one block between the MFMA groups
     if (ilv_env && ilv_env[0] == '0') return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, false>, a, lds_k, 512, stream);
+    // Tail balance: one workgroup per CU means whole ROUNDS of 256 tiles -- 36 positions x 32 tiles = 1152 = 4.5 rounds pay for
+    // 5.  The last positions go to a second launch on 128-row tiles (half the time each): 32 positions = 4 rounds + 4 positions
+    // x 64 half-tiles = one half-length round.
+    const int p_main = split8_main_positions(rows, cout, batches);
+    if (p_main < batches) {
+      ConvArgs t = a;
+      t.batches = batches - p_main;
+      t.x = a.x + (long long)p_main * a.x_bs;
+      t.w = static_cast<const float*>(a.w) + (long long)p_main * a.w_bs;
+      t.y = a.y + (long long)p_main * a.y_bs;
+      t.m_tiles = (int)((rows + 127) / 128);
+      constexpr size_t lds_t = 2 * 3 * (size_t)(128 + 128) * 64;
+      static_assert(lds_t >= (size_t)128 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
+      if (p_main > 0) {
+        a.batches = p_main;
+        const int rc = launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
+        if (rc != 0) return rc;
+      }
+      return launch_kernel(conv_gemm_split8_kernel<128, 128, 4, 2, true, 0>, t, lds_t, 512, stream);
+    }
     return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
   }
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
