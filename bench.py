@@ -33,6 +33,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# more hardware queues than streams (main + meta + wgrad + copy + comm): the HIP runtime's default is 4 (read at its first use)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -305,6 +307,13 @@ class Leg(object):
         for _ in range(warmup):
             step()
         self.fence()
+        self.stream_tuning = None
+        if streams_on and self.dist is None and self.opt is not None:
+            # untimed: make sure the side streams pay in THIS process (streams.autotune: an unlucky stream -> hardware-queue
+            # mapping makes a step 40 % slower for the life of the streams; it re-draws them or falls back to one stream)
+            self.stream_tuning = streams.autotune(step)
+            streams_on = streams.ENABLED
+            self.fence()
         if self.opt is not None:
             self.opt.allreduce_wait_ms = [0.0] * len(self.opt.buckets)
         prof_steps = min(steps, prof_steps)
@@ -348,6 +357,7 @@ class Leg(object):
         loss_val = float(loss.detach())
         assert np.isfinite(loss_val), "non-finite loss"
         return {"elapsed": elapsed, "steps": steps, "loss": loss_val, "prof": prof, "prof_steps": prof_steps,
+                "stream_tuning": self.stream_tuning, "streams_on": streams_on,
                 "prof_index": [lo, hi] if prof_steps else None, "kp": ops.kernel_profile_collect(),
                 "ms_unprofiled": (((t_a - t0) + (t_end - t_b)) / (steps - prof_steps) * 1e3
                                   if t_a is not None and steps > prof_steps else None),
@@ -522,6 +532,10 @@ def compact_line(res, full_path=None):
     if st:
         out["streams"] = {"enabled": st.get("enabled"), "ms_per_step_unprofiled": st.get("ms_per_step_unprofiled"),
                           "ms_per_step_profiled": st.get("ms_per_step_profiled")}
+        tn = st.get("tuning") or {}
+        if tn.get("tries"):
+            out["streams"]["autotune_tries"] = len(tn["tries"])
+            out["streams"]["autotune_ms"] = [tn["tries"][-1]["streams_ms"], tn["tries"][-1]["one_stream_ms"]]
     dp = res.get("dp") or {}
     if dp:
         out["dp"] = {"world_size": dp.get("world_size"), "backend": dp.get("backend"), "buckets": dp.get("gradient_buckets"),
@@ -888,7 +902,7 @@ def _main(args, real_stdout):
             "gpu_clock": dict(clock, what="shader clock from a dependent fp32-MFMA chain on every SIMD (fsd_clock_probe), right "
                                           "before the warm-up and after the timed region; the MFMA peaks in `roofline` are "
                                           "quoted at the nominal clock"),
-            "streams": {"enabled": bool(streams_on),
+            "streams": {"enabled": bool(r.get("streams_on", streams_on)), "tuning": r.get("stream_tuning"),
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
                                 "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
                         "profiled_steps_on_one_stream": r["prof_steps"], "profiled_step_index": r["prof_index"],

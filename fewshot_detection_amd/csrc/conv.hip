@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 // ACT: activation on load (p.in_scale, see ConvArgs): x = leaky(y * scale[k] + shift[k]) is formed in the staging registers, one
 // value per micro-step, a chunk ahead of its split.  ACT = 1: 0 <= in_slope <= 1, leaky(t) = max(t, t * slope) (the bits of
 // affine_act4's select, one instruction less); ACT = 2: any slope, the select itself.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV, int ACT = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV = true, int ACT = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   static_assert(NT == 512, "8 waves");
@@ -409,31 +409,38 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
 
-  int batch = blockIdx.y, L;
-  if (p.flat_xcd && gridDim.y > 1) {
-    const int Lf = xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-    batch = Lf / (int)gridDim.x;
-    L = Lf - batch * (int)gridDim.x;
-  } else {
-    L = xcd_swizzle(blockIdx.x, gridDim.x);
-  }
-  p.x += (long long)batch * p.x_bs;
-  p.w = static_cast<const float*>(p.w) + (long long)batch * p.w_bs;
-  p.y += (long long)batch * p.y_bs;
-  const int mt = L / p.n_tiles, nt = L - mt * p.n_tiles;
-  const int m0 = p.m_base + mt * BM, n0 = nt * BN;
+  // PERSISTENT: the launch has at most one workgroup per CU (the kernel needs 144 KB of LDS); workgroup b walks the virtual
+  // block ids b, b + G, b + 2G, ... of the flat (batch, tile) space (G % 8 == 0 keeps a workgroup on the XCD-contiguous run
+  // xcd_swizzle gives its XCD).  The first chunk of the NEXT tile is fetched before the epilogue of the current one, whose
+  // global stores then drain under the next tile's main loop -- a one-shot workgroup pays the first-load latency and the
+  // store tail of every tile with the matrix pipe idle (one workgroup per CU: nobody else is there to fill it).
+  const int tiles_pb = p.m_tiles * p.n_tiles, total = tiles_pb * p.batches;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int kq = tid & 7, g8 = tid >> 3;
-
   const float* asrc[A_PER_T];
+  const float* bsrc;
+  int m0 = 0, n0 = 0, mt = 0;
+  float* ybase = p.y;
+  auto set_tile = [&](int v) {
+    const int Lf = xcd_swizzle(v, total);
+    const int batch = Lf / tiles_pb, L = Lf - batch * tiles_pb;
+    mt = L / p.n_tiles;
+    const int nt = L - mt * p.n_tiles;
+    m0 = p.m_base + mt * BM;
+    n0 = nt * BN;
+    const float* xb = p.x + (long long)batch * p.x_bs;
 #pragma unroll
-  for (int j = 0; j < A_PER_T; ++j) {
-    int row = m0 + g8 + RPP * j;
-    row = row < p.M ? row : p.M - 1;
-    asrc[j] = p.x + (unsigned)row * (unsigned)p.x_ld + kq * 4;
-  }
-  const float* bsrc = static_cast<const float*>(p.w) + (long long)(n0 + g8) * p.Kpad + kq * 4;
+    for (int j = 0; j < A_PER_T; ++j) {
+      int row = m0 + g8 + RPP * j;
+      row = row < p.M ? row : p.M - 1;
+      asrc[j] = xb + (unsigned)row * (unsigned)p.x_ld + kq * 4;
+    }
+    bsrc = static_cast<const float*>(p.w) + (long long)batch * p.w_bs + (long long)(n0 + g8) * p.Kpad + kq * 4;
+    ybase = p.y + (long long)batch * p.y_bs;
+  };
+  int v = blockIdx.x;
+  set_tile(v);
   const long long b_step = (long long)RPP * p.Kpad;
   // byte offset of this thread's 8-byte piece inside a plane: row g8 (+ RPP * j: multiples of 64 rows leave (row >> 2) & 3 alone)
   const int st_off = g8 * ROWB + ((((kq >> 1) ^ ((g8 >> 2) & 3))) << 4) + (kq & 1) * 8;
@@ -467,12 +474,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment reads: lane = tile row (lane & 31), k-half (lane >> 5) of the 16 k of one MFMA; logical 16-byte piece
   // 2 * step + half sits at piece ^ ((row >> 2) & 3)
@@ -492,35 +493,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
       for (int j = 0; j < TN; ++j) bf[s][QB[o]][j] = *reinterpret_cast<const bf16x8*>(st + fb_off + QB[o] * PLANE_B + j * 32 * ROWB + po);
     }
   };
-  auto mfmas = [&](int s) {
-    // the six terms, smallest first; each term sweeps the TM x TN independent accumulators
-    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][TA[t]][i], bf[s][TB[t]][j], acc[i][j], 0, 0, 0);
-  };
 
-  if constexpr (!ILV) {
-    gload(0);
-    sstore(sm);
-    __syncthreads();
-    for (int kc = 0; kc < p.nk; ++kc) {
-      unsigned char* cur = sm + (kc & 1) * STAGE;
-      unsigned char* nxt = sm + ((kc & 1) ^ 1) * STAGE;
-      const bool more = kc + 1 < p.nk;
-      if (more) gload(kc + 1);
-      frags(cur, 0);
-      frags(cur, 1);
-      mfmas(0);
-      if (more) sstore(nxt);          // stage `nxt` was last read before the previous barrier
-      mfmas(1);
-      __syncthreads();
-    }
-  } else {
+  {
+    static_assert(ILV, "one schedule");
     // Software pipeline with a hand-dealt issue order.  At the top of iteration kc the raw fp32 values of chunk kc+1 are
     // already in registers (loaded during iteration kc-1).  Their split + LDS stores are cut into 48 micro-steps of 2-4 VALU
     // (+ one DS) instructions, ONE after each of the 48 MFMAs of chunk kc, pinned with sched_barrier: the wave keeps issuing
@@ -553,7 +528,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
       if constexpr (ACT == 2) return t > 0.f ? t : t * slope;
       return __builtin_fmaxf(t, t * slope);
     };
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
     gload(0);
+    for (;;) {
     if constexpr (ACT) {
       load_sc(0);
 #pragma unroll
@@ -568,8 +545,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
 #pragma unroll
       for (int e = 0; e < 4; ++e) ra[0][e] = act1(ra[0][e], e);
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();
-    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
     for (int kc = 0; kc < p.nk; ++kc) {
       unsigned char* cur = sm + (kc & 1) * STAGE;
       unsigned char* nxt = sm + ((kc & 1) ^ 1) * STAGE;
@@ -622,8 +604,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
       }
       __syncthreads();
     }
+    // ---- end of the tile: fetch the first chunk of the next one, then store this one ----
+    const int em0 = m0, en0 = n0, emt = mt;
+    ConvArgs q = p;
+    q.y = ybase;
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < total;
+    if (has_next) {
+      set_tile(vn);
+      gload(0);
+    }
+    conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, false>(q, acc, smem, em0, en0, emt, tid, lane, wm, wn);
+    if (!has_next) break;
+    v = vn;
+    __syncthreads();               // the epilogue's LDS tile is read: stage 0 may be overwritten
+    }
   }
-  conv_epilogue<BM, BN, WAVES_M, WAVES_N, TM, TN, false>(p, acc, smem, m0, n0, mt, tid, lane, wm, wn);
 }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
@@ -677,6 +673,29 @@ inline int tile_cfg(int cin, int ksize, int cout, bool nchw = false) {
   // split arithmetic, 3x3 into 64 channels (32 -> 64 at 208x208): 128x64 tiles 0.994 ms against 1.076 for 64x64
   if (fsd_conv::f32_split_on() && ksize == 3 && cout == 64 && !nchw) return kTile128x64;
   return kTile64;
+}
+
+// conv_gemm_split8_kernel is persistent: one workgroup per CU at most, a multiple of 8 (XCD order), each walking
+// total / grid tiles
+template <typename K>
+int launch_split8(K k, const ConvArgs& a, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
+      v = 256;
+    n_cu = v;
+  }
+  const long long total = (long long)a.m_tiles * a.n_tiles * a.batches;
+  static const char* env = getenv("FSD_SPLIT8_PERSIST");             // tuning aid: 0 = one tile per workgroup
+  long long grid = total < n_cu || (env && env[0] == '0') ? total : n_cu;
+  if (grid >= 8 && grid < total) grid = grid / 8 * 8;
+  const double rows = (double)a.M - (double)a.m_base;
+  fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * rows * a.Cout * ((double)a.nk * kBK) * a.batches, stream);
+  FSD_LAUNCH(k, dim3((unsigned)grid), dim3(512), lds, stream, a);
+  return (int)hipGetLastError();
 }
 
 template <typename K>
@@ -872,8 +891,6 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   if (pick == 'k') {
     constexpr size_t lds_k = 2 * 3 * (size_t)(256 + 128) * 64;        // two stages of three planes; >= the 256x128 fp32 tile
     static_assert(lds_k >= (size_t)256 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
-    static const char* ilv_env = getenv("FSD_SPLIT8_ILV");               // tuning aid: 0 = split + stores as one block between the MFMA groups
-    if (ilv_env && ilv_env[0] == '0') return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, false>, a, lds_k, 512, stream);
     // Tail balance: one workgroup per CU means whole ROUNDS of 256 tiles -- 36 positions x 32 tiles = 1152 = 4.5 rounds pay for
     // 5.  The last positions go to a second launch on 128-row tiles (half the time each): 32 positions = 4 rounds + 4 positions
     // x 64 half-tiles = one half-length round.
@@ -889,12 +906,12 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
       static_assert(lds_t >= (size_t)128 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
       if (p_main > 0) {
         a.batches = p_main;
-        const int rc = launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
+        const int rc = launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
         if (rc != 0) return rc;
       }
-      return launch_kernel(conv_gemm_split8_kernel<128, 128, 4, 2, true, 0>, t, lds_t, 512, stream);
+      return launch_split8(conv_gemm_split8_kernel<128, 128, 4, 2, true, 0>, t, lds_t, stream);
     }
-    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
+    return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
   }
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
@@ -999,9 +1016,9 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
     a.M = full_tiles * 256;            // the main launch sees whole tiles only
     constexpr size_t lds_k = 2 * 3 * (size_t)(256 + 128) * 64;
     if (in_scale && in_slope >= 0.f && in_slope <= 1.f)
-      return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 1>, a, lds_k, 512, stream);
-    if (in_scale) return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 2>, a, lds_k, 512, stream);
-    return launch_kernel(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, 512, stream);
+      return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 1>, a, lds_k, stream);
+    if (in_scale) return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 2>, a, lds_k, stream);
+    return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
   }
   const int cfg = tile_cfg(cin, ksize, cout, nchw);
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;

@@ -22,6 +22,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTilesPerBlock = 64;     // tiles reduced by one block of the output transform
 
+// Stride (elements) between the (tile+2)^2 position matrices of a transformed operand V / M / Wt: the matrix itself plus a
+// pad.  With the bare T * C stride the 36 streams a transform thread reads or writes are a multiple of 64 KB apart on the big
+// layers (43264 tiles x 128 channels x 4 B = 338 x 64 KB) -- FSD_WINO_PAD elements (a build-time constant) break that up.
+#ifndef FSD_WINO_PAD
+#define FSD_WINO_PAD 0
+#endif
+__host__ __device__ inline long long pos_stride(long long T, int C) { return T * C + FSD_WINO_PAD; }
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     t[3][j] = d[1][j] - d[3][j];
   }
   float* dst = V + tile * C + g * 4;
-  const long long ps = T * C;                 // stride between the 16 position matrices
+  const long long ps = pos_stride(T, C);      // stride between the 16 position matrices
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     st4(dst + (i * 4 + 0) * ps, t[i][0] - t[i][2]);
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
   f32x4 s1 = zero, s2 = zero;
   const long long t0 = (long long)blockIdx.x * tpb;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
   if (g_ok) {
     for (int it = pl; it < tpb; it += 4) {
       const long long tile = t0 + it;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     t[3][j] = -q[1][j];
   }
   float* dst = Wt + tile * C + g * 4;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     st4(dst + (i * 4 + 0) * ps, t[i][0]);
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     for (int i = 0; i < 6; ++i) d[i][j] = r[i];
   }
   float* dst = V + tile * C + g * 2;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {            // rows: V = t B
     f32x2 r[6];
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, l
     for (int i = 0; i < 6; ++i) t[i][j] = r[i];
   }
   float* dst = Wt + tile * C + g * 4;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     f32x4 r[6];
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
       }
     }
   }
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
   {   // weight-gradient operand from the inner 4x4
     f32x2 t[6][4];
 #pragma unroll
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   const f32x2 bv = (g_ok && bias) ? ld2(bias + g * 2) : zero;
   f32x2 s1 = zero, s2 = zero;
   const long long t0 = (long long)blockIdx.x * tpb;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
   if (g_ok) {
     for (int it = pl; it < tpb; it += NPL) {
       const long long tile = t0 + it;
@@ -698,7 +706,7 @@ __global__ __launch_bounds__(256) void wino4_output4_kernel(const float* __restr
   const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
   f32x4 s1 = zero, s2 = zero;
   const long long t0 = (long long)blockIdx.x * tpb;
-  const long long ps = T * C;
+  const long long ps = pos_stride(T, C);
   if (g_ok) {
     for (int it = pl; it < tpb; it += NPL) {
       const long long tile = t0 + it;
@@ -918,7 +926,8 @@ extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int co
 }
 
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
-  return (size_t)npos(tile) * tiles_of(batch, height, width, tile) * (size_t)(cin + cout) * sizeof(float);
+  const long long T = tiles_of(batch, height, width, tile);
+  return (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + pos_stride(T, cout)) * sizeof(float);
 }
 
 extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
@@ -928,7 +937,7 @@ extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile)
 }
 
 extern "C" size_t fsd_wino_v_elems(int batch, int height, int width, int cin, int tile) {
-  return (size_t)npos(tile) * tiles_of(batch, height, width, tile) * cin;
+  return (size_t)npos(tile) * (size_t)pos_stride(tiles_of(batch, height, width, tile), cin);
 }
 
 extern "C" int fsd_wino_conv3x3_fwd(const float* x, long long x_ld, const float* u_packed, const float* bias, float* y,
@@ -966,7 +975,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
-  float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * T * cin;
+  float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * pos_stride(T, cin);
   const long long n_in = T * (cin / 4);
   const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
   if (!V) {
@@ -984,7 +993,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     V = Vw;
   }
   const int rows_pad = round_up(cout, 128);
-  int rc = fsd_conv::conv_gemm_batched(V, cin, T * cin, u_packed, (long long)rows_pad * cin, Mb, cout, T * cout, T, cin, cout,
+  int rc = fsd_conv::conv_gemm_batched(V, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout, pos_stride(T, cout), T, cin, cout,
                                        P, stream);
   if (rc != 0) return rc;
   const int tpb = tiles_per_block(T);
@@ -1031,7 +1040,7 @@ extern "C" size_t fsd_wino_wgrad_workspace_bytes(int batch, int height, int widt
   const long long T = tiles_of(batch, height, width, tile);
   const int P = npos(tile);
   const int splits = fsd_conv::wgrad_batched_splits(T, cin, cout, P);
-  return ((size_t)P * T * (size_t)(cin + cout) + (size_t)P * splits * cout * cin) * sizeof(float);
+  return ((size_t)P * (pos_stride(T, cin) + pos_stride(T, cout)) + (size_t)P * splits * cout * cin) * sizeof(float);
 }
 
 extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const float* x, long long x_ld,
@@ -1051,8 +1060,8 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
   if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   float* Vw = reinterpret_cast<float*>(workspace);
-  float* Wt = Vw + (size_t)P * T * cin;
-  float* ws = Wt + (size_t)P * T * cout;
+  float* Wt = Vw + (size_t)P * pos_stride(T, cin);
+  float* ws = Wt + (size_t)P * pos_stride(T, cout);
   const long long n_in = T * (cin / 4), n_dy = T * (cout / 4);
   const float* V = v_kept;                                   // the forward pass's B^T d B, if the caller kept it
   if (!V) {
@@ -1079,7 +1088,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
     Wg = Wt;
   }
   int splits = 0;
-  int rc = fsd_conv::wgrad_gemm_batched(Wg, cout, T * cout, V, cin, T * cin, ws, T, cin, cout, P, &splits, stream);
+  int rc = fsd_conv::wgrad_gemm_batched(Wg, cout, pos_stride(T, cout), V, cin, pos_stride(T, cin), ws, T, cin, cout, P, &splits, stream);
   if (rc != 0) return rc;
   const long long n = (long long)cout * cin;
   if (tile == 2)

@@ -42,6 +42,60 @@ def side(device, name):
     return s
 
 
+def reset():
+    """Forget the side streams (new ones are taken from torch's pool on next use) and everything keyed on them.  HIP maps
+    streams onto a handful of hardware queues; an unlucky mapping (a side stream sharing the main stream's queue) turns the
+    overlap into a slowdown for the life of the streams -- autotune() below uses this to draw a new mapping."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    with _LOCK:
+        _SIDE.clear()
+        _READY.clear()
+        _FROM_SIDE.clear()
+        _EARLY.clear()
+
+
+def autotune(step, tries=3, reps=2, slack=1.03):
+    """Check that the side streams pay on THIS process / GPU: time `reps` synchronised calls of `step` with and without
+    them; if the multi-stream form is slower than `slack` x the one-stream form, re-create the streams and try again (up to
+    `tries` times), else fall back to one stream (ENABLED = False).  Measured on MI355X boxes of the pool: about one process
+    in eight starts with a stream set on which a step takes 36-43 ms instead of 26 (the one-stream step: 27.5), for as long as
+    those streams live.  -> dict(report).  A no-op when the streams are disabled."""
+    import time
+    global ENABLED
+    report = {"enabled_before": ENABLED, "tries": []}
+    if not ENABLED or not torch.cuda.is_available():
+        report["enabled_after"] = ENABLED
+        return report
+
+    def timed(on):
+        global ENABLED
+        ENABLED = on
+        step()                                    # settle (allocator, caches) in this mode
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    try:
+        off = timed(False)
+        for _ in range(tries):
+            on = timed(True)
+            report["tries"].append({"streams_ms": on, "one_stream_ms": off})
+            if on <= slack * off:
+                ENABLED = True
+                break
+            reset()
+        else:
+            ENABLED = False
+    except Exception:
+        ENABLED = report["enabled_before"]
+        raise
+    report["enabled_after"] = ENABLED
+    return report
+
+
 def _key(t):
     return (t.device.index if t.is_cuda else -1, t.data_ptr())
 
