@@ -11,6 +11,7 @@
 //   leave as ONE partial row per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fsdet.h"
 #include "profile.hpp"
 #include "ew_types.hpp"
@@ -26,11 +27,13 @@ struct FirstFwdArgs {
   int H, W, cin, Cout;
   long long pixels;
   int ppw;                          // pixels per wave (multiple of 32)
+  int wide;                         // y 16-byte aligned, pixel rows whole 16-byte pieces: wide stores through LDS
 };
 
 template <typename TO>
 __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
   __shared__ float s_red[4][32][2];
+  __shared__ float s_tile[4][32 * 33];              // one output tile per wave on its way to 16-byte stores
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int co = blockIdx.y * 32 + c;
@@ -71,21 +74,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
     for (int s = 0; s < 18; ++s) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[s >> 1][s & 1], bw[s], acc, 0, 0, 0);
     }
-    // rows of this lane: (r & 3) + 8 * (r >> 2) + 4h; byte offsets advance by whole pixel rows of y
+    // rows of this lane: (r & 3) + 8 * (r >> 2) + 4h.  Straight from the accumulators a lane would store ONE channel of a
+    // pixel per instruction (16 four- or two-byte stores: 1.42 GB of output left at 3.2 TB/s, the float4 fill of the same
+    // buffer runs at 5.3).  The 32 x 32 tile crosses a wave-private LDS patch instead ([pixel][33 floats]: conflict-free
+    // both ways) and leaves as 16-byte pieces: lane l stores channels 4 (l & 7) ... +3 (8 as bf16: lanes 0-3 ... of each
+    // pixel group) of pixel (l >> 3) + 8 q.
     char* y_b = reinterpret_cast<char*>(p.y);
     const unsigned ys = p.y_ld * (unsigned)sizeof(TO);
-    unsigned off = ((unsigned)base + 4u * h) * ys + (unsigned)co * (unsigned)sizeof(TO);
-    if (base + 32 <= p_end) {                        // whole tile inside this wave's run (wave-uniform)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[r];
-        fsd_ew::st1<TO>(reinterpret_cast<TO*>(y_b + off), v + bv);
-        s1 += v;
-        s2 += v * v;
-        off += ((r & 3) == 3) ? 5u * ys : ys;
-      }
-    } else {
-      const int left = (int)(p_end - base);
+    const int left = (int)(p_end - base) < 32 ? (int)(p_end - base) : 32;       // pixels of this tile inside the wave's run
+    if (!p.wide) {                                   // unaligned destinations: one value per lane and instruction
+      unsigned off = ((unsigned)base + 4u * h) * ys + (unsigned)co * (unsigned)sizeof(TO);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if ((r & 3) + 8 * (r >> 2) + 4 * h < left) {
@@ -96,7 +94,47 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
         }
         off += ((r & 3) == 3) ? 5u * ys : ys;
       }
+      return;
     }
+    float* tile = s_tile[wave];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = acc[r];
+      tile[row * 33 + c] = v + bv;
+      if (row < left) {
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    // (wave-private: the DS unit serves a wave's requests in order, the waitcnt is all the synchronisation needed)
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0)
+    if constexpr (sizeof(TO) == 4) {
+      const int pc = lane & 7, pr = lane >> 3;          // 8 pieces of 4 channels per pixel, 8 pixels per pass
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = pr + 8 * q;
+        if (row < left) {
+          const float* t = tile + row * 33 + pc * 4;
+          const fsd_ew::f32x4 v = {t[0], t[1], t[2], t[3]};
+          *reinterpret_cast<fsd_ew::f32x4*>(y_b + ((unsigned)base + (unsigned)row) * ys + ((unsigned)blockIdx.y * 32u + pc * 4u) * 4u) = v;
+        }
+      }
+    } else {
+      const int pc = lane & 3, pr = lane >> 2;          // 4 pieces of 8 channels per pixel, 16 pixels per pass
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = pr + 16 * q;
+        if (row < left) {
+          const float* t = tile + row * 33 + pc * 8;
+          fsd_ew::f32x8 v;
+          v.lo = fsd_ew::f32x4{t[0], t[1], t[2], t[3]};
+          v.hi = fsd_ew::f32x4{t[4], t[5], t[6], t[7]};
+          fsd_ew::st8(reinterpret_cast<fsd_ew::bf16_t*>(y_b + ((unsigned)base + (unsigned)row) * ys + ((unsigned)blockIdx.y * 32u + pc * 8u) * 2u), v);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // the patch is read before the next tile overwrites it
   };
 
   if (p_begin < p_end) {
@@ -154,6 +192,8 @@ int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const f
   a.H = height; a.W = width; a.cin = cin; a.Cout = cout; a.pixels = pixels;
   const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
   a.ppw = (int)((per + 63) / 64 * 64);
+  static const char* wide_env = getenv("FSD_FIRST_WIDE");           // tuning aid: 0 = narrow stores
+  a.wide = (!(wide_env && wide_env[0] == '0') && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ld * sizeof(TO)) % 16 == 0) ? 1 : 0;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + (double)sizeof(TO) * cout), stream);
   FSD_LAUNCH(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();

@@ -113,3 +113,26 @@ def test_autograd_without_trainer_and_public_meta_forward(dev, cfg_paths):
     assert torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+def test_autotune_keeps_streams_that_pay_and_drops_streams_that_do_not():
+    """streams.autotune: a step that is faster with the side streams keeps them; one that is slower gets new streams up to
+    `tries` times and then falls back to one stream."""
+    import time
+    from fewshot_detection_amd import streams
+    before = streams.ENABLED
+    try:
+        streams.ENABLED = True
+        rep = streams.autotune(lambda: time.sleep(0.004 if streams.ENABLED else 0.008), tries=2, reps=2)
+        assert rep["enabled_after"] is True and streams.ENABLED is True and len(rep["tries"]) == 1
+        streams.ENABLED = True
+        made = []
+        orig = streams.reset
+        streams.reset = lambda: (made.append(1), orig())[1]
+        try:
+            rep = streams.autotune(lambda: time.sleep(0.008 if streams.ENABLED else 0.004), tries=2, reps=2)
+        finally:
+            streams.reset = orig
+        assert rep["enabled_after"] is False and streams.ENABLED is False and len(rep["tries"]) == 2 and len(made) == 2
+    finally:
+        streams.ENABLED = before

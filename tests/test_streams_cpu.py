@@ -91,3 +91,16 @@ def test_side_output_marks_are_bounded_and_queryable():
         streams.mark_side_output(t)
     assert len(streams._FROM_SIDE) <= 16
     assert streams.from_side(keep[-1]) and not streams.from_side(keep[0]) and not streams.from_side(torch.zeros(2))
+
+
+def test_autotune_is_a_noop_without_a_gpu_or_with_streams_off(monkeypatch):
+    """streams.autotune only ever acts on a HIP device with the side streams enabled; elsewhere it reports and leaves the
+    switch alone (the timing logic itself runs on the GPU box: tests/test_gpu_streams.py)."""
+    calls = []
+    monkeypatch.setattr(streams, "ENABLED", False)
+    rep = streams.autotune(lambda: calls.append(1))
+    assert rep["enabled_before"] is False and rep["enabled_after"] is False and rep["tries"] == [] and not calls
+    if not torch.cuda.is_available():
+        monkeypatch.setattr(streams, "ENABLED", True)
+        rep = streams.autotune(lambda: calls.append(1))
+        assert rep["enabled_after"] is True and rep["tries"] == [] and not calls
