@@ -54,14 +54,25 @@ def bump_stats_epoch():
 
 
 class _WeightCache(object):
-    """Packed (K-major) copies of conv weights, refreshed when the parameter changes."""
+    """Packed (K-major) copies of conv weights, refreshed when the parameter changes.
+    Entries: key -> [tag, packed, weight, event]; `event` is set by prepack() (the copy was rebuilt on a side stream: the
+    first reader waits for it)."""
 
     def __init__(self):
         self._store = {}
 
+    @staticmethod
+    def _tag(w):
+        return (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+
+    def _build(self, w, mode, dtype):
+        if dtype in ("wino2", "wino4"):
+            return ops.pack_weight_wino(w.detach(), mode, int(dtype[4]))
+        return ops.pack_weight(w.detach(), mode, dtype)
+
     def get(self, w, mode=0, dtype="f32"):
         key = (id(w), mode, dtype)
-        tag = (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
+        tag = self._tag(w)
         hit = self._store.get(key)
         if dtype == "bf16" and (hit is None or hit[0] != tag):
             # both bf16 operands (forward, data gradient) in ONE pass over the weight, into buffers that are kept
@@ -70,17 +81,33 @@ class _WeightCache(object):
             if hit is not None and other is not None:
                 bufs = (hit[1], other[1]) if mode == 0 else (other[1], hit[1])
             pair = ops.pack_weight_bf16_pair(w.detach(), bufs)
-            self._store[(id(w), 0, dtype)] = (tag, pair[0])
-            self._store[(id(w), 1, dtype)] = (tag, pair[1])
+            self._store[(id(w), 0, dtype)] = [tag, pair[0], w, None]
+            self._store[(id(w), 1, dtype)] = [tag, pair[1], w, None]
             return pair[mode]
         if hit is None or hit[0] != tag:
-            if dtype in ("wino2", "wino4"):
-                packed = ops.pack_weight_wino(w.detach(), mode, int(dtype[4]))
-            else:
-                packed = ops.pack_weight(w.detach(), mode, dtype)
-            hit = (tag, packed)
+            hit = [tag, self._build(w, mode, dtype), w, None]
             self._store[key] = hit
+        elif hit[3] is not None:
+            torch.cuda.current_stream().wait_event(hit[3])      # rebuilt by prepack() on a side stream
+            hit[1].record_stream(torch.cuda.current_stream())
+            hit[3] = None
         return hit[1]
+
+    def prepack(self, stream):
+        """Rebuild every stale fp32 copy NOW, on `stream` (a side stream that already waits for the parameter update):
+        ~50 small transform / pack kernels per step (0.7 ms of kernel time) leave the critical path of the next step's
+        forward and backward sweeps, whose first reader of each copy waits on its event instead.  -> copies rebuilt."""
+        n = 0
+        with torch.cuda.stream(stream):
+            for key, ent in self._store.items():
+                w = ent[2]
+                if key[2] == "bf16" or ent[0] == self._tag(w):
+                    continue
+                ent[1] = self._build(w, key[1], key[2])
+                ent[0] = self._tag(w)
+                ent[3] = stream.record_event()
+                n += 1
+        return n
 
 
 FOLD_EVAL_BN = True     # inference: BatchNorm folded into the conv operands, leaky in the conv epilogue (Network._conv_eval)
