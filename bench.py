@@ -764,7 +764,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="multi-GPU: weak = --batch queries + N supports per rank; strong = --batch queries split over "
                          "the ranks, supports replicated (SURVEY 8e)")
-    ap.add_argument("--profile-steps", type=int, default=2, help="timed steps that carry the per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=1, help="timed steps that carry the per-kernel HIP events (they run on one stream)")
     ap.add_argument("--streams", type=int, choices=[0, 1], default=None,
                     help="side HIP streams (reweighting net, weight gradients, target upload beside the main stream); "
                          "default: on unless FSD_STREAMS=0")
