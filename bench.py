@@ -403,9 +403,11 @@ def roofline_block(r, dtype, ms, gemm_mode="native"):
         "kernel": ("conv_gemm_kernel: the fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernel behind the direct "
                    "3x3/1x1 convolutions, the data gradients and the 36 / 16 position GEMMs of the Winograd layers"
                    if dom == "gemm_fwd" and gemm_mode == "native" else
-                   "conv_gemm_kernel<..., SPLIT>: the implicit-GEMM kernel behind the direct 3x3/1x1 convolutions, the data "
-                   "gradients and the 36 / 16 position GEMMs of the Winograd layers; fp32 operands split in-kernel into three "
-                   "bf16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 accumulate"
+                   "conv_gemm_split8_kernel + conv_gemm_kernel<..., SPLIT> + conv3x3_halo_kernel: the forward / data-gradient "
+                   "GEMM kernels (8-wave 256x128 tiles for the 36 position GEMMs of the Winograd layers with K >= 256, 4-wave "
+                   "tiles for the rest and the 1x1 layers, the halo-staged direct kernel for the 32 / 64-channel 3x3 layers); "
+                   "fp32 operands split in-kernel into three bf16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 "
+                   "accumulate"
                    if dom == "gemm_fwd" else
                    "conv_bf16_*_kernel + wgrad_bf16_tr_kernel: the bf16-operand MFMA (v_mfma_f32_32x32x16_bf16) implicit-GEMM "
                    "kernels of the bf16 storage mode (forward, data gradient, weight gradient)"),
@@ -471,7 +473,7 @@ COMPACT_LIMIT = 4096            # bytes; the driver keeps ~8 KB of stdout tail a
 
 
 def _kernel_short(s):
-    return s.split(":")[0][:120] if s else s
+    return s.split(":")[0][:120] if s else s      # "a + b + c: description" -> the kernel names
 
 
 def compact_line(res, full_path=None):
