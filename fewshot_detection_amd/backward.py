@@ -16,6 +16,7 @@ from . import ops, streams
 from .ops import View
 
 AVAILABLE = True
+WGRAD_AFTER_DGRAD = __import__("os").environ.get("FSD_WGRAD_ORDER", "1") != "0"
 
 
 def _accumulate(grads, view, g):
@@ -148,14 +149,23 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
     kept = rec.get("wino_v")
     wtile = rec.get("wino_tile") or 0
     bf16 = net.compute_dtype == "bf16"
-    # the weight gradient is off the critical path of the sweep: on the "wgrad" stream it overlaps the data-gradient chain
-    if bf16:
-        pgrads[id(conv.weight)] = _off_path(ws, lambda: _wgrad_h(net, dy, cout, xv, cin, k, conv.weight), (dy.t, xv.t))
-    else:
-        pgrads[id(conv.weight)] = _off_path(
-            ws, lambda: ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32", wino_v=kept[0] if kept else None,
-                                         param=conv.weight, tile=wtile, wt_in=wt_in),
-            (dy.t, xv.t, kept[0] if kept else None, wt_in))
+    # The weight gradient is off the critical path of the sweep: on the "wgrad" stream it runs beside the main stream's chain.
+    # WHEN it is released matters: both the data gradient and the weight gradient of a layer are matrix-bound kernels that
+    # fill every CU on their own -- launched side by side they only time-share the matrix pipes, and the HBM-bound kernels that
+    # follow on the main stream (output transform, the next layer's statistics pass, gradient and input transforms) then run
+    # with nothing beside them.  WGRAD_AFTER_DGRAD (default) queues the data gradient first and releases the weight gradient
+    # behind it, so that it overlaps those HBM-bound kernels instead (FSD_WGRAD_ORDER=0: the round-2/3 order).
+    def launch_wgrad():
+        if bf16:
+            pgrads[id(conv.weight)] = _off_path(ws, lambda: _wgrad_h(net, dy, cout, xv, cin, k, conv.weight), (dy.t, xv.t))
+        else:
+            pgrads[id(conv.weight)] = _off_path(
+                ws, lambda: ops.conv2d_wgrad(dy, cout, xv, cin, k, "f32", wino_v=kept[0] if kept else None,
+                                             param=conv.weight, tile=wtile, wt_in=wt_in),
+                (dy.t, xv.t, kept[0] if kept else None, wt_in))
+    after = WGRAD_AFTER_DGRAD and ws is not None
+    if not after:
+        launch_wgrad()
     if xv is not first_input and not rec.get("input_cast"):
         dyv = dy if dy.C % 4 == 0 else View(dy.t, dy.B, dy.H, dy.W, (dy.C + 3) // 4 * 4, dy.c0)
         tile = 0 if bf16 else ops.wino_tile(dyv.C, xv.C, k, xv.H, xv.W)
@@ -166,6 +176,8 @@ def _conv_backward(net, rec, grads, pgrads, first_input, ws=None):
         else:
             dx, _ = ops.conv2d(dyv, net.cache.get(conv.weight, 1, "f32"), xv.C, k)
         _accumulate(grads, xv, dx)
+    if after:
+        launch_wgrad()
 
 
 def run_early(ctx, grad_out):

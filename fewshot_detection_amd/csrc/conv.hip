@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 // ACT: activation on load (p.in_scale, see ConvArgs): x = leaky(y * scale[k] + shift[k]) is formed in the staging registers, one
 // value per micro-step, a chunk ahead of its split.  ACT = 1: 0 <= in_slope <= 1, leaky(t) = max(t, t * slope) (the bits of
 // affine_act4's select, one instruction less); ACT = 2: any slope, the select itself.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV = true, int ACT = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV = true, int ACT = 0, bool PERSIST = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   static_assert(NT == 512, "8 waves");
@@ -409,7 +409,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
 
-  // PERSISTENT: the launch has at most one workgroup per CU (the kernel needs 144 KB of LDS); workgroup b walks the virtual
+  // PERSIST (tuning aid, FSD_SPLIT8_PERSIST=1; measured +-0 and 25 more registers, which is what decides whether an HBM-bound
+  // kernel of another stream fits beside this one on a SIMD -- default off): the launch has at most one workgroup per CU (the
+  // kernel needs 144 KB of LDS); workgroup b walks the virtual
   // block ids b, b + G, b + 2G, ... of the flat (batch, tile) space (G % 8 == 0 keeps a workgroup on the XCD-contiguous run
   // xcd_swizzle gives its XCD).  The first chunk of the NEXT tile is fetched before the epilogue of the current one, whose
   // global stores then drain under the next tile's main loop -- a one-shot workgroup pays the first-load latency and the
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
     ConvArgs q = p;
     q.y = ybase;
     const int vn = v + (int)gridDim.x;
-    const bool has_next = vn < total;
+    const bool has_next = PERSIST && vn < total;
     if (has_next) {
       set_tile(vn);
       gload(0);
@@ -680,10 +682,10 @@ inline int tile_cfg(int cin, int ksize, int cout, bool nchw = false) {
   return kTile64;
 }
 
-// conv_gemm_split8_kernel is persistent: one workgroup per CU at most, a multiple of 8 (XCD order), each walking
-// total / grid tiles
+// conv_gemm_split8_kernel launches: one tile per workgroup (default), or persistent (at most one workgroup per CU, a multiple
+// of 8 for the XCD order, each walking total / grid tiles)
 template <typename K>
-int launch_split8(K k, const ConvArgs& a, size_t lds, hipStream_t stream) {
+int launch_split8_grid(K k, const ConvArgs& a, size_t lds, bool persist, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   static int n_cu = 0;
@@ -697,13 +699,19 @@ int launch_split8(K k, const ConvArgs& a, size_t lds, hipStream_t stream) {
   static const char* prio_env = getenv("FSD_SPLIT8_PRIO");            // tuning aid: 1 = s_setprio 1 for waves 4-7
   ConvArgs b = a;
   if (prio_env && prio_env[0] == '1' && b.wide) b.wide |= 2;      // (bit 1 rides on the wide-epilogue flag: still truthy)
-  static const char* env = getenv("FSD_SPLIT8_PERSIST");             // tuning aid: 0 = one tile per workgroup
-  long long grid = total < n_cu || (env && env[0] == '0') ? total : n_cu;
+  long long grid = total < n_cu || !persist ? total : n_cu;
   if (grid >= 8 && grid < total) grid = grid / 8 * 8;
   const double rows = (double)a.M - (double)a.m_base;
   fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * rows * a.Cout * ((double)a.nk * kBK) * a.batches, stream);
   FSD_LAUNCH(k, dim3((unsigned)grid), dim3(512), lds, stream, b);
   return (int)hipGetLastError();
+}
+
+template <int BM, int ACT>
+int launch_split8_t(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  static const char* env = getenv("FSD_SPLIT8_PERSIST");
+  if (env && env[0] == '1') return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, true>, a, lds, true, stream);
+  return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, false>, a, lds, false, stream);
 }
 
 template <typename K>
@@ -914,12 +922,12 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
       static_assert(lds_t >= (size_t)128 * 128 * sizeof(float), "the wide epilogue's tile must fit the staging space");
       if (p_main > 0) {
         a.batches = p_main;
-        const int rc = launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
+        const int rc = launch_split8_t<256, 0>(a, lds_k, stream);
         if (rc != 0) return rc;
       }
-      return launch_split8(conv_gemm_split8_kernel<128, 128, 4, 2, true, 0>, t, lds_t, stream);
+      return launch_split8_t<128, 0>(t, lds_t, stream);
     }
-    return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
+    return launch_split8_t<256, 0>(a, lds_k, stream);
   }
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
@@ -1024,9 +1032,9 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
     a.M = full_tiles * 256;            // the main launch sees whole tiles only
     constexpr size_t lds_k = 2 * 3 * (size_t)(256 + 128) * 64;
     if (in_scale && in_slope >= 0.f && in_slope <= 1.f)
-      return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 1>, a, lds_k, stream);
-    if (in_scale) return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 2>, a, lds_k, stream);
-    return launch_split8(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0>, a, lds_k, stream);
+      return launch_split8_t<256, 1>(a, lds_k, stream);
+    if (in_scale) return launch_split8_t<256, 2>(a, lds_k, stream);
+    return launch_split8_t<256, 0>(a, lds_k, stream);
   }
   const int cfg = tile_cfg(cin, ksize, cout, nchw);
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;

@@ -28,6 +28,14 @@ constexpr int kTilesPerBlock = 64;     // tiles reduced by one block of the outp
 #ifndef FSD_WINO_PAD
 #define FSD_WINO_PAD 0
 #endif
+// Minimum waves per SIMD of the F(4x4) output / gradient transforms (build-time, tuning aid; 4 = at most 128 VGPRs): left alone the compiler takes 242 / 130
+// VGPRs for them (every load of a tile in flight at once) -- two waves per SIMD, and no room beside an 8-wave GEMM workgroup of
+// another stream (2 x 200 of the 512 registers of a SIMD lane: 112 left).
+#ifdef FSD_XFORM_WAVES
+#define FSD_XFORM_LB __launch_bounds__(256, FSD_XFORM_WAVES)
+#else
+#define FSD_XFORM_LB __launch_bounds__(256)
+#endif
 __host__ __device__ inline long long pos_stride(long long T, int C) { return T * C + FSD_WINO_PAD; }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -426,7 +434,7 @@ struct DyFromG {
 };
 
 template <int BN>
-__global__ __launch_bounds__(256) void wino4_dy_kernel(float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
+__global__ FSD_XFORM_LB void wino4_dy_kernel(float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
                                                       int H, int W, int TH, int TW, int C, long long T,
                                                       const float* __restrict__ y, long long y_ld,
                                                       const float* __restrict__ coef, const float* __restrict__ mean,
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256) void wino4_grad_kernel(const float* __restrict
 // 4x4 output with the column weights A^T[:, r] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1),
 // so only 16 outputs + one row are live (the all-at-once form needs 256 VGPRs and runs at occupancy 1).
 template <int GL>
-__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+__global__ FSD_XFORM_LB void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                           float* __restrict__ y, long long y_ld, float* __restrict__ partial,
                                                           int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
   constexpr int NPL = 256 / GL;
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 // The same with FOUR channels per thread (16-byte loads of M and 16-byte stores of y; 64 accumulator registers): for layers
 // with >= 128 output channels.  FSD_WINO_OUT4=0 keeps the two-channel kernel everywhere.
 template <int GL>
-__global__ __launch_bounds__(256) void wino4_output4_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+__global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                            float* __restrict__ y, long long y_ld, float* __restrict__ partial,
                                                            int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
   constexpr int NPL = 256 / GL;
