@@ -326,6 +326,8 @@ class Leg(object):
         # full-heap pass in the middle of the timed region
         gc.collect()
         gc.disable()
+        step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # per-step GPU time (diagnostic)
+        step_ev[0].record()
         t0 = time.perf_counter()
         for i in range(steps):
             if i == lo and prof_steps:
@@ -341,11 +343,13 @@ class Leg(object):
                 torch.cuda.synchronize()
                 t_b = time.perf_counter()
             loss = step()
+            step_ev[i + 1].record()
         ops.PROFILE = None
         ops.kernel_profile(False)
         streams.ENABLED = streams_on
         self.fence()
         t_end = time.perf_counter()
+        step_gpu_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)]
         gc.enable()
         if prof_steps and t_b is None:        # the profiled steps were the last ones
             t_b = t_end
@@ -357,7 +361,7 @@ class Leg(object):
         loss_val = float(loss.detach())
         assert np.isfinite(loss_val), "non-finite loss"
         return {"elapsed": elapsed, "steps": steps, "loss": loss_val, "prof": prof, "prof_steps": prof_steps,
-                "stream_tuning": self.stream_tuning, "streams_on": streams_on,
+                "stream_tuning": self.stream_tuning, "streams_on": streams_on, "step_gpu_ms": step_gpu_ms,
                 "prof_index": [lo, hi] if prof_steps else None, "kp": ops.kernel_profile_collect(),
                 "ms_unprofiled": (((t_a - t0) + (t_end - t_b)) / (steps - prof_steps) * 1e3
                                   if t_a is not None and steps > prof_steps else None),
@@ -904,6 +908,7 @@ def _main(args, real_stdout):
             "gpu_clock": dict(clock, what="shader clock from a dependent fp32-MFMA chain on every SIMD (fsd_clock_probe), right "
                                           "before the warm-up and after the timed region; the MFMA peaks in `roofline` are "
                                           "quoted at the nominal clock"),
+            "step_gpu_ms": r.get("step_gpu_ms"),
             "streams": {"enabled": bool(r.get("streams_on", streams_on)), "tuning": r.get("stream_tuning"),
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
                                 "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",

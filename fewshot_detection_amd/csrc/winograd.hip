@@ -416,6 +416,23 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   }
 }
 
+// vector of CPT channels per thread (2: 8-byte accesses and half the registers; 4: 16-byte accesses)
+template <int CPT> struct VecOf;
+template <> struct VecOf<4> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
+};
+template <> struct VecOf<2> {
+  typedef f32x2 type;
+  static __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+};
+template <int CPT> __device__ __forceinline__ typename VecOf<CPT>::type ldv(const float* p) {
+  return *reinterpret_cast<const typename VecOf<CPT>::type*>(p);
+}
+template <int CPT> __device__ __forceinline__ void stv(float* p, typename VecOf<CPT>::type v) {
+  *reinterpret_cast<typename VecOf<CPT>::type*>(p) = v;
+}
+
 // dy (4x4 tile) -> G4 dy G4^T  (36 positions)
 // BN = 1: `dy` holds dt (gradient w.r.t. the BatchNorm output); the BatchNorm backward c1*(dt - c2 - xhat*c3) is
 // applied on the way in and written back IN PLACE (tiles do not overlap), so fsd_bn_bwd_apply's separate pass -- and
@@ -433,13 +450,14 @@ struct DyFromG {
   int pool, OH, OW;
 };
 
-template <int BN>
+template <int BN, int CPT>
 __global__ FSD_XFORM_LB void wino4_dy_kernel(float* __restrict__ dy, long long dy_ld, float* __restrict__ Wt,
                                                       int H, int W, int TH, int TW, int C, long long T,
                                                       const float* __restrict__ y, long long y_ld,
                                                       const float* __restrict__ coef, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, DyFromG gg) {
-  const int cg = C >> 2;
+  typedef typename VecOf<CPT>::type VT;
+  const int cg = C / CPT;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * cg) return;
   const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
@@ -450,58 +468,58 @@ __global__ FSD_XFORM_LB void wino4_dy_kernel(float* __restrict__ dy, long long d
   const unsigned ut2 = utile / (unsigned)TW;
   const int ty = (int)(ut2 % (unsigned)TH);
   const long long b = ut2 / (unsigned)TH;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 c1 = zero, c2 = zero, c3 = zero, mu = zero, is = zero;
+  const VT zero = VecOf<CPT>::splat(0.f);
+  VT c1 = zero, c2 = zero, c3 = zero, mu = zero, is = zero;
   if constexpr (BN != 0) {
-    c1 = ld4(coef + g * 4); c2 = ld4(coef + C + g * 4); c3 = ld4(coef + 2 * C + g * 4);
-    mu = ld4(mean + g * 4); is = ld4(invstd + g * 4);
+    c1 = ldv<CPT>(coef + g * CPT); c2 = ldv<CPT>(coef + C + g * CPT); c3 = ldv<CPT>(coef + 2 * C + g * CPT);
+    mu = ldv<CPT>(mean + g * CPT); is = ldv<CPT>(invstd + g * CPT);
   }
-  f32x4 q[4][4];
+  VT q[4][4];
   if constexpr (BN == 2) {
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-    const f32x4 sc = gg.scale ? ld4(gg.scale + g * 4) : one, sh = gg.shift ? ld4(gg.shift + g * 4) : zero;
+    const VT one = VecOf<CPT>::splat(1.f);
+    const VT sc = gg.scale ? ldv<CPT>(gg.scale + g * CPT) : one, sh = gg.shift ? ldv<CPT>(gg.shift + g * CPT) : zero;
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
       for (int cj = 0; cj < 2; ++cj) {
         const int cy = 2 * ty + ci, cx = 2 * tx + cj;            // pooling cell of the image
-        f32x4 yv[4], tv[4];
+        VT yv[4], tv[4];
         bool in[4];
-        int best[4] = {0, 0, 0, 0};
-        f32x4 bv = zero;
+        int best[CPT] = {};
+        VT bv = zero;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int oy = 2 * cy + (w >> 1), ox = 2 * cx + (w & 1);
           in[w] = oy < H && ox < W;
-          yv[w] = in[w] ? ld4(y + ((b * H + oy) * (long long)W + ox) * y_ld + g * 4) : zero;
+          yv[w] = in[w] ? ldv<CPT>(y + ((b * H + oy) * (long long)W + ox) * y_ld + g * CPT) : zero;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < CPT; ++k) {
             tv[w][k] = __builtin_fmaf(yv[w][k], sc[k], sh[k]);   // one rounding, like the forward pass that picked the sign / the pool winner
             const float a = tv[w][k] > 0.f ? tv[w][k] : tv[w][k] * gg.slope;
             if (w == 0 || a > bv[k]) { bv[k] = a; best[k] = w; }
           }
         }
         const bool win = gg.pool == 1 && cy < gg.OH && cx < gg.OW;
-        const f32x4 gz = win ? ld4(gg.dz + ((b * gg.OH + cy) * (long long)gg.OW + cx) * gg.dz_ld + g * 4) : zero;
+        const VT gz = win ? ldv<CPT>(gg.dz + ((b * gg.OH + cy) * (long long)gg.OW + cx) * gg.dz_ld + g * CPT) : zero;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int i = 2 * ci + (w >> 1), j = 2 * cj + (w & 1);
           if (!in[w]) { q[i][j] = zero; continue; }
           const long long pix = (b * H + (4 * ty + i)) * (long long)W + 4 * tx + j;
-          f32x4 gin = gg.pool == 0 ? ld4(gg.dz + pix * gg.dz_ld + g * 4) : zero;
+          VT gin = gg.pool == 0 ? ldv<CPT>(gg.dz + pix * gg.dz_ld + g * CPT) : zero;
           if (gg.dz_full) {
-            const f32x4 gf = ld4(gg.dz_full + pix * gg.dzf_ld + g * 4);
+            const VT gf = ldv<CPT>(gg.dz_full + pix * gg.dzf_ld + g * CPT);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gin[k] += gf[k];
+            for (int k = 0; k < CPT; ++k) gin[k] += gf[k];
           }
-          f32x4 v;
+          VT v;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < CPT; ++k) {
             if (win && best[k] == w) gin[k] += gz[k];
             const float d = tv[w][k] > 0.f ? gin[k] : gin[k] * gg.slope;
             v[k] = c1[k] * (d - c2[k] - (yv[w][k] - mu[k]) * is[k] * c3[k]);
           }
-          st4(dy + pix * dy_ld + g * 4, v);
+          stv<CPT>(dy + pix * dy_ld + g * CPT, v);
           q[i][j] = v;
         }
       }
@@ -513,12 +531,12 @@ __global__ FSD_XFORM_LB void wino4_dy_kernel(float* __restrict__ dy, long long d
       const int oy = 4 * ty + i, ox = 4 * tx + j;
       if (oy < H && ox < W) {
         const long long pix = (b * H + oy) * (long long)W + ox;
-        f32x4 v = ld4(dy + pix * dy_ld + g * 4);
+        VT v = ldv<CPT>(dy + pix * dy_ld + g * CPT);
         if constexpr (BN == 1) {
-          const f32x4 yv = ld4(y + pix * y_ld + g * 4);
+          const VT yv = ldv<CPT>(y + pix * y_ld + g * CPT);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = c1[k] * (v[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);   // == bn_bwd_apply
-          st4(dy + pix * dy_ld + g * 4, v);
+          for (int k = 0; k < CPT; ++k) v[k] = c1[k] * (v[k] - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);   // == bn_bwd_apply
+          stv<CPT>(dy + pix * dy_ld + g * CPT, v);
         }
         q[i][j] = v;
       } else {
@@ -526,22 +544,22 @@ __global__ FSD_XFORM_LB void wino4_dy_kernel(float* __restrict__ dy, long long d
       }
     }
   }
-  f32x4 t[6][4];
+  VT t[6][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f32x4 r[6];
+    VT r[6];
     g6x4(q[0][j], q[1][j], q[2][j], q[3][j], r);
 #pragma unroll
     for (int i = 0; i < 6; ++i) t[i][j] = r[i];
   }
-  float* dst = Wt + tile * C + g * 4;
+  float* dst = Wt + tile * C + g * CPT;
   const long long ps = pos_stride(T, C);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    f32x4 r[6];
+    VT r[6];
     g6x4(t[i][0], t[i][1], t[i][2], t[i][3], r);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) st4(dst + (i * 6 + j) * ps, r[j]);
+    for (int j = 0; j < 6; ++j) stv<CPT>(dst + (i * 6 + j) * ps, r[j]);
   }
 }
 
@@ -1090,7 +1108,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
       FSD_LAUNCH(wino_dy_kernel, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream, dy, dy_ld, Wt,
                          height, width, TH, TW, cout, T);
     else
-      FSD_LAUNCH(wino4_dy_kernel<0>, dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
+      FSD_LAUNCH((wino4_dy_kernel<0, 4>), dim3((unsigned)((n_dy + 255) / 256)), dim3(256), 0, stream,
                          const_cast<float*>(dy), dy_ld, Wt, height, width, TH, TW, cout, T, (const float*)nullptr, 0LL,
                          (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, DyFromG{});
     Wg = Wt;
@@ -1134,7 +1152,7 @@ extern "C" int fsd_wino_dy_bn_transform(float* dt, long long dt_ld, const float*
   const long long n = T * (channels / 4);
   // reads dt and y, writes dy (in place) and the 36 transformed positions
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * (3.0 * batch * height * width + 36.0 * T), stream);
-  FSD_LAUNCH(wino4_dy_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
+  FSD_LAUNCH((wino4_dy_kernel<1, 4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dt, dt_ld, wt_out,
                      height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, DyFromG{});
   return (int)hipGetLastError();
 }
@@ -1158,7 +1176,15 @@ extern "C" int fsd_wino_dy_bn_transform_g(const float* dz, long long dz_ld, cons
   const long long n = T * (channels / 4);
   // reads dz (+ dz_full) and y, writes dy and the 36 transformed positions
   fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * channels * ((double)batch * gg.OH * gg.OW + (dz_full ? 3.0 : 2.0) * batch * height * width + 36.0 * T), stream);
-  FSD_LAUNCH(wino4_dy_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
-                     wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);
+  // FSD_DY_CPT=2 (tuning aid): two channels per thread, 79 registers instead of 130 -- the kernel then fits beside an 8-wave GEMM
+  // workgroup of the weight-gradient stream (112 registers of a SIMD lane are free there).  Measured in the step, four runs per
+  // arm on one box: 25.84 against 25.83 ms -- co-residency alone buys nothing, the default stays four channels (16-byte accesses).
+  static const char* cpt_env = getenv("FSD_DY_CPT");
+  if (cpt_env && cpt_env[0] == '2')
+    FSD_LAUNCH((wino4_dy_kernel<2, 2>), dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
+               wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);
+  else
+    FSD_LAUNCH((wino4_dy_kernel<2, 4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
+               wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);
   return (int)hipGetLastError();
 }
