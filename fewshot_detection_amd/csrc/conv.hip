@@ -814,17 +814,16 @@ inline char batched_pick(long long rows, int cin, int cout) {
   return cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a';
 }
 
-// 1x1 convolutions on the 8-wave split kernel (K >= 256, whole 128-column tiles, >= 512 rows): OPT-IN, FSD_CONV1_SPLIT8=1.
-// Alone the kernel is 20-25 % faster than the 64x64 tiles on these launches (13x13 1024->512 0.104 -> 0.078 ms, 26x26 512->256
-// 0.098 -> 0.084, 52x52 256->128 0.106 -> 0.085) -- but a train step with the side streams on got SLOWER with it (27.0 -> 33.7 ms
-// on one box; 28.0 with one stream): a 144 KB workgroup needs a CU free of every other LDS user, and these launches run
-// beside the weight-gradient stream's small-LDS workgroups, which keep trickling onto every CU -- the critical-path launch
-// waits for the side kernel to drain instead of sharing the chip with it.  (The Winograd position GEMMs run beside the
-// weight-gradient stream's own 144 KB workgroups and LDS-free transforms: no such blocking.)  The row tiling (and with it the
-// number of BatchNorm partial rows, fsd_conv_row_tiles) does not depend on the activation arguments.
+// 1x1 convolutions on the 8-wave split kernel (K >= 256, whole 128-column tiles, >= 512 rows; FSD_CONV1_SPLIT8=0 keeps the 64x64
+// tiles).  Alone the kernel is 20-25 % faster than the 64x64 tiles on these launches (13x13 1024->512 0.104 -> 0.078 ms, 26x26
+// 512->256 0.098 -> 0.084, 52x52 256->128 0.106 -> 0.085, incl. the activation-on-load variant); in the step that is 0.1-0.15 ms
+// (same box, four runs per arm: 25.81 against 25.91 ms).  (A first A/B had shown 33.7 against 27.0 ms and was blamed on the
+// 144 KB workgroups waiting behind small-LDS kernels of the side streams; it was the unbounded queue depth of section 5.0 --
+// with two steps in flight the difference is the one above.)  The row tiling (and with it the number of BatchNorm partial rows,
+// fsd_conv_row_tiles) does not depend on the activation arguments.
 inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw) {
   static const char* env = getenv("FSD_CONV1_SPLIT8");
-  if (!(env && env[0] == '1')) return false;
+  if (env && env[0] == '0') return false;
   return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 && pixels >= 512;
 }
 
