@@ -332,6 +332,10 @@ __global__ __launch_bounds__(kThreads, SPLIT ? 3 : 1) void wgrad_kernel(WgradArg
 // stay 128-channel SUB-tiles ([32 rows][128 channels] bf16, 16-byte pieces XOR-permuted by (row & 3) << 2): the swizzle and
 // the ds_read_b64_tr_b16 geometry of wgrad_kernel<128, ..., SPLIT> carry over unchanged.  Whole 32-row chunks only (the
 // launcher sends the last < 32 rows through the 64x64 kernel into an extra workspace slot, like the DMA variant).
+// ACT (the 1x1 layers' weight gradient, fsd_conv2d_wgrad_ex): x holds the RAW output of the producing convolution; the operand
+// leaky(x * x_scale[ci] + x_shift[ci]) is formed in the staging registers one value per micro-step, ahead of its split (a
+// thread's four x channels never change).  ACT = 1: 0 <= slope <= 1, max(t, t * slope); ACT = 2: the select (any slope).
+template <int ACT>
 __global__ __launch_bounds__(512, 2) void wgrad_split8_kernel(WgradArgs p) {
   constexpr int PT = kBK * 128;                    // bf16 elements of one plane of one sub-tile
   constexpr int STAGE = 9 * PT;                    // 3 sub-tiles (A0, A1, B) x 3 planes, in elements (72 KB)
@@ -420,7 +424,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_split8_kernel(WgradArgs p) {
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};     // the six terms, smallest first
 
     const int last = nk - 1;
+    f32x4 xs = {1.f, 1.f, 1.f, 1.f}, xh = {0.f, 0.f, 0.f, 0.f};
+    const float xslope = p.x_slope;
+    if constexpr (ACT != 0) {
+      xs = *reinterpret_cast<const f32x4*>(p.x_scale + n0 + cq * 4);
+      xh = *reinterpret_cast<const f32x4*>(p.x_shift + n0 + cq * 4);
+    }
+    auto act1 = [&](float v, int e) -> float {
+      const float t = __builtin_fmaf(v, xs[e], xh[e]);
+      if constexpr (ACT == 2) return t > 0.f ? t : t * xslope;
+      return __builtin_fmaxf(t, t * xslope);
+    };
     gload(0);
+    if constexpr (ACT != 0) {
+#pragma unroll
+      for (int f = 4; f < 6; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rr[f][e] = act1(rr[f][e], e);
+    }
     sstore(sm);
     gload(last < 1 ? last : 1);
     __syncthreads();
@@ -440,6 +461,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_split8_kernel(WgradArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
         if (u < 12) frag_one(cur, 1, u / 4, u % 4);                        // fragments of k-step 1: one (two reads) per MFMA
         const int f = u / 8, step = u % 8;                               // split + store of float4 f of chunk kc+1, 8 micro-steps
+        if constexpr (ACT != 0) {
+          // the x float4s (f = 4, 5) of chunk kc+1 are still raw: one value per even micro-step under the float4 before them
+          if ((f == 3 || f == 4) && step % 2 == 0) rr[f + 1][step / 2] = act1(rr[f + 1][step / 2], step / 2);
+        }
         const f32x4 v = rr[f];
         u16* d = nxt + (f >> 1) * 3 * PT + st_off + (f & 1) * 2048;
         if (step == 0) { h0 = cvt2(v[0], v[1]); h1 = cvt2(v[2], v[3]); }
@@ -680,6 +705,25 @@ inline int f32_tile(int cout, int ncols) {
   return (cout % 128 == 0 && ncols >= 128) ? 128 : 64;
 }
 
+// 1x1 weight gradients on the 8-wave split kernel: > 0 = number of row splits (few, long ones), 0 = not this shape.
+// OPT-IN (FSD_WGRAD1_SPLIT8=1).  Measured: 26x26 512->256 0.100 -> 0.083 ms, 13x13 1024->512 0.101 -> 0.087 -- but the kernel
+// only pays with >= 32 chunks (1024+ rows) per split, and an fp32 accumulator that long is where the round-off goes: relative
+// L2 error of dW against float64 5.7e-7 against 2.9e-7 for the many short splits of the 4-wave kernels (tests/test_gpu_split.py
+// holds the split arithmetic to 1.25x the native kernel's error + 2e-7: missed by 1 %).  0.06 ms per step is not worth a
+// looser gate.
+inline int split8_1x1_splits(long long pixels, int cin, int cout, int ksize) {
+  static const char* env = getenv("FSD_WGRAD1_SPLIT8");
+  if (!(env && env[0] == '1')) return 0;
+  if (!fsd_conv::f32_split_on() || f32_variant() != 0 || ksize != 1 || cout % 256 || cin % 128 || cin < 256) return 0;
+  const long long chunks = pixels / kBK;
+  if (chunks < 64) return 0;
+  const int tiles = (cout / 256) * (cin / 128);
+  long long sp = chunks / 32;                       // >= 32 chunks per split
+  const long long want = (256 + tiles - 1) / tiles; // ... but no more splits than it takes to give every CU a workgroup
+  if (sp > want) sp = want;
+  return (int)(sp < 1 ? 1 : sp);
+}
+
 int launch_wgrad(const WgradArgs& a, int bf16, dim3 grid, hipStream_t stream, int tile = 0) {
   // issued MFMA work: dW[Cout][ncols] reduced over M pixel rows, per batch (grid.z)
   fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)a.Cout * a.ncols * grid.z, stream);
@@ -735,6 +779,55 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
   if ((dy_ld & 3) || (x_ld & 3) || dy_ld < round_up(cout, 4) || x_ld < cin4) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
   if (pixels > 0x7fffffffLL - 4096) return FSD_ERR_UNSUPPORTED;
+  if (!bf16 && split8_1x1_splits(pixels, cin, cout, ksize) > 0) {
+    // 1x1 layer = plain reduction GEMM over the pixel rows: 256x128 tiles on 8 waves (wgrad_split8_kernel) over the whole 32-row
+    // chunks, few LONG splits (>= 32 chunks each: a split stores 128 KB), the last < 32 rows through the 64x64 kernel
+    const int sp = split8_1x1_splits(pixels, cin, cout, ksize);
+    const long long full = pixels / kBK * kBK;
+    const int tail = (int)(pixels - full);
+    const int slots = sp + (tail ? 1 : 0);
+    if (workspace_bytes < (size_t)slots * cout * cin * sizeof(float)) return FSD_ERR_WORKSPACE;
+    WgradArgs a;
+    a.dy = dy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
+    a.dy_ld = dy_ld; a.x_ld = x_ld;
+    a.H = 1; a.W = (int)full; a.HW = (int)full; a.M = (int)full;
+    a.Cout = cout; a.cin4 = cin; a.ks = 1; a.pad = 0; a.ncols = cin;
+    a.m_tiles = cout / 256; a.n_tiles = cin / 128;
+    a.pix_per_split = round_up((int)((full + sp - 1) / sp), kBK);
+    a.dy_bs = a.x_bs = a.ws_bs = 0;
+    a.x_scale = x_scale; a.x_shift = x_shift; a.x_slope = x_slope;
+    const size_t lds = 2 * (size_t)9 * kBK * 128 * sizeof(u16);
+    const dim3 grid(a.m_tiles * a.n_tiles, sp, 1);
+    {
+      fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin, stream);
+      const int act = !x_scale ? 0 : (x_slope >= 0.f && x_slope <= 1.f) ? 1 : 2;
+      hipError_t e = hipSuccess;
+      if (act == 0) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) FSD_LAUNCH(wgrad_split8_kernel<0>, grid, dim3(512), lds, stream, a);
+      } else if (act == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) FSD_LAUNCH(wgrad_split8_kernel<1>, grid, dim3(512), lds, stream, a);
+      } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) FSD_LAUNCH(wgrad_split8_kernel<2>, grid, dim3(512), lds, stream, a);
+      }
+      if (e != hipSuccess) return (int)e;
+    }
+    if (tail) {
+      WgradArgs t = a;
+      t.dy = dy + full * dy_ld; t.x = x + full * x_ld; t.ws = a.ws + (long long)sp * cout * cin;
+      t.H = 1; t.W = tail; t.HW = tail; t.M = tail;
+      t.m_tiles = (cout + 63) / 64; t.n_tiles = (cin + 63) / 64;
+      t.pix_per_split = kBK;
+      if (int rc = launch_wgrad(t, 0, dim3(t.m_tiles * t.n_tiles, 1, 1), stream, 64)) return rc;
+    }
+    if (slots <= 8)
+      FSD_LAUNCH(wgrad_reduce_kernel<1>, dim3((cin + 255) / 256, cout), dim3(256), 0, stream, a.ws, dw_oihw, slots, cout, cin, cin, 1, cin);
+    else
+      FSD_LAUNCH(wgrad_reduce_kernel<8>, dim3((cin + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw, slots, cout, cin, cin, 1, cin);
+    return (int)hipGetLastError();
+  }
   const int tile = bf16 ? tile_of(bf16) : f32_tile(cout, ksize * ksize * cin4);
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
@@ -836,11 +929,11 @@ int fsd_conv::wgrad_gemm_batched(const float* dy, long long dy_ld, long long dy_
     a.pix_per_split = round_up((int)((full + pl.splits - 1) / pl.splits), kBK);
     if (pl.s8) {
       const size_t lds = 2 * (size_t)9 * kBK * 128 * sizeof(u16);       // two stages x 3 sub-tiles x 3 planes
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split8_kernel<0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       fsd_prof::Scope prof(fsd_prof::kGemmWgrad, 2.0 * a.M * (double)cout * cin * batches, stream);
-      FSD_LAUNCH(wgrad_split8_kernel, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), dim3(512), lds, stream, a);
+      FSD_LAUNCH(wgrad_split8_kernel<0>, dim3(a.m_tiles * a.n_tiles, pl.splits, batches), dim3(512), lds, stream, a);
     } else {
       const size_t lds = 2 * (size_t)(2 * kBK * 128) * sizeof(float);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<128, 2, false, true, true>),
@@ -952,6 +1045,8 @@ extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int wi
     const int s = pick_splits(pixels, tiles, tile);
     splits = s > splits ? s : splits;
   }
+  const int s8 = split8_1x1_splits(pixels, cin, cout, ksize);
+  if (s8 + 1 > splits) splits = s8 + 1;             // + the slot of the < 32-row side launch
   return (size_t)splits * cout * ncols * sizeof(float);
 }
 
