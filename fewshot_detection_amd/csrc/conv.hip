@@ -395,7 +395,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 // ACT: activation on load (p.in_scale, see ConvArgs): x = leaky(y * scale[k] + shift[k]) is formed in the staging registers, one
 // value per micro-step, a chunk ahead of its split.  ACT = 1: 0 <= in_slope <= 1, leaky(t) = max(t, t * slope) (the bits of
 // affine_act4's select, one instruction less); ACT = 2: any slope, the select itself.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV = true, int ACT = 0, bool PERSIST = false>
+// DBG (timing experiments only, WRONG results; FSD_SPLIT8_DBG): 1 = no plane stores, 2 = no barrier in the loop, 3 = no global
+// loads in the loop, 4 = no split arithmetic (raw halves stored), 5 = no fragment reads of k-step 1.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ILV = true, int ACT = 0, bool PERSIST = false, int DBG = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_kernel(ConvArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   static_assert(NT == 512, "8 waves");
@@ -582,15 +584,22 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
         const f32x4 v = f < A_PER_T ? ra[f < A_PER_T ? f : 0] : rb[f < A_PER_T ? 0 : f - A_PER_T];
         unsigned char* d = f < A_PER_T ? nxt + st_off + f * RPP * ROWB : nxt + 3 * PLANE_A + st_off + (f - A_PER_T) * RPP * ROWB;
         const int pl = f < A_PER_T ? PLANE_A : PLANE_B;
+        if constexpr (DBG == 4) {                     // timing experiment: no split arithmetic
+          if (step == 2) *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]));
+          else if (step == 5) *reinterpret_cast<uint2*>(d + pl) = make_uint2(__builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+          else if (step == 7) *reinterpret_cast<uint2*>(d + 2 * pl) = make_uint2(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[3]));
+        } else {
         if (step == 0) { h0 = cvt2(v[0], v[1]); h1 = cvt2(v[2], v[3]); }
         else if (step == 1) { r0 = v[0] - lo_f(h0); r1 = v[1] - hi_f(h0); }
-        else if (step == 2) { r2 = v[2] - lo_f(h1); r3 = v[3] - hi_f(h1); *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1); }
+        else if (step == 2) { r2 = v[2] - lo_f(h1); r3 = v[3] - hi_f(h1); if constexpr (DBG != 1) *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1); }
         else if (step == 3) { m0_ = cvt2(r0, r1); m1_ = cvt2(r2, r3); }
         else if (step == 4) { r0 -= lo_f(m0_); r1 -= hi_f(m0_); }
-        else if (step == 5) { r2 -= lo_f(m1_); r3 -= hi_f(m1_); *reinterpret_cast<uint2*>(d + pl) = make_uint2(m0_, m1_); }
+        else if (step == 5) { r2 -= lo_f(m1_); r3 -= hi_f(m1_); if constexpr (DBG != 1) *reinterpret_cast<uint2*>(d + pl) = make_uint2(m0_, m1_); }
         else if (step == 6) { l0 = cvt2(r0, r1); l1 = cvt2(r2, r3); }
-        else {
-          *reinterpret_cast<uint2*>(d + 2 * pl) = make_uint2(l0, l1);
+        else if constexpr (DBG == 1) { acc[0][0][0] += __builtin_bit_cast(float, l0 ^ l1 ^ h0 ^ m1_) * 1e-30f; }
+        else *reinterpret_cast<uint2*>(d + 2 * pl) = make_uint2(l0, l1);
+        }
+        if (step == 7 && DBG != 3) {
           // this float4's registers are free: fetch its successor (chunk kc+2)
           if (f < A_PER_T) ra[f < A_PER_T ? f : 0] = *reinterpret_cast<const f32x4*>(asrc[f < A_PER_T ? f : 0] + kn * kBK);
           else rb[f < A_PER_T ? 0 : f - A_PER_T] = *reinterpret_cast<const f32x4*>(bsrc + (f - A_PER_T) * b_step + kn * kBK);
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
       for (int u = 0; u < NMF; ++u) {
         const int ks = u / (NMF / 2), t = (u % (NMF / 2)) / (TM * TN), i = (u % (TM * TN)) / TN, j = u % TN;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][TA[t]][i], bf[ks][TB[t]][j], acc[i][j], 0, 0, 0);
-        if (u < NFR) {                                                   // fragments of k-step 1: one per MFMA
+        if (u < NFR && DBG != 5) {                                       // fragments of k-step 1: one per MFMA
           const int q = u / (TM + TN), w = u % (TM + TN);
           if (w < TM) af[1][q][w] = *reinterpret_cast<const bf16x8*>(cur + fa_off + q * PLANE_A + w * 32 * ROWB + po1);
           else bf[1][q][w - TM] = *reinterpret_cast<const bf16x8*>(cur + fb_off + q * PLANE_B + (w - TM) * 32 * ROWB + po1);
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void conv_gemm_split8_ke
         for (int sidx = u * NST / NMF; sidx < (u + 1) * NST / NMF; ++sidx) micro(sidx);
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      if constexpr (DBG != 2) __syncthreads();
     }
     // ---- end of the tile: fetch the first chunk of the next one, then store this one ----
     const int em0 = m0, en0 = n0, emt = mt;
@@ -709,6 +718,17 @@ int launch_split8_grid(K k, const ConvArgs& a, size_t lds, bool persist, hipStre
 
 template <int BM, int ACT>
 int launch_split8_t(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  static const char* dbg = getenv("FSD_SPLIT8_DBG");                 // timing experiments, wrong results
+  if (dbg && BM == 256 && ACT == 0) {
+    switch (dbg[0]) {
+      case '1': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 1>, a, lds, false, stream);
+      case '2': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 2>, a, lds, false, stream);
+      case '3': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 3>, a, lds, false, stream);
+      case '4': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 4>, a, lds, false, stream);
+      case '5': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 5>, a, lds, false, stream);
+      default: break;
+    }
+  }
   static const char* env = getenv("FSD_SPLIT8_PERSIST");
   if (env && env[0] == '1') return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, true>, a, lds, true, stream);
   return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, false>, a, lds, false, stream);
