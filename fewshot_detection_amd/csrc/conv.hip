@@ -75,7 +75,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   } else {
     L = xcd_swizzle(blockIdx.x, gridDim.x);
   }
+  int kc0 = 0, kc1 = p.nk;      // this workgroup's k-chunks (split-K: one slice)
   if (gridDim.y > 1) {      // batched GEMMs: every batch has its own operand / result matrices
+    if (p.ksplit > 1) {
+      const int slice = batch % p.ksplit;
+      batch /= p.ksplit;
+      const int per = p.nk / p.ksplit;
+      kc0 = slice * per;
+      kc1 = kc0 + per;
+      p.y += (long long)slice * p.y_ks;
+    }
     p.x += (long long)batch * p.x_bs;
     p.w = static_cast<const float*>(p.w) + (long long)batch * p.w_bs;
     p.y += (long long)batch * p.y_bs;
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // address work is one add per load.  Offsets are 32-bit element indices (launcher checks range).
   unsigned a_off[A_PER_T];
   unsigned tap_mask = 0;
-  int f_tap = 0, f_cc = 0;
+  int f_tap = 0, f_cc = kc0;         // (split-K launches are 1x1: one tap, the chunk index is the channel chunk)
   auto retap = [&]() {
     const int ky = f_tap / p.ks, kx = f_tap - ky * p.ks;
     const int dy = ky - p.pad, dx = kx - p.pad;
@@ -355,12 +364,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     }
     __syncthreads();
   } else {
-  gload(0);
+  gload(kc0);
   sstore(smem);
   __syncthreads();
   int cur = 0;
-  for (int kc = 0; kc < p.nk; ++kc) {
-    const bool more = kc + 1 < p.nk;
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const bool more = kc + 1 < kc1;
     if (more) gload(kc + 1);
     __builtin_amdgcn_sched_barrier(0);   // the zero-select/LDS store of the prefetched registers stays below the MFMAs
     compute(smem + cur * STAGE);
@@ -741,7 +750,7 @@ int launch_kernel(K k, const ConvArgs& a, size_t lds, int threads, hipStream_t s
   // issued MFMA work of this launch: every output row x column x (padded) reduction element, all batches
   const double rows = (double)a.M - (double)a.m_base;
   fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * rows * a.Cout * ((double)a.nk * kBK) * a.batches, stream);
-  FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, a.batches), dim3(threads), lds, stream, a);
+  FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, a.batches * a.ksplit), dim3(threads), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -844,7 +853,9 @@ inline char batched_pick(long long rows, int cin, int cout) {
 inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw) {
   static const char* env = getenv("FSD_CONV1_SPLIT8");
   if (env && env[0] == '0') return false;
-  return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 && pixels >= 512;
+  // ... and only when the 256x128 tiles cover at least half of the 256 CUs (two images at 26x26 are 10 such tiles: 64x64 there)
+  return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 &&
+         (pixels / 256) * (cout / 128) >= 128;
 }
 
 // How many of the `batches` positions of a batched launch go to the 256-row tiles (the rest: 128-row tiles, second launch).
@@ -895,11 +906,39 @@ int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_
   return (int)((rows + bm - 1) / bm);
 }
 
+// Split-K of a batched launch.  Two images at 13x13 are 32 tile rows per Winograd position: 36 positions x 16 column tiles =
+// 576 workgroups of 64x64, ~2 per CU, each with ONE 16 KB k-chunk in flight at a time (single LDS stage) -- the launch streams
+// its 151 MB of transformed weights (1024 -> 1024) at 2.8 TB/s, 54 us.  Cutting K puts more chunks in flight; the slices land
+// side by side and the output transform adds them on load (they are 4.7 MB each at that size).
+// MEASURED SLOWER (two images, whole forward 0.83 -> 0.87 ms; four images 0.98 -> 1.05; train step unchanged), so it is OPT-IN:
+// FSD_KSPLIT=a picks the slices automatically (launches short of workgroups, < 1024, with >= 8 chunks per slice), =N forces N.
+// The launch is not short of requests in flight: it reads U exactly once in 128-byte pieces 4 KB apart (64 rows of a [n][K]
+// panel per chunk), which is what HBM serves at ~2.8 TB/s; more, shorter workgroups scatter the pieces further.  A chunk-major
+// copy of U for these launches (8 KB contiguous per workgroup and chunk) is the layout that would stream.
+int fsd_conv::batched_ksplit(long long rows, int cin, int cout, int batches) {
+  static const char* env = getenv("FSD_KSPLIT");
+  if (!env || cin % kBK != 0) return 1;
+  const int nk = cin / kBK;
+  const char pick = batched_pick(rows, cin, cout);
+  if (pick != 'a' && pick != 'c') return 1;                       // the register-staged 4-wave kernels (plain main loop)
+  if (env[0] != 'a') {
+    const int forced = atoi(env);
+    return forced >= 1 && forced <= 16 && nk % forced == 0 ? forced : 1;
+  }
+  const int bm = pick == 'c' ? 128 : 64, bn = bm;
+  const long long total = ((rows + bm - 1) / bm) * ((cout + bn - 1) / bn) * batches;
+  int s = 1;
+  while (s < 8 && total * s < 1024 && nk % (2 * s) == 0 && nk / (2 * s) >= 8) s *= 2;
+  return s;
+}
+
 int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs,
                                 float* y, long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches,
-                                hipStream_t stream) {
+                                hipStream_t stream, int ksplit, long long y_ks) {
   if (cin % kBK != 0 || rows < 1 || rows > 0x7fffffffLL - 512 || (rows + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
+  if (ksplit < 1 || (ksplit > 1 && (ksplit != batched_ksplit(rows, cin, cout, batches) || (y_ks & 3)))) return FSD_ERR_ARG;
   ConvArgs a;
+  a.ksplit = ksplit; a.y_ks = y_ks;
   a.x = x; a.w = w_packed; a.bias = nullptr; a.y = y; a.bn_partial = nullptr;
   a.x_ld = x_ld; a.y_ld = y_ld;
   a.H = 1; a.W = (int)rows; a.HW = (int)rows; a.M = (int)rows;     // one "image" of `rows` pixels, 1x1 taps

@@ -38,6 +38,11 @@ struct ConvArgs {
   const float* in_scale;
   const float* in_shift;
   float in_slope;
+  // split-K of the batched plain GEMMs (conv_gemm_batched, 4-wave split kernel): gridDim.y = batches * ksplit; slice s of batch
+  // b reduces k-chunks [s, s + 1) * nk / ksplit into y + b * y_bs + s * y_ks -- the reader (Winograd output transform) adds the
+  // slices.  1 = off (every other launch).
+  int ksplit = 1;
+  long long y_ks = 0;
 };
 
 // leaky(v * sc + sh), the expression of bn_act_pool_kernel (elementwise.hip): consumers that apply it on load produce the
@@ -53,8 +58,13 @@ __device__ __forceinline__ f32x4 affine_act4(f32x4 v, f32x4 sc, f32x4 sh, float 
 }
 
 // fp32 1x1 "convolutions" as a batch of plain GEMMs y[b] = x[b] * w[b]^T (defined in conv.hip)
+// ksplit > 1: the reduction is cut into ksplit slices, slice s written at y + s * y_ks (see ConvArgs; batched_ksplit's answer)
 int conv_gemm_batched(const float* x, long long x_ld, long long x_bs, const float* w_packed, long long w_bs, float* y,
-                      long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches, hipStream_t stream);
+                      long long y_ld, long long y_bs, long long rows, int cin, int cout, int batches, hipStream_t stream,
+                      int ksplit = 1, long long y_ks = 0);
+// how many K slices a batched launch of this shape should be cut into (1 = none): few rows per batch (a small batch of images
+// or the reweighting net's 3x3 / 7x7 maps) leave the launch with ~2 workgroups per CU, each waiting for one 16 KB chunk at a time
+int batched_ksplit(long long rows, int cin, int cout, int batches);
 
 // fp32 -> three bfloat16 planes x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); the residuals
 // are exact: 3 x 8 significant bits = the 24 of fp32) for four values; see conv.hip, conv_gemm_kernel SPLIT.

@@ -718,10 +718,13 @@ __global__ FSD_XFORM_LB void wino4_output_kernel(const float* __restrict__ Mb, c
 
 // The same with FOUR channels per thread (16-byte loads of M and 16-byte stores of y; 64 accumulator registers): for layers
 // with >= 128 output channels.  FSD_WINO_OUT4=0 keeps the two-channel kernel everywhere.
-template <int GL>
+// KS: the position GEMMs were cut into `ks` K slices (fsd_conv::batched_ksplit), slice s lies `ss` floats behind slice 0: added
+// on load, in slice order.
+template <int GL, bool KS = false>
 __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                            float* __restrict__ y, long long y_ld, float* __restrict__ partial,
-                                                           int H, int W, int TH, int TW, int C, long long T, int tpb, float slope) {
+                                                           int H, int W, int TH, int TW, int C, long long T, int tpb, float slope,
+                                                           int ks, long long ss) {
   constexpr int NPL = 256 / GL;
   __shared__ float s_red[NPL][GL][8];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
@@ -743,12 +746,18 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
       const int ty = (int)(ut2 % (unsigned)TH);
       const long long b = ut2 / (unsigned)TH;
       const float* src = Mb + tile * C + g * 4;
+      auto ldm = [&](const float* q) -> f32x4 {
+        f32x4 v = ld4(q);
+        if constexpr (KS)
+          for (int sl = 1; sl < ks; ++sl) v += ld4(q + sl * ss);
+        return v;
+      };
       f32x4 o[4][4];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         f32x4 u[4];
-        at4(ld4(src + (r * 6 + 0) * ps), ld4(src + (r * 6 + 1) * ps), ld4(src + (r * 6 + 2) * ps),
-            ld4(src + (r * 6 + 3) * ps), ld4(src + (r * 6 + 4) * ps), ld4(src + (r * 6 + 5) * ps), u);
+        at4(ldm(src + (r * 6 + 0) * ps), ldm(src + (r * 6 + 1) * ps), ldm(src + (r * 6 + 2) * ps),
+            ldm(src + (r * 6 + 3) * ps), ldm(src + (r * 6 + 4) * ps), ldm(src + (r * 6 + 5) * ps), u);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (r == 0) { o[0][j] = u[j]; }
@@ -951,9 +960,20 @@ extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int co
   return (int)hipGetLastError();
 }
 
+inline bool out4_on(int cout) {
+  static const char* out4_env = getenv("FSD_WINO_OUT4");
+  return cout >= 128 && !(out4_env && out4_env[0] == '0');
+}
+
+// K slices of the forward / data-gradient position GEMMs (only the four-channel output transform adds slices)
+inline int fwd_ksplit(long long T, int cin, int cout, int tile) {
+  return tile == 4 && out4_on(cout) ? fsd_conv::batched_ksplit(T, cin, cout, npos(tile)) : 1;
+}
+
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
-  return (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + pos_stride(T, cout)) * sizeof(float);
+  const int ks = fwd_ksplit(T, cin, cout, tile);
+  return (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + ks * pos_stride(T, cout)) * sizeof(float);
 }
 
 extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
@@ -1019,8 +1039,10 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     V = Vw;
   }
   const int rows_pad = round_up(cout, 128);
+  const int ks = fwd_ksplit(T, cin, cout, tile);
+  const long long ss = (long long)P * pos_stride(T, cout);          // slice s of every position lies behind slice s - 1 of all
   int rc = fsd_conv::conv_gemm_batched(V, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout, pos_stride(T, cout), T, cin, cout,
-                                       P, stream);
+                                       P, stream, ks, ss);
   if (rc != 0) return rc;
   const int tpb = tiles_per_block(T);
   const unsigned bx = (unsigned)((T + tpb - 1) / tpb);
@@ -1030,10 +1052,12 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                        bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
-    static const char* out4_env = getenv("FSD_WINO_OUT4");
-    if (cout >= 128 && !(out4_env && out4_env[0] == '0'))
+    if (out4_on(cout) && ks > 1)
+      FSD_LAUNCH((wino4_output4_kernel<32, true>), dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, ks, ss);
+    else if (out4_on(cout))
       FSD_LAUNCH(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb, slope);
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, 1, 0LL);
     else if (cg <= 32)
       FSD_LAUNCH(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);

@@ -283,6 +283,8 @@ class Network(object):
         first = not wino and not xv.bf16 and ops.c4_bnfused_eligible(xv, cout, k)   # NHWC4 input: direct-operand first-layer kernel
         if (FOLD_EVAL_BN and bn is not None and not training and not self._record
                 and (not bf16 or (xv.bf16 and xv.C % 32 == 0 and cout % 2 == 0 and xv.c0 % 8 == 0) or first)):
+            if wino:
+                wino = ops.wino_tile_inference(xv.C, cout, k, xv.H, xv.W, xv.B)
             return self._conv_eval(ind, xv, conv, bn, k, cout, slope, pool, wino, first, bufs, tape)
         wp = self.cache.get(conv.weight, 0, "wino%d" % wino) if wino else None
         dev = xv.t.device

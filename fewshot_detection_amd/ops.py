@@ -254,6 +254,20 @@ def wino_tile(cin, cout, ksize, H, W):
     return 2 if lo >= 128 else 0
 
 
+def wino_tile_inference(cin, cout, ksize, H, W, batch):
+    """The inference form's choice (BatchNorm folded, nothing kept for a backward pass): wino_tile's, except that a position
+    GEMM of at most 64 rows is bound by READING its transformed weights -- 36 x Cin x Cout floats for F(4x4) against 16 for
+    F(2x2): 151 MB against 67 MB on a 1024 -> 1024 layer, 30 us against 13 at the transforms' 5 TB/s, which is more than
+    the layer's arithmetic at valid_ensemble.py's two images per batch.  OPT-IN (FSD_INFER_F2=1): measured on MI355X the
+    forward of two images went from 0.83 to 0.88 ms with it -- the F(4x4) launches are short of bytes in flight, not of
+    bandwidth (fsd_conv::batched_ksplit is the fix that worked), and the F(2x2) transforms are the older, slower kernels."""
+    tile = wino_tile(cin, cout, ksize, H, W)
+    if (tile == 4 and SMALL_BATCH_F2 and batch * ((H + 3) // 4) * ((W + 3) // 4) <= 64 and cin * cout >= 512 * 512):
+        return 2
+    return tile
+
+
+SMALL_BATCH_F2 = os.environ.get("FSD_INFER_F2", "0") == "1"
 WINOGRAD = True     # Winograd for eligible fp32 3x3 layers (forward, data gradient, weight gradient)
 WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
 # One-pass BN backward + both gradient transforms (fsd_wino_grad_transforms).  Bit-identical to the separate kernels but

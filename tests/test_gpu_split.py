@@ -33,8 +33,10 @@ SHAPES = [  # B, H, W, cin, cout, k
     (2, 104, 104, 32, 64, 3),      # direct 3x3
     (2, 112, 112, 32, 64, 3),      # direct 3x3, halo-staged under split (H % 8 == 0, W % 16 == 0): forward 32->64, data gradient 64->32
     (3, 16, 32, 64, 64, 3),        # halo-staged, two 32-channel slices each way
-    (4, 26, 26, 512, 256, 1),      # 1x1
+    (4, 26, 26, 512, 256, 1),      # 1x1 (20 tiles of 256x128: too few for the 8-wave kernel, 64x64 tiles)
+    (24, 26, 26, 512, 512, 1),     # 1x1 on the 8-wave kernel: 63 whole 256-row tiles x 4 + a 96-row tail on 64x64 tiles
     (3, 7, 7, 256, 512, 3),        # small map of the reweighting net
+    (2, 13, 13, 512, 1024, 3),     # two images (valid_ensemble.py's batch): 32 rows per position (FSD_KSPLIT=a: K cut into 2 / 4 slices)
 ]
 
 

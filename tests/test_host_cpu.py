@@ -325,3 +325,20 @@ def test_batchnorm_batch_counters_follow_state_dict_and_load_state_dict():
     m[1]._fsd_pending_batches = 1
     ops.flush_bn_counters(m)
     assert int(m[1].num_batches_tracked) == 6
+
+
+def test_inference_can_pick_the_smaller_winograd_form_when_the_weights_are_the_traffic(monkeypatch):
+    """Opt-in rule (FSD_INFER_F2=1; measured slower, see ops.wino_tile_inference): valid_ensemble.py's two images at 13x13 are
+    32 tiles per position -> F(2x2) (16 weight planes instead of 36); the training batch and the wider feature maps keep
+    wino_tile's answer; narrow layers too (their weights are small either way).  Off: wino_tile's answer everywhere."""
+    from fewshot_detection_amd import ops
+    assert ops.wino_tile(1024, 1024, 3, 13, 13) == 4
+    monkeypatch.setattr(ops, "SMALL_BATCH_F2", False)
+    assert ops.wino_tile_inference(1024, 1024, 3, 13, 13, 2) == 4
+    monkeypatch.setattr(ops, "SMALL_BATCH_F2", True)
+    assert ops.wino_tile_inference(1024, 1024, 3, 13, 13, 2) == 2
+    assert ops.wino_tile_inference(512, 1024, 3, 13, 13, 2) == 2
+    assert ops.wino_tile_inference(1024, 1024, 3, 13, 13, 64) == 4
+    assert ops.wino_tile_inference(256, 512, 3, 26, 26, 2) == 4        # 98 tiles per position
+    assert ops.wino_tile_inference(128, 256, 3, 13, 13, 2) == 4        # 1.2 MB of transformed weights
+    assert ops.wino_tile_inference(1024, 1024, 1, 13, 13, 2) == 0
