@@ -910,11 +910,16 @@ int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_
 // 576 workgroups of 64x64, ~2 per CU, each with ONE 16 KB k-chunk in flight at a time (single LDS stage) -- the launch streams
 // its 151 MB of transformed weights (1024 -> 1024) at 2.8 TB/s, 54 us.  Cutting K puts more chunks in flight; the slices land
 // side by side and the output transform adds them on load (they are 4.7 MB each at that size).
-// MEASURED SLOWER (two images, whole forward 0.83 -> 0.87 ms; four images 0.98 -> 1.05; train step unchanged), so it is OPT-IN:
-// FSD_KSPLIT=a picks the slices automatically (launches short of workgroups, < 1024, with >= 8 chunks per slice), =N forces N.
-// The launch is not short of requests in flight: it reads U exactly once in 128-byte pieces 4 KB apart (64 rows of a [n][K]
-// panel per chunk), which is what HBM serves at ~2.8 TB/s; more, shorter workgroups scatter the pieces further.  A chunk-major
-// copy of U for these launches (8 KB contiguous per workgroup and chunk) is the layout that would stream.
+// MEASURED SLOWER, so it is OPT-IN (FSD_KSPLIT=a picks the slices automatically -- launches short of workgroups, < 1024, with
+// >= 8 chunks per slice -- =N forces N): two images, whole forward 0.83 -> 0.87 ms; four images 0.98 -> 1.05; train step
+// unchanged.  Per kernel (rocprofv3, 13 Winograd layers of one forward): the 64x64 GEMMs 406 -> 382 us with 2 slices, 373 with
+// 4 -- and the output transform that adds the slices 6.5 -> 16.5 / 35.7 us per launch.  So the launch is NOT short of bytes in
+// flight, and not bound by its access pattern either (tools/probes/panel_stream_probe.hip: the same 576 workgroups reading the
+// same panels the same way, one chunk ahead of a barrier, stream 151 MB in 33.7 us = 4.5 TB/s; 5.7 TB/s if a chunk's 64 x 32
+// block were contiguous).  It is bound by what a CU does per chunk whatever the concurrency: the split of 16 operand values per
+// thread (~160 VALU instructions = 640 cycles a wave) + 12 MFMAs (384) + the LDS round trip, serialised by the single stage --
+// 72 chunk-tiles per CU x ~1500 cycles = 54 us.  Operands that are constant between calls (inference weights) would have to
+// arrive already split for these launches to approach the 30 us their bytes cost.
 int fsd_conv::batched_ksplit(long long rows, int cin, int cout, int batches) {
   static const char* env = getenv("FSD_KSPLIT");
   if (!env || cin % kBK != 0) return 1;
