@@ -838,6 +838,12 @@ inline char batched_pick(long long rows, int cin, int cout) {
     static const char* k_env = getenv("FSD_WINO_SPLIT8");      // tuning aid: 0 keeps the 4-wave tiles everywhere
     // (K <= 128: those launches are bound by the V / M traffic, where two 4-wave workgroups per CU hide each other's epilogue)
     if (!(k_env && k_env[0] == '0') && rows >= 512 && cout >= 128 && cout % 128 == 0 && cin >= 256) return 'k';
+    // 'b': at most 32 rows per position (two images at 13x13, the reweighting net's 3x3 maps of 20 supports): a 32x128 tile
+    // (1 x 4 waves).  Such a launch is bound by what a CU does per k-chunk -- the split of every staged value, the MFMAs, the
+    // LDS round trip (see batched_ksplit) -- and half of a 64x64 tile's rows are padding: 32x128 stages 5120 values for four
+    // useful 32x32 tiles where 64x64 stages 4096 for two.  FSD_WINO_TILE32=0 keeps 64x64.
+    static const char* b_env = getenv("FSD_WINO_TILE32");
+    if (!(b_env && b_env[0] == '0') && rows <= 32 && cout >= 128 && cout % 128 == 0) return 'b';
     return rows >= 96 && cout > 64 ? 'c' : 'a';
   }
   return cin >= 512 && cout >= 512 && cout % 128 == 0 && rows >= 256 ? 'd' : 'a';
@@ -896,10 +902,16 @@ extern "C" int fsd_f32_gemm_mode(int mode) {
   return prev;
 }
 
+inline void batched_tile(char pick, int* bm, int* bn) {
+  const int big = pick == 'c' || pick == 'd' || pick == 'k';
+  *bm = pick == 'k' ? 256 : pick == 'b' ? 32 : (big || pick == 'e' || pick == 'h') ? 128 : 64;
+  *bn = big || pick == 'b' ? 128 : 64;
+}
+
 int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_out, int* bn_out, int* dma_out) {
   const char pick = batched_pick(rows, cin, cout);
-  const int big = pick == 'c' || pick == 'd' || pick == 'k';
-  const int bm = pick == 'k' ? 256 : (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
+  int bm, bn;
+  batched_tile(pick, &bm, &bn);
   if (bm_out) *bm_out = bm;
   if (bn_out) *bn_out = bn;
   if (dma_out) *dma_out = pick == 'd';
@@ -955,7 +967,8 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.cpt = cin / kBK;
   const char pick = batched_pick(rows, cin, cout);
   const int big = pick == 'c' || pick == 'd' || pick == 'k';
-  const int bm = pick == 'k' ? 256 : (big || pick == 'e' || pick == 'h') ? 128 : 64, bn = big ? 128 : 64;
+  int bm, bn;
+  batched_tile(pick, &bm, &bn);
   a.m_tiles = (int)((rows + bm - 1) / bm);
   a.n_tiles = (cout + bn - 1) / bn;
   a.m_base = 0;
@@ -992,6 +1005,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
     }
     return launch_split8_t<256, 0>(a, lds_k, stream);
   }
+  if (pick == 'b') return launch<32, 128, 1, 4, 1>(a, false, stream);
   if (pick == 'e') return launch<128, 64, 4, 1, 1>(a, false, stream);
   if (pick == 'h') return launch<128, 64, 2, 2, 2, true>(a, false, stream);      // 128x64 DMA, two stages (48 KB: 3 per CU)
   if (pick == 'f') return launch<64, 64, 2, 2, 2, true>(a, false, stream);       // 64x64 DMA, two stages

@@ -169,3 +169,25 @@ def test_halo_staged_narrow_conv_epilogue(dev, B, H, W, cin, cout):
     got = ops.nhwc_to_nchw(dst).cpu().double()
     assert float((got - refb).abs().max()) < 2e-5 * float(refb.abs().max())
     assert float((wide.t[:, :32] - 7.0).abs().max()) == 0.0          # the neighbouring channels are untouched
+
+
+def test_positions_of_at_most_32_rows_take_the_32x128_tile(dev):
+    """Two images at 13x13 (valid_ensemble.py's batch) and the reweighting net's 3x3 maps: 32 / 20 tile rows per Winograd
+    position.  Under the split arithmetic such a launch runs 32x128 tiles (half of a 64x64 tile would be padding that is
+    split and multiplied like data); 33+ rows, narrow outputs and the native arithmetic keep 64x64."""
+    import ctypes as C
+    from fewshot_detection_amd import ops
+    L = ops.lib()
+
+    def plan(B, H, W, cin, cout):
+        a = (C.c_int * 4)()
+        assert L.fsd_wino_fwd_plan(B, H, W, cin, cout, 4, a) == 0
+        return tuple(a)[:2] + (a[3],)
+
+    ops.f32_gemm_mode("split")
+    assert plan(2, 13, 13, 1024, 1024) == (32, 128, 1)
+    assert plan(20, 3, 3, 512, 1024) == (32, 128, 1)
+    assert plan(3, 13, 13, 1024, 1024) == (64, 64, 1)          # 48 rows
+    assert plan(2, 13, 13, 1024, 64) == (64, 64, 1)
+    ops.f32_gemm_mode("native")
+    assert plan(2, 13, 13, 1024, 1024) == (64, 64, 1)
