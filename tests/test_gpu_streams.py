@@ -134,5 +134,24 @@ def test_autotune_keeps_streams_that_pay_and_drops_streams_that_do_not():
         finally:
             streams.reset = orig
         assert rep["enabled_after"] is False and streams.ENABLED is False and len(rep["tries"]) == 2 and len(made) == 2
+        # a set that overlaps only a little is traded for a new draw; the better of the sets seen is the one that stays
+        dev = torch.device("cuda:0")
+        streams.ENABLED = True
+        streams.reset()
+        seen = []
+
+        def step():
+            if streams.ENABLED:
+                st = streams.side(dev, "probe")
+                if not any(st is t for t in seen):
+                    seen.append(st)
+                time.sleep(0.0078 if st is seen[0] else 0.0090)        # first set: 2.5 % under one stream; later sets: slower
+            else:
+                time.sleep(0.008)
+        rep = streams.autotune(step, tries=3, reps=2)
+        assert rep["enabled_after"] is True and len(rep["tries"]) == 3 and len(seen) == 3
+        assert streams.side(dev, "probe") is seen[0]
+        assert abs(rep["kept_ms"] - rep["tries"][0]["streams_ms"]) < 1e-9
     finally:
+        streams.reset()
         streams.ENABLED = before
