@@ -111,6 +111,7 @@ PROTOTYPES = {
     "fsd_launch_count": (_ll, [_i]),
     "fsd_clock_probe": (_i, [_p, _i, _p, _p]),
     "fsd_f32_gemm_mode": (_i, [_i]),
+    "fsd_wino_fused_mode": (_i, [_i]),
     "fsd_version": (C.c_char_p, []),
 }
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
@@ -804,6 +805,310 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
   }
 }
 
+// Input transform for the fused kernel below: V = B^T d B as three bf16 PLANES (conv.hip's split: x = x1 + x2 + x3) in the
+// MFMA's fragment order -- [plane][position][32-tile block][k / 16][lane][8], lane = (tile & 31) + 32 * ((k >> 3) & 1) -- so the
+// A operand of a v_mfma_f32_32x32x16_bf16 is 64 lanes x 16 contiguous bytes and nobody splits V again (the first version of the
+// fused kernel read the row-major fp32 V, a lane's 32 bytes a row apart from its neighbour's: 64 cache lines per load, and
+// split it once per 32-channel output block).  A wave = 32 tiles x 8 channels, lane = (tile, channel quad): its store of one
+// plane of one position is 512 contiguous bytes.  KEEP: the fp32 V the weight gradient reads is written as well.
+template <bool ACT, bool KEEP>
+__global__ __launch_bounds__(256) void wino4_input_planes_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
+                                                                uint2* __restrict__ planes, long long plane_u2, int H, int W,
+                                                                int TH, int TW, int C, long long T,
+                                                                const float* __restrict__ in_scale,
+                                                                const float* __restrict__ in_shift, float in_slope) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c8n = C >> 3;
+  const long long wv = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
+  const long long tb = wv / c8n;
+  const int c8 = (int)(wv - tb * c8n);
+  const long long TB = (T + 31) >> 5;
+  if (tb >= TB) return;
+  const int r = lane >> 1, q = lane & 1;
+  const int c = c8 * 8 + q * 4;
+  const long long tile = tb * 32 + r;
+  const bool t_ok = tile < T;
+  const unsigned utile = (unsigned)(t_ok ? tile : 0);
+  const int tx = (int)(utile % (unsigned)TW);
+  const unsigned ut2 = utile / (unsigned)TW;
+  const int ty = (int)(ut2 % (unsigned)TH);
+  const long long b = ut2 / (unsigned)TH;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = zero;
+  if constexpr (ACT) { isc = ld4(in_scale + c); ish = ld4(in_shift + c); }
+  f32x4 d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int iy = 4 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = 4 * tx - 1 + j;
+      const bool ok = t_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      f32x4 v = ok ? ld4(x + ((b * H + iy) * (long long)W + ix) * x_ld + c) : zero;
+      if constexpr (ACT) {
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {                    // the expression of bn_act_pool_kernel (elementwise.hip)
+            const float t = __builtin_fmaf(v[k], isc[k], ish[k]);
+            v[k] = t > 0.f ? t : t * in_slope;
+          }
+        }
+      }
+      d[i][j] = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {            // columns: t = B^T d (in place)
+    f32x4 rr[6];
+    bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], rr);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i][j] = rr[i];
+  }
+  const int KS = C >> 4;
+  // uint2 (4 bf16) index of this lane's piece inside one position of one plane
+  const long long piece = ((tb * KS + (c8 >> 1)) * 64 + r + 32 * (c8 & 1)) * 2 + q;
+  const long long pos_u2 = TB * KS * 128;                  // uint2 per position
+  float* dstv = KEEP ? V + tile * C + c : nullptr;
+  const long long ps = pos_stride(T, C);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {            // rows: V = t B
+    f32x4 rr[6];
+    bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], rr);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if constexpr (KEEP) {
+        if (t_ok) st4(dstv + (i * 6 + j) * ps, rr[j]);
+      }
+      uint2 h, m, l;
+      fsd_conv::split3(rr[j], h, m, l);
+      uint2* dp = planes + (i * 6 + j) * pos_u2 + piece;
+      dp[0] = h;
+      dp[plane_u2] = m;
+      dp[2 * plane_u2] = l;
+    }
+  }
+}
+
+// ---- fused position GEMMs + output transform for SHORT reductions (round 4; EXPERIMENTAL, off: fsd_wino_fused_mode) ---------
+// The F(4x4) layers with 64 or 128 input channels (104x104 64 <-> 128, 52x52 128 -> 256 and the reweighting net's twins) are
+// bound by their intermediates, not by arithmetic: M = 36 x tiles x Cout floats is written by the position GEMMs and read back
+// by the output transform -- 797 MB each way on 64 -> 128 at 104x104, where the layer's own input + output are 531 MB -- and
+// the GEMM launch (two k-chunks a tile: all prologue and epilogue) runs AT the HBM rate, 4.2-4.4 TB/s, with the matrix cores
+// 0.29 busy.  Here M never leaves the CU: a workgroup owns 32 tiles x 32 output channels, its four waves compute the 36
+// position products M[p] = V[p] U[p]^T (32 x 32 x K each, nine positions a wave) into LDS -- 36 x 32 x 32 floats = 144 KB --
+// and the same workgroup then runs the output transform A^T M A (+ bias, leaky, BatchNorm partial sums) out of LDS, exactly the
+// arithmetic of wino4_output4_kernel.  With LDS full of M the operands cannot be staged there: both arrive as bf16 planes in
+// the MFMA's fragment order (wino4_input_planes_kernel, wino4_split_planes_kernel: every load is 64 lanes x 16 contiguous
+// bytes, nothing is split in this kernel) and go from global memory straight into the MFMA.
+// MEASURED (64 -> 128 at 104x104, B = 64; the three launches: transform 0.12 + GEMM 0.35 + transform 0.23 = 0.70 ms):
+//   row-major fp32 V split in registers, row-major U planes      0.75 ms in the kernel (+ 0.10 input transform)
+//   + U in fragment order, rolled stage loop (18 unrolled stages of K = 128 overflow the instruction cache)   0.52
+//   + V as planes in fragment order from the input transform     0.55 (+ 0.19: the transform now writes 2.5x)
+//   8 waves instead of 4, prefetch without a branch, two accumulators: 0.52-0.60, i.e. no change.
+// PMC on that launch says why nothing moved it: MFMA-busy 0.14, the texture addresser busy 65 % of the time, the L1 stalled on
+// pending misses 65 % of the time, 19 bytes / clock / CU delivered of the L1's 64.  A 32 x 32 wave tile fed from L1 needs 1 KB
+// of operands per MFMA -- 128 bytes / clock / CU at full matrix rate, twice what the L1 can deliver even when it hits, and
+// here half of the lines come from L2 (every workgroup streams the same U planes, V once per 32-channel block).  An MFMA
+// kernel needs the operand reuse of an LDS-staged tile, and LDS is where M sits.
+// The way out (not built): the output transform is separable -- y += At[., r] x (M[r][.] A) -- so only the SIX positions of one
+// transform row have to be resident at a time (24 KB for 32 x 32, 98 KB for 64 x 64 tiles) if the 4 x 4 partial outputs stay
+// in registers across the six row groups; that leaves LDS for a normally staged 64 x 64 GEMM tile.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// U [36][rows_pad][K] fp32 -> three bf16 planes in FRAGMENT ORDER: [plane][position][32-row block][k / 16][lane][8], lane =
+// (row & 31) + 32 * ((k >> 3) & 1) -- the B operand of one v_mfma_f32_32x32x16_bf16 is then 64 lanes x 16 contiguous bytes.
+// (Read straight from the row-major panel, a lane's 16 bytes are a row apart from its neighbour's: 64 cache lines per load
+// instruction, and the L1 handles a line a cycle -- the first version of the kernel below spent its time there.)
+__global__ __launch_bounds__(256) void wino4_split_planes_kernel(const float* __restrict__ u, uint2* __restrict__ planes,
+                                                                 long long n4, int rows_pad, int K) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  uint2 h, m, l;
+  fsd_conv::split3(ld4(u + i * 4), h, m, l);
+  const int k4 = K >> 2;
+  const int k = (int)(i % k4) * 4;
+  const long long rowi = i / k4;                         // position * rows_pad + row
+  const int n = (int)(rowi % rows_pad);
+  const long long pos = rowi / rows_pad;
+  const long long d = ((((pos * (rows_pad >> 5) + (n >> 5)) * (K >> 4) + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)) >> 2;
+  planes[d] = h;
+  planes[d + n4] = m;
+  planes[d + 2 * n4] = l;
+}
+
+struct FusedArgs {
+  const unsigned short* V3;       // three planes of the transformed input, fragment order (wino4_input_planes_kernel)
+  const unsigned short* U3;       // three planes of the transformed weights, fragment order (wino4_split_planes_kernel)
+  const float* bias;
+  float* y;
+  float* partial;                 // [ceil(T / tpb)][N][2] or null
+  long long y_ld, v_plane_elems, plane_elems, T;
+  int H, W, TH, TW, N, rows_pad, tpb;
+  float slope;
+};
+
+constexpr int kFusedTiles = 32, kFusedCols = 32;
+constexpr size_t kFusedLds = (size_t)36 * kFusedTiles * kFusedCols * 4 + (size_t)kFusedTiles * 8 * 8 * 4;
+
+template <int K, int NW>
+__global__ __launch_bounds__(NW * 64) void wino4_gemm_out_kernel(FusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ml = lds;                                   // [36][32 tiles][32 channels]
+  float* s_red = lds + 36 * kFusedTiles * kFusedCols; // [32 tiles][8 channel groups][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_lane = lane & 31, kh = lane >> 5;
+  const int group = p.tpb > kFusedTiles ? p.tpb : kFusedTiles;      // tiles of this workgroup: whole BatchNorm partial rows
+  const int halves = group / kFusedTiles;
+  const long long tw0 = (long long)blockIdx.x * group;
+  const int t_tile = tid >> 3, t_cg = tid & 7;       // transform phase: one tile x 4 channels per thread
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  constexpr int SPP = K / 64;                        // 64-k stages per position
+  const int nst = (36 - wave + NW - 1) / NW * SPP;   // stages of this wave in one GEMM phase (positions wave, wave + NW, ...)
+
+  for (int n0 = 0; n0 < p.N; n0 += kFusedCols) {
+    f32x4 s1 = zero, s2 = zero;
+    for (int half = 0; half < halves; ++half) {
+      const long long t0 = tw0 + (long long)half * kFusedTiles;
+      if (t0 >= p.T) break;
+      // ---- the 36 position products of this (tile block, channel block) ----
+      {
+        const long long TBk = ((p.T + 31) >> 5) * (K / 16);                      // 1 KB fragments per position of V3
+        const unsigned short* a_base = p.V3 + ((t0 >> 5) * (K / 16)) * 512 + lane * 8;
+        const unsigned short* b_base = p.U3 + (long long)(n0 >> 5) * (K / 16) * 512 + lane * 8;
+        bf16x8_t pa[2][12], rb[2][12];
+        auto issue = [&](int st, int buf) {
+          const int pos = wave + NW * (st / SPP), kb = (st % SPP) * 64;
+          const unsigned short* a = a_base + ((long long)pos * TBk + kb / 16) * 512;
+          const unsigned short* b = b_base + ((long long)pos * (p.rows_pad >> 5) * (K / 16) + kb / 16) * 512;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              pa[buf][ks * 3 + q] = *reinterpret_cast<const bf16x8_t*>(a + q * p.v_plane_elems + ks * 512);
+              rb[buf][ks * 3 + q] = *reinterpret_cast<const bf16x8_t*>(b + q * p.plane_elems + ks * 512);
+            }
+          }
+        };
+        f32x16_t acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        auto compute = [&](int st, int buf, bool store) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            // the six terms, smallest first (conv.hip)
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; t += 2) {        // two accumulators: a chain of dependent MFMAs waits out each one's latency
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[buf][ks * 3 + TA[t]], rb[buf][ks * 3 + TB[t]], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[buf][ks * 3 + TA[t + 1]], rb[buf][ks * 3 + TB[t + 1]], acc2, 0, 0, 0);
+            }
+          }
+          if (store) {
+            const int pos = wave + NW * (st / SPP);
+            float* dst = Ml + pos * (kFusedTiles * kFusedCols) + (4 * kh) * kFusedCols + r_lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              dst[((r & 3) + 8 * (r >> 2)) * kFusedCols] = acc[r] + acc2[r];
+              acc[r] = 0.f;
+              acc2[r] = 0.f;
+            }
+          }
+        };
+        // two stages per trip of a ROLLED loop (static register buffers; the fully unrolled 18 stages of K = 128 are ~70 KB of
+        // code, more than the instruction cache holds: 2.3x slower than K = 64 per stage)
+        issue(0, 0);
+#pragma unroll 1
+        for (int st = 0; st + 1 < nst; st += 2) {
+          issue(st + 1, 1);
+          compute(st, 0, SPP == 1);
+          // unconditional (the last trip re-fetches its own stage): behind a branch the compiler no longer knows how many loads
+          // are in flight behind the ones it waits for and drains the queue -- s_waitcnt vmcnt(0) in front of every stage
+          issue(st + 2 < nst ? st + 2 : nst - 1, 0);
+          compute(st + 1, 1, true);
+        }
+        if (nst & 1) compute(nst - 1, 0, true);
+      }
+      __syncthreads();
+      // ---- output transform of the block out of LDS (wino4_output4_kernel's arithmetic) ----
+      const long long tile = t0 + t_tile;
+      if (tid < 256 && tile < p.T) {
+        const int g4 = n0 + t_cg * 4;                  // first of this thread's 4 output channels
+        const f32x4 bv = p.bias ? ld4(p.bias + g4) : zero;
+        const unsigned utile = (unsigned)tile;
+        const int tx = (int)(utile % (unsigned)p.TW);
+        const unsigned ut2 = utile / (unsigned)p.TW;
+        const int ty = (int)(ut2 % (unsigned)p.TH);
+        const long long b = ut2 / (unsigned)p.TH;
+        const float* src = Ml + t_tile * kFusedCols + t_cg * 4;
+        constexpr int ps = kFusedTiles * kFusedCols;
+        f32x4 o[4][4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          f32x4 u[4];
+          at4(ld4(src + (r * 6 + 0) * ps), ld4(src + (r * 6 + 1) * ps), ld4(src + (r * 6 + 2) * ps),
+              ld4(src + (r * 6 + 3) * ps), ld4(src + (r * 6 + 4) * ps), ld4(src + (r * 6 + 5) * ps), u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (r == 0) { o[0][j] = u[j]; }
+            else if (r == 1) { o[0][j] += u[j]; o[1][j] = u[j]; o[2][j] = u[j]; o[3][j] = u[j]; }
+            else if (r == 2) { o[0][j] += u[j]; o[1][j] -= u[j]; o[2][j] += u[j]; o[3][j] -= u[j]; }
+            else if (r == 3) { o[0][j] += u[j]; o[1][j] += 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] += 8.f * u[j]; }
+            else if (r == 4) { o[0][j] += u[j]; o[1][j] -= 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] -= 8.f * u[j]; }
+            else { o[3][j] += u[j]; }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int oy = 4 * ty + i;
+          if (oy >= p.H) continue;
+          float* dst = p.y + ((b * p.H + oy) * (long long)p.W + 4 * tx) * p.y_ld + g4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (4 * tx + j >= p.W) continue;
+            f32x4 v = o[i][j] + bv;
+            if (p.slope != 1.f) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.slope;
+            }
+            st4(dst + j * p.y_ld, v);
+            s1 += o[i][j];
+            s2 += o[i][j] * o[i][j];
+          }
+        }
+      }
+      __syncthreads();                                 // M is overwritten by the next GEMM phase
+    }
+    if (p.partial != nullptr) {
+      // BatchNorm partial rows of tpb tiles each: tpb <= 32 -> 32 / tpb rows of this workgroup, tpb = 64 -> one (both halves)
+      if (tid < 256) {
+        float* mine = s_red + (t_tile * 8 + t_cg) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mine[k] = s1[k]; mine[4 + k] = s2[k]; }
+      }
+      __syncthreads();
+      const int gt = p.tpb < kFusedTiles ? p.tpb : kFusedTiles;      // tiles summed into one row
+      const int ngroups = kFusedTiles / gt;
+      if (tid < ngroups * 32) {
+        const int grp = tid >> 5, ch = tid & 31;
+        const long long prow = p.tpb < kFusedTiles ? (long long)blockIdx.x * ngroups + grp : (long long)blockIdx.x;
+        if (prow * p.tpb < p.T) {
+          float a = 0.f, q = 0.f;
+          for (int t = 0; t < gt; ++t) {
+            const float* e = s_red + ((grp * gt + t) * 8 + (ch >> 2)) * 8 + (ch & 3);
+            a += e[0];
+            q += e[4];
+          }
+          float* dst = p.partial + (prow * p.N + n0 + ch) * 2;
+          dst[0] = a;
+          dst[1] = q;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
 // rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
 // row -> for each of the 36 positions the workgroup writes RB runs of KB * 4 bytes (512 for KB = 128).  (Rounds 1-2: one
@@ -970,10 +1275,39 @@ inline int fwd_ksplit(long long T, int cin, int cout, int tile) {
   return tile == 4 && out4_on(cout) ? fsd_conv::batched_ksplit(T, cin, cout, npos(tile)) : 1;
 }
 
+// The fused position-GEMM + output-transform kernel (wino4_gemm_out_kernel) can take the F(4x4) layers with 64 / 128 input
+// channels under the split arithmetic.  EXPERIMENTAL, off by default (FSD_WINO_FUSED=1 or fsd_wino_fused_mode(1) turns it on):
+// measured slower than the three launches it replaces, see the kernel's comment.
+std::atomic<int> g_fused_mode{-1};      // -1: not yet read from the environment
+inline bool fused_on() {
+  int m = g_fused_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* env = getenv("FSD_WINO_FUSED");
+    m = env && env[0] == '1' ? 1 : 0;
+    g_fused_mode.store(m, std::memory_order_relaxed);
+  }
+  return m == 1;
+}
+inline bool fused_ok(int cin, int cout, int tile) {
+  return fused_on() && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout >= kFusedCols &&
+         cout % kFusedCols == 0;
+}
+
+extern "C" int fsd_wino_fused_mode(int mode) {
+  const int prev = fused_on() ? 1 : 0;
+  if (mode == 0 || mode == 1) g_fused_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
   const int ks = fwd_ksplit(T, cin, cout, tile);
-  return (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + ks * pos_stride(T, cout)) * sizeof(float);
+  const size_t plain = (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + ks * pos_stride(T, cout)) * sizeof(float);
+  if (fused_ok(cin, cout, tile)) {    // the three bf16 planes of V (whole 32-tile blocks) and of U; no fp32 V, no M
+    const size_t fused = (size_t)npos(tile) * 3 * 2 * ((size_t)((T + 31) / 32 * 32) + round_up(cout, 128)) * cin;
+    return fused > plain ? fused : plain;      // (a caller that brings its own V takes the three-launch pipeline)
+  }
+  return plain;
 }
 
 extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
@@ -1020,6 +1354,50 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   const long long T = tiles_of(batch, height, width, tile);
   if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
+  const int rows_pad = round_up(cout, 128);
+  if (fused_ok(cin, cout, tile) && !v_in) {
+    // input transform -> bf16 planes in fragment order (+ the fp32 V for the weight gradient if asked); weights -> planes;
+    // position GEMMs + output transform in one kernel
+    const long long TB = (T + 31) / 32;
+    const long long v_plane = (long long)P * TB * 32 * cin, u_plane = (long long)P * rows_pad * cin;   // bf16 elements
+    unsigned short* v3 = reinterpret_cast<unsigned short*>(workspace);
+    unsigned short* u3 = v3 + 3 * v_plane;
+    {
+      fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width) + (v_keep ? 10.0 : 6.0) * cin * (double)P * T,
+                           stream);
+      const unsigned blocks = (unsigned)((TB * (cin / 8) + 3) / 4);
+      uint2* pl = reinterpret_cast<uint2*>(v3);
+#define FSD_INP(ACT, KEEP)                                                                                                   \
+  FSD_LAUNCH((wino4_input_planes_kernel<ACT, KEEP>), dim3(blocks), dim3(256), 0, stream, x, x_ld, v_keep, pl, v_plane / 4,    \
+             height, width, TH, TW, cin, T, in_scale, in_shift, in_slope)
+      if (in_scale) { if (v_keep) FSD_INP(true, true); else FSD_INP(true, false); }
+      else { if (v_keep) FSD_INP(false, true); else FSD_INP(false, false); }
+#undef FSD_INP
+    }
+    const int tpb = tiles_per_block(T);
+    const int group = tpb > kFusedTiles ? tpb : kFusedTiles;
+    FusedArgs a;
+    a.V3 = v3; a.U3 = u3; a.bias = bias; a.y = y; a.partial = bn_partial;
+    a.y_ld = y_ld; a.v_plane_elems = v_plane; a.plane_elems = u_plane; a.T = T;
+    a.H = height; a.W = width; a.TH = TH; a.TW = TW; a.N = cout; a.rows_pad = rows_pad; a.tpb = tpb;
+    a.slope = slope;
+    // issued MFMA work as for the position GEMMs it replaces; the transform's share of the time rides in the same class
+    fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * (double)T * cout * cin * P, stream);
+    FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
+               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin);
+    const unsigned grid = (unsigned)((T + group - 1) / group);
+    static const char* nw_env = getenv("FSD_WINO_FUSED_WAVES");        // tuning aid: 4 or 8 waves
+    const bool w8 = nw_env && nw_env[0] == '8';
+    auto go = [&](auto kern, int threads) -> int {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kFusedLds);
+      if (e != hipSuccess) return (int)e;
+      FSD_LAUNCH(kern, dim3(grid), dim3(threads), kFusedLds, stream, a);
+      return (int)hipGetLastError();
+    };
+    if (cin == 64) return w8 ? go(wino4_gemm_out_kernel<64, 8>, 512) : go(wino4_gemm_out_kernel<64, 4>, 256);
+    return w8 ? go(wino4_gemm_out_kernel<128, 8>, 512) : go(wino4_gemm_out_kernel<128, 4>, 256);
+  }
   float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * pos_stride(T, cin);
   const long long n_in = T * (cin / 4);
@@ -1038,7 +1416,6 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
     V = Vw;
   }
-  const int rows_pad = round_up(cout, 128);
   const int ks = fwd_ksplit(T, cin, cout, tile);
   const long long ss = (long long)P * pos_stride(T, cout);          // slice s of every position lies behind slice s - 1 of all
   int rc = fsd_conv::conv_gemm_batched(V, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout, pos_stride(T, cout), T, cin, cout,

@@ -804,3 +804,9 @@ def f32_gemm_mode(mode=None):
     operands, fp32-accurate; include/fsdet.h fsd_f32_gemm_mode).  Returns the previous mode; None only queries."""
     prev = lib().fsd_f32_gemm_mode(-1 if mode is None else {"native": 0, "split": 1}[mode])
     return "split" if prev else "native"
+
+
+def wino_fused_mode(on=None):
+    """EXPERIMENTAL: the fused position-GEMM + output-transform kernel for F(4x4) layers with 64 / 128 input channels
+    (include/fsdet.h fsd_wino_fused_mode; off by default, measured slower).  Returns the previous setting; None only queries."""
+    return bool(lib().fsd_wino_fused_mode(-1 if on is None else int(bool(on))))

@@ -487,6 +487,13 @@ int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stre
  * first use reads the environment variable FSD_F32_SPLIT (0 / 1). */
 int fsd_f32_gemm_mode(int mode);
 
+/* EXPERIMENTAL (default off; first use reads FSD_WINO_FUSED): F(4x4) layers with 64 / 128 input channels under the split
+ * arithmetic run input transform -> bf16 operand planes -> ONE kernel for the 36 position GEMMs and the output transform (the
+ * 36 x tiles x Cout intermediate never leaves the CU).  Same results to fp32 round-off; measured slower than the three launches
+ * it replaces on MI355X (csrc/winograd.hip, wino4_gemm_out_kernel).  mode 0 / 1 sets, anything else queries; returns the
+ * previous mode.  fsd_wino_workspace_bytes follows the mode: query it after switching. */
+int fsd_wino_fused_mode(int mode);
+
 const char* fsd_version(void);
 
 #ifdef __cplusplus
