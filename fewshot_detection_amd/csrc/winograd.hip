@@ -912,7 +912,10 @@ __global__ __launch_bounds__(256) void wino4_input_planes_kernel(const float* __
 // kernel needs the operand reuse of an LDS-staged tile, and LDS is where M sits.
 // The way out (not built): the output transform is separable -- y += At[., r] x (M[r][.] A) -- so only the SIX positions of one
 // transform row have to be resident at a time (24 KB for 32 x 32, 98 KB for 64 x 64 tiles) if the 4 x 4 partial outputs stay
-// in registers across the six row groups; that leaves LDS for a normally staged 64 x 64 GEMM tile.
+// in registers across the six row groups (64 tiles x 64 channels x 16 outputs = 256 registers a thread: 32 x 64 is what fits);
+// that leaves LDS for a normally staged GEMM tile.  What it could buy: the position GEMMs of 64 -> 128 at 104x104 WITHOUT their
+// M stores take 0.23 ms on 128x128 tiles / 0.28 on 64x64 (0.37 / 0.40 with them), the output transform 0.23 -- so 0.60 ms
+// would become ~0.35; over the six launches of the step that have K <= 128 that is 0.6-1.1 ms.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
