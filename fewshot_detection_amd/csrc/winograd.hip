@@ -362,14 +362,15 @@ template <bool ACT>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
                                                          int H, int W, int TH, int TW, int C, long long T,
                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                         float in_slope) {
+                                                         float in_slope, long long t_base, long long t_count) {
+  // tiles [t_base, t_base + t_count) of the T tiles of the launch's tensor (a slab, see fsd_wino_conv3x3_fwd_ex)
   const int cg = C >> 1;
   // neighbouring tiles re-read 2 of their 6 patch rows/columns: keep runs of consecutive tiles on one XCD (own L2)
   const long long idx = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x;
-  if (idx >= T * cg) return;
+  if (idx >= t_count * cg) return;
   const unsigned uidx = (unsigned)idx;                 // < 2^32 (launcher check): 32-bit divisions, not 64-bit ones
   const int g = (int)(uidx % (unsigned)cg);
-  const unsigned utile = uidx / (unsigned)cg;
+  const unsigned utile = uidx / (unsigned)cg + (unsigned)t_base;
   const long long tile = utile;
   const int tx = (int)(utile % (unsigned)TW);
   const unsigned ut2 = utile / (unsigned)TW;
@@ -725,7 +726,9 @@ template <int GL, bool KS = false>
 __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                            float* __restrict__ y, long long y_ld, float* __restrict__ partial,
                                                            int H, int W, int TH, int TW, int C, long long T, int tpb, float slope,
-                                                           int ks, long long ss) {
+                                                           int ks, long long ss, long long m_ps, long long t_base) {
+  // Mb: the position matrices of tiles [t_base, T) (position stride m_ps), blockIdx.x counts blocks of tpb tiles from t_base;
+  // `partial` points at this launch's first row
   constexpr int NPL = 256 / GL;
   __shared__ float s_red[NPL][GL][8];
   const int gl = threadIdx.x % GL, pl = threadIdx.x / GL;
@@ -735,8 +738,8 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 bv = (g_ok && bias) ? ld4(bias + g * 4) : zero;
   f32x4 s1 = zero, s2 = zero;
-  const long long t0 = (long long)blockIdx.x * tpb;
-  const long long ps = pos_stride(T, C);
+  const long long t0 = t_base + (long long)blockIdx.x * tpb;
+  const long long ps = m_ps;
   if (g_ok) {
     for (int it = pl; it < tpb; it += NPL) {
       const long long tile = t0 + it;
@@ -746,7 +749,7 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
       const unsigned ut2 = utile / (unsigned)TW;
       const int ty = (int)(ut2 % (unsigned)TH);
       const long long b = ut2 / (unsigned)TH;
-      const float* src = Mb + tile * C + g * 4;
+      const float* src = Mb + (tile - t_base) * C + g * 4;
       auto ldm = [&](const float* q) -> f32x4 {
         f32x4 v = ld4(q);
         if constexpr (KS)
@@ -1302,6 +1305,25 @@ extern "C" int fsd_wino_fused_mode(int mode) {
   return prev;
 }
 
+// Tiles per slab of the forward / data-gradient pipeline (T = one pass).  OPT-IN: FSD_WINO_SLAB_MB = budget for a slab's V + M
+// in MB (default 0 = never slab); a multiple of 512 tiles (whole 256-row GEMM tiles and BatchNorm partial rows), slabs evened
+// out.  MEASURED SLOWER: 64 -> 128 at 104x104 0.66 ms in one pass, 0.79 / 1.04 / 1.56 ms with 160 / 96 / 48 MB slabs (8 / 13 / 25
+// of them); train step 25.5 -> 29.0 ms at 96 MB.  A slab's transforms are a few hundred workgroups -- too few to reach the
+// bandwidth the one-pass launches run at -- and that costs more than the memory-side cache gives back (copies inside 192 MB:
+// 6.8-7.0 TB/s against 4.7-5.3 beyond 384 MB, tools/probes/mall_probe.py).
+inline long long slab_tiles(long long T, int cin, int cout, int tile, bool has_vin) {
+  static const char* env = getenv("FSD_WINO_SLAB_MB");
+  const long long budget = (env ? atoll(env) : 0) * 1000000LL;
+  if (budget <= 0 || tile != 4 || !out4_on(cout) || has_vin || fwd_ksplit(T, cin, cout, tile) > 1) return T;
+  const long long per_tile = 36LL * (cin + cout) * 4;
+  if (T * per_tile <= budget * 3 / 2) return T;
+  long long S = budget / per_tile / 512 * 512;
+  if (S < 512) S = 512;
+  const long long n = (T + S - 1) / S;
+  S = ((T + n - 1) / n + 511) / 512 * 512;
+  return S < T ? S : T;
+}
+
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
   const int ks = fwd_ksplit(T, cin, cout, tile);
@@ -1405,6 +1427,36 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * pos_stride(T, cin);
   const long long n_in = T * (cin / 4);
   const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
+  const long long S = slab_tiles(T, cin, cout, tile, v_in != nullptr);
+  if (S < T) {
+    // Slabs (opt-in, measured slower -- slab_tiles): transform -> position GEMMs -> transform for S tiles at a time.  V (36 x T x
+    // Cin floats) and M (36 x T x Cout) of the 104x104 / 52x52 layers are 0.6-1.2 GB per launch, each written by one kernel and
+    // read by the next -- from HBM, because the 256 MB memory-side cache has long been overwritten by then.  A slab's V + M fit
+    // it, and the M buffer is the same for every slab.
+    const int tpb = tiles_per_block(T);
+    const long long m_ps = pos_stride(S, cout);
+    for (long long t0 = 0; t0 < T; t0 += S) {
+      const long long cnt = T - t0 < S ? T - t0 : S;
+      {
+        fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)cnt * tile * tile + (double)P * cnt), stream);
+        const unsigned blocks = (unsigned)((cnt * (cin / 2) + 255) / 256);
+        if (in_scale)
+          FSD_LAUNCH(wino4_input_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, x_ld, Vw, height, width, TH, TW, cin, T,
+                     in_scale, in_shift, in_slope, t0, cnt);
+        else
+          FSD_LAUNCH(wino4_input_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, x_ld, Vw, height, width, TH, TW, cin, T,
+                     (const float*)nullptr, (const float*)nullptr, 1.f, t0, cnt);
+      }
+      int rc = fsd_conv::conv_gemm_batched(Vw + t0 * cin, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout,
+                                           m_ps, cnt, cin, cout, P, stream, 1, 0);
+      if (rc != 0) return rc;
+      fsd_prof::Scope prof_out(fsd_prof::kWinoXform, 4.0 * cout * ((double)cnt * tile * tile + (double)P * cnt), stream);
+      FSD_LAUNCH(wino4_output4_kernel<32>, dim3((unsigned)((cnt + tpb - 1) / tpb), (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb,
+                 bias, y, y_ld, bn_partial ? bn_partial + (t0 / tpb) * cout * 2 : nullptr, height, width, TH, TW, cout, t0 + cnt,
+                 tpb, slope, 1, 0LL, m_ps, t0);
+    }
+    return (int)hipGetLastError();
+  }
   if (!V) {
     // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
@@ -1413,10 +1465,10 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                          height, width, TH, TW, cin, T);
     else if (in_scale)
       FSD_LAUNCH(wino4_input_kernel<true>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
-                         height, width, TH, TW, cin, T, in_scale, in_shift, in_slope);
+                         height, width, TH, TW, cin, T, in_scale, in_shift, in_slope, 0LL, T);
     else
       FSD_LAUNCH(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
-                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
+                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f, 0LL, T);
     V = Vw;
   }
   const int ks = fwd_ksplit(T, cin, cout, tile);
@@ -1434,10 +1486,10 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     const int cg = cout / 2;                                 // channel pairs
     if (out4_on(cout) && ks > 1)
       FSD_LAUNCH((wino4_output4_kernel<32, true>), dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, ks, ss);
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, ks, ss, pos_stride(T, cout), 0LL);
     else if (out4_on(cout))
       FSD_LAUNCH(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, 1, 0LL);
+                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, 1, 0LL, pos_stride(T, cout), 0LL);
     else if (cg <= 32)
       FSD_LAUNCH(wino4_output_kernel<32>, dim3(bx, (cg + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope);
@@ -1502,7 +1554,7 @@ extern "C" int fsd_wino_conv3x3_wgrad(const float* dy, long long dy_ld, const fl
                          height, width, TH, TW, cin, T);
     else
       FSD_LAUNCH(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
-                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f);
+                         height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f, 0LL, T);
     V = Vw;
   }
   const float* Wg = wt_in;                                   // already transformed (fsd_wino_grad_transforms)
