@@ -314,8 +314,32 @@ class Leg(object):
             self.stream_tuning = streams.autotune(step)
             streams_on = streams.ENABLED
             self.fence()
+        # untimed: let the caching allocator reach its steady state (tensors that cross streams are re-used only after the
+        # GPU has passed them, so the pool keeps growing for some steps; a hipMalloc inside the timed region drains the
+        # device: one 39 ms step among 25 ms ones).  Extra steps until three in a row allocated nothing, at most 12.
+        self.settle_steps = 0
+        if warmup > 0 and self.dev.type == "cuda":
+            if prof_steps:                    # one step in the form of the profiled ones (one stream, per-launch events)
+                ops.PROFILE = []
+                ops.kernel_profile(True)
+                streams.ENABLED = False
+                step()
+                ops.PROFILE = None
+                ops.kernel_profile(False)
+                streams.ENABLED = streams_on
+                ops.kernel_profile_collect()
+                self.settle_steps += 1
+            quiet, last = 0, torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            while quiet < 3 and self.settle_steps < 12:
+                step()
+                self.settle_steps += 1
+                now = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+                quiet = quiet + 1 if now == last else 0
+                last = now
+            self.fence()
         if self.opt is not None:
             self.opt.allreduce_wait_ms = [0.0] * len(self.opt.buckets)
+        allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) if self.dev.type == "cuda" else 0
         prof_steps = min(steps, prof_steps)
         lo = (steps - prof_steps) // 2
         hi = lo + prof_steps
@@ -351,6 +375,7 @@ class Leg(object):
         t_end = time.perf_counter()
         step_gpu_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)]
         gc.enable()
+        allocs = (torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0) if self.dev.type == "cuda" else 0
         if prof_steps and t_b is None:        # the profiled steps were the last ones
             t_b = t_end
         elapsed = t_end - t0
@@ -362,6 +387,7 @@ class Leg(object):
         assert np.isfinite(loss_val), "non-finite loss"
         return {"elapsed": elapsed, "steps": steps, "loss": loss_val, "prof": prof, "prof_steps": prof_steps,
                 "stream_tuning": self.stream_tuning, "streams_on": streams_on, "step_gpu_ms": step_gpu_ms,
+                "settle_steps": self.settle_steps, "device_allocs_in_timed_region": allocs,
                 "prof_index": [lo, hi] if prof_steps else None, "kp": ops.kernel_profile_collect(),
                 "ms_unprofiled": (((t_a - t0) + (t_end - t_b)) / (steps - prof_steps) * 1e3
                                   if t_a is not None and steps > prof_steps else None),
@@ -542,6 +568,13 @@ def compact_line(res, full_path=None):
         if tn.get("tries"):
             out["streams"]["autotune_tries"] = len(tn["tries"])
             out["streams"]["autotune_ms"] = [tn["tries"][-1]["streams_ms"], tn["tries"][-1]["one_stream_ms"]]
+    al = res.get("allocator") or {}
+    if al:
+        out["allocator"] = {"settle_steps_untimed": al.get("settle_steps_untimed"),
+                            "device_allocs_in_timed_region": al.get("device_allocs_in_timed_region")}
+    sg = res.get("step_gpu_ms")
+    if sg:
+        out["step_gpu_ms_median_max"] = [_r(sorted(sg)[len(sg) // 2]), _r(max(sg))]
     dp = res.get("dp") or {}
     if dp:
         out["dp"] = {"world_size": dp.get("world_size"), "backend": dp.get("backend"), "buckets": dp.get("gradient_buckets"),
@@ -913,6 +946,8 @@ def _main(args, real_stdout):
                                           "before the warm-up and after the timed region; the MFMA peaks in `roofline` are "
                                           "quoted at the nominal clock"),
             "step_gpu_ms": r.get("step_gpu_ms"),
+            "allocator": {"settle_steps_untimed": r.get("settle_steps"),
+                          "device_allocs_in_timed_region": r.get("device_allocs_in_timed_region")},
             "streams": {"enabled": bool(r.get("streams_on", streams_on)), "tuning": r.get("stream_tuning"),
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
                                 "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
