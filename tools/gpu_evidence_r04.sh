@@ -22,7 +22,7 @@ pmc() {  # name, counters, bench args...
 run stats_f32_serial --streams 0
 run stats_f32_streams --streams 1
 run stats_bf16_serial --streams 0 --dtype bf16
-pmc fetch_f32 FETCH_SIZE
+pmc fetch_f32 FETCH_SIZE   # (tools/pmc_traffic.py counts the steps of a pass itself: pass 0 as its step count)
 pmc write_f32 WRITE_SIZE
 pmc mfma_f32 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
 pmc wait_f32 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"

@@ -11,7 +11,7 @@ under-counted the traffic by 135 MB per launch).  Reported:
                                               write the second operand of the SAME layers' backward
 FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM); both counters are in KiB.
 
-Usage: python tools/pmc_traffic.py <fetch_prefix> <write_prefix> <steps_profiled> <conv_launches_per_step> <out.json> [episode]
+Usage: python tools/pmc_traffic.py <fetch_prefix> <write_prefix> <steps_profiled | 0 = count them> <conv_launches_per_step> <out.json> [episode]
 episode: "metric_string" (64 queries 416x416 + 20 supports 224x224, the headline) or "configs1" -- bench.py only quotes a
 traffic file on the episode it was measured on."""
 import csv
@@ -77,9 +77,20 @@ def totals(prefix, counter):
     return tot, n, names
 
 
+def steps_in(prefix, counter):
+    """Train steps a pass really ran (warm-up, bench.py's untimed settle steps and the timed ones): one region_finalize_kernel
+    launch per step."""
+    return sum(1 for r in csv.DictReader(open(prefix + "_counter_collection.csv"))
+               if r["Counter_Name"] == counter and "region_finalize_kernel" in r["Kernel_Name"])
+
+
 def main():
     fetch_prefix, write_prefix, steps, per_step, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     episode = sys.argv[6] if len(sys.argv) > 6 else "metric_string"
+    if steps <= 0:                       # 0: count them
+        steps = steps_in(fetch_prefix, "FETCH_SIZE")
+        if steps != steps_in(write_prefix, "WRITE_SIZE") or steps < 1:
+            raise SystemExit("the two passes ran different numbers of steps")
     f, nf, names = totals(fetch_prefix, "FETCH_SIZE")
     w, nw, _ = totals(write_prefix, "WRITE_SIZE")
     launches = steps * per_step
@@ -94,9 +105,10 @@ def main():
            "kernel_dispatches_fetch_pass": nf.get("conv_launch", 0), "kernel_dispatches_write_pass": nw.get("conv_launch", 0),
            "conv_launches": launches, "fetch_bytes_per_launch_x2": fb, "write_bytes_per_launch": wb,
            "hbm_bytes_per_launch": fb + wb, "hbm_bytes_per_launch_with_grad_transforms": fg + wg, "episode": episode}
-    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --streams 0 --steps %d --warmup 1`; "
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --streams 0 --steps 3 --warmup 1` "
+                   "(%d train steps per pass with the untimed settle steps, counted from the region_finalize_kernel launches); "
                    "FETCH_SIZE x2 per MI355X_MICROARCH.md; per conv launch as bracketed by bench.py; kernels classified by "
-                   "tools/pmc_traffic.py::classify" % (steps - 1))
+                   "tools/pmc_traffic.py::classify" % steps)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
