@@ -342,3 +342,29 @@ def test_inference_can_pick_the_smaller_winograd_form_when_the_weights_are_the_t
     assert ops.wino_tile_inference(256, 512, 3, 26, 26, 2) == 4        # 98 tiles per position
     assert ops.wino_tile_inference(128, 256, 3, 13, 13, 2) == 4        # 1.2 MB of transformed weights
     assert ops.wino_tile_inference(1024, 1024, 1, 13, 13, 2) == 0
+
+
+def test_winograd_workspace_follows_the_arithmetic_and_the_experimental_pipeline_switch():
+    """fsd_wino_workspace_bytes is host logic (no GPU): V + M of the three-launch pipeline; with the experimental fused pipeline
+    on (fsd_wino_fused_mode, split arithmetic, 64 / 128 input channels) at least the bf16 operand planes of V and U as well.
+    The switch reports the previous setting and only changes on 0 / 1."""
+    from fewshot_detection_amd import _lib
+    lib = _lib.lib()
+    split_before = lib.fsd_f32_gemm_mode(-1)
+    fused_before = lib.fsd_wino_fused_mode(-1)
+    try:
+        lib.fsd_f32_gemm_mode(1)
+        assert lib.fsd_wino_fused_mode(0) == fused_before and lib.fsd_wino_fused_mode(7) == 0 and lib.fsd_wino_fused_mode(-1) == 0
+        B, H, W, cin, cout = 64, 104, 104, 64, 128
+        T = B * 26 * 26
+        plain = 36 * T * (cin + cout) * 4
+        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
+        assert lib.fsd_wino_fused_mode(1) == 0 and lib.fsd_wino_fused_mode(-1) == 1
+        planes = 36 * 3 * 2 * (T + 128) * cin                              # T is a multiple of 32; U rows padded to 128
+        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == max(plain, planes)
+        assert lib.fsd_wino_workspace_bytes(B, 13, 13, 1024, 1024, 4) == 36 * B * 16 * 2048 * 4     # not a fused shape
+        lib.fsd_f32_gemm_mode(0)                                           # the fused kernels are split-arithmetic kernels
+        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
+    finally:
+        lib.fsd_wino_fused_mode(fused_before)
+        lib.fsd_f32_gemm_mode(split_before)
