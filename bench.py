@@ -330,7 +330,9 @@ class Leg(object):
                 ops.kernel_profile_collect()
                 self.settle_steps += 1
             quiet, last = 0, torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
-            while quiet < 3 and self.settle_steps < 12:
+            # (several ranks: a FIXED number of steps -- every step holds collectives, and the ranks' allocators need not
+            # go quiet after the same number of them)
+            while (quiet < 3 and self.settle_steps < 12) if self.dist is None else self.settle_steps < 5:
                 step()
                 self.settle_steps += 1
                 now = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
