@@ -927,11 +927,17 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // (Read straight from the row-major panel, a lane's 16 bytes are a row apart from its neighbour's: 64 cache lines per load
 // instruction, and the L1 handles a line a cycle -- the first version of the kernel below spent its time there.)
 __global__ __launch_bounds__(256) void wino4_split_planes_kernel(const float* __restrict__ u, uint2* __restrict__ planes,
-                                                                 long long n4, int rows_pad, int K) {
+                                                                 long long n4, int rows_pad, int K, int frag) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   uint2 h, m, l;
   fsd_conv::split3(ld4(u + i * 4), h, m, l);
+  if (!frag) {                                             // row-major planes (wino4_rowfused_kernel stages them through LDS)
+    planes[i] = h;
+    planes[i + n4] = m;
+    planes[i + 2 * n4] = l;
+    return;
+  }
   const int k4 = K >> 2;
   const int k = (int)(i % k4) * 4;
   const long long rowi = i / k4;                         // position * rows_pad + row
@@ -1115,6 +1121,213 @@ __global__ __launch_bounds__(NW * 64) void wino4_gemm_out_kernel(FusedArgs p) {
   }
 }
 
+// ---- row-fused variant (fsd_wino_fused_mode(2)): operands staged in LDS, M resident one transform ROW at a time -------------
+// The output transform is separable, Y = At (M A): with W_r = M[r][.] A (the six positions of transform row r -> four values)
+// a thread adds At[., r] x W_r into the 16 outputs of its (tile, 4 channels) items, which it keeps in registers across the six
+// row groups.  Only six positions of M are ever resident: [6][32 tiles][64 channels] fp32 = 48 KB, and the rest of LDS stages
+// operands like any GEMM kernel: per 32-wide k-chunk the fp32 V rows of TWO positions (32 tiles each, split into three bf16
+// planes on the way in, conv.hip) and the already split weight planes of the same two positions (64 channels each, copied).
+// Waves 0/1 multiply position c (channels 0-31 / 32-63), waves 2/3 position c + 1; after three such pairs the row is complete.
+// Plane rows are padded to 80 bytes (conv_gemm_kernel's layout: conflict-free ds_read_b128 fragment reads).
+// MEASURED (64 -> 128 at 104x104, B = 64): correct on the first run, 1.43 ms against 0.60 for GEMM + output transform.  One
+// workgroup per CU (95 KB of LDS) walks 36 dependent chunk iterations per 32-tile block, each a global load -> barrier -> LDS ->
+// barrier -> 12 MFMAs round trip of ~3 us.  A deeper pipeline would not rescue the shape: a 32-tile block re-streams all 36
+// weight planes of its 64 channels (885 KB of L2 -> LDS traffic per 0.3 MB of V), ~0.3 ms at best, and the block cannot grow --
+// the 16 partial outputs per item are 128 registers a thread at 32 x 64 already.  Kept as the record of the attempt.
+constexpr int kRfTiles = 32, kRfCols = 64;
+constexpr int kRfLd = 40;                                   // bf16 elements per plane row (32 + pad)
+constexpr int kRfRows = 2 * kRfTiles + 2 * kRfCols;         // staged rows of a chunk: A of two positions, B of two positions
+constexpr int kRfPlane = kRfRows * kRfLd;                   // bf16 elements of one plane
+constexpr size_t kRfLds = (size_t)6 * kRfTiles * kRfCols * 4 + (size_t)3 * kRfPlane * 2;
+
+struct RowFusedArgs {
+  const float* V;                 // [36][ps_v]: rows of K floats
+  const unsigned short* U3;       // three ROW-MAJOR planes of [36][rows_pad][K] bf16
+  const float* bias;
+  float* y;
+  float* partial;                 // [ceil(T / tpb)][N][2] or null
+  long long y_ld, ps_v, plane_elems, T;
+  int H, W, TH, TW, N, rows_pad, tpb;
+  float slope;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void wino4_rowfused_kernel(RowFusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* M6 = lds;                                                     // [6][32][64]
+  unsigned short* sp = reinterpret_cast<unsigned short*>(lds + 6 * kRfTiles * kRfCols);   // three planes of kRfRows rows
+  float* s_red = reinterpret_cast<float*>(sp);                         // BatchNorm sums re-use the staging space at the end
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pp = wave >> 1, chh = wave & 1;                            // position of the pair, channel half
+  const int n0 = blockIdx.y * kRfCols;
+  const int group = p.tpb > kRfTiles ? p.tpb : kRfTiles;
+  const int halves = group / kRfTiles;
+  const long long tw0 = (long long)blockIdx.x * group;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // staging roles: A = one float4 of V per position of the pair; B = one 16-byte piece per (position, plane)
+  const int g8 = tid >> 3, kq = tid & 7;
+  const int a_row = (g8 & ~15) | ((g8 >> 2) & 3) | ((g8 & 3) << 2);    // conv_gemm_kernel's row order (conflict-free 8-byte stores)
+  const int b_row = tid >> 2, b_piece = tid & 3;
+  f32x4 s1[2] = {zero, zero}, s2[2] = {zero, zero};                    // BatchNorm sums of this thread's two items
+
+  for (int half = 0; half < halves; ++half) {
+    const long long t0 = tw0 + (long long)half * kRfTiles;
+    if (t0 >= p.T) break;
+    long long arow = t0 + a_row;
+    arow = arow < p.T ? arow : p.T - 1;
+    const float* a_src = p.V + arow * K + kq * 4;
+    const unsigned short* b_src = p.U3 + (long long)(n0 + b_row) * K + b_piece * 8;
+    f32x4 o[2][4][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[it][i][j] = zero;
+
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll 1
+      for (int pair = 0; pair < 3; ++pair) {
+        const int pos0 = r * 6 + pair * 2;
+        f32x16_t acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll 1
+        for (int kc = 0; kc < K / 32; ++kc) {
+          // global -> registers
+          f32x4 ra[2];
+          uint4 rb[2][3];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            ra[j] = ld4(a_src + (long long)(pos0 + j) * p.ps_v + kc * 32);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              rb[j][q] = *reinterpret_cast<const uint4*>(b_src + q * p.plane_elems + (long long)(pos0 + j) * p.rows_pad * K + kc * 32);
+          }
+          __syncthreads();                       // the previous chunk's fragment reads are done
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            uint2 h, m, l;
+            fsd_conv::split3(ra[j], h, m, l);
+            unsigned short* d = sp + (j * kRfTiles + a_row) * kRfLd + kq * 4;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + kRfPlane) = m;
+            *reinterpret_cast<uint2*>(d + 2 * kRfPlane) = l;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              *reinterpret_cast<uint4*>(sp + q * kRfPlane + (2 * kRfTiles + j * kRfCols + b_row) * kRfLd + b_piece * 8) = rb[j][q];
+          }
+          __syncthreads();
+          const unsigned short* sa = sp + (pp * kRfTiles + (lane & 31)) * kRfLd + (lane >> 5) * 8;
+          const unsigned short* sb = sp + (2 * kRfTiles + pp * kRfCols + chh * 32 + (lane & 31)) * kRfLd + (lane >> 5) * 8;
+#pragma unroll
+          for (int k16 = 0; k16 < 2; ++k16) {
+            bf16x8_t af[3], bf[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              af[q] = *reinterpret_cast<const bf16x8_t*>(sa + q * kRfPlane + k16 * 16);
+              bf[q] = *reinterpret_cast<const bf16x8_t*>(sb + q * kRfPlane + k16 * 16);
+            }
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};     // the six terms, smallest first (conv.hip)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]], bf[TB[t]], acc, 0, 0, 0);
+          }
+        }
+        // this wave's 32 x 32 block of M[r][pair * 2 + pp]
+        float* dst = M6 + ((pair * 2 + pp) * kRfTiles + 4 * (lane >> 5)) * kRfCols + chh * 32 + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * kRfCols] = acc[q];
+      }
+      __syncthreads();                           // row r of M is complete
+      // At column r: the weights of W_r in the four output rows
+      const float c1 = r == 0 || r == 5 ? 0.f : ((r & 1) ? 1.f : -1.f) * (r >= 3 ? 2.f : 1.f);
+      const float c0 = r == 5 ? 0.f : 1.f;
+      const float c2 = r == 0 || r == 5 ? 0.f : (r >= 3 ? 4.f : 1.f);
+      const float c3 = r == 0 ? 0.f : r == 5 ? 1.f : ((r & 1) ? 1.f : -1.f) * (r >= 3 ? 8.f : 1.f);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it;
+        const float* src = M6 + (idx >> 4) * kRfCols + (idx & 15) * 4;
+        f32x4 u[4];
+        at4(ld4(src), ld4(src + kRfTiles * kRfCols), ld4(src + 2 * kRfTiles * kRfCols), ld4(src + 3 * kRfTiles * kRfCols),
+            ld4(src + 4 * kRfTiles * kRfCols), ld4(src + 5 * kRfTiles * kRfCols), u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[it][0][j] = fma_s(c0, u[j], o[it][0][j]);
+          o[it][1][j] = fma_s(c1, u[j], o[it][1][j]);
+          o[it][2][j] = fma_s(c2, u[j], o[it][2][j]);
+          o[it][3][j] = fma_s(c3, u[j], o[it][3][j]);
+        }
+      }
+      // (the next row's M stores come after at least one staging barrier, which every thread reaches after these reads)
+    }
+    // ---- outputs of this half ----
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + 256 * it;
+      const long long tile = t0 + (idx >> 4);
+      if (tile >= p.T) continue;
+      const int g4 = n0 + (idx & 15) * 4;
+      const f32x4 bv = p.bias ? ld4(p.bias + g4) : zero;
+      const unsigned utile = (unsigned)tile;
+      const int tx = (int)(utile % (unsigned)p.TW);
+      const unsigned ut2 = utile / (unsigned)p.TW;
+      const int ty = (int)(ut2 % (unsigned)p.TH);
+      const long long b = ut2 / (unsigned)p.TH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = 4 * ty + i;
+        if (oy >= p.H) continue;
+        float* dsty = p.y + ((b * p.H + oy) * (long long)p.W + 4 * tx) * p.y_ld + g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (4 * tx + j >= p.W) continue;
+          f32x4 v = o[it][i][j] + bv;
+          if (p.slope != 1.f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.slope;
+          }
+          st4(dsty + j * p.y_ld, v);
+          s1[it] += o[it][i][j];
+          s2[it] += o[it][i][j] * o[it][i][j];
+        }
+      }
+    }
+    if (p.partial != nullptr && (p.tpb <= kRfTiles || half == halves - 1 || t0 + kRfTiles >= p.T)) {
+      // BatchNorm partial rows of tpb tiles: tpb <= 32 -> 32 / tpb rows per half, tpb = 64 -> one row for both halves
+      __syncthreads();                           // staging space is free
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        float* mine = s_red + (size_t)(tid + 256 * it) * 8;              // [32 tiles][16 quads][8]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mine[k] = s1[it][k]; mine[4 + k] = s2[it][k]; }
+        s1[it] = zero;
+        s2[it] = zero;
+      }
+      __syncthreads();
+      const int gt = p.tpb < kRfTiles ? p.tpb : kRfTiles;
+      const int ngroups = kRfTiles / gt;
+      for (int e = tid; e < ngroups * kRfCols; e += 256) {
+        const int grp = e / kRfCols, ch = e - grp * kRfCols;
+        const long long prow = p.tpb < kRfTiles ? (t0 / p.tpb) + grp : (long long)blockIdx.x;
+        if (prow * p.tpb < p.T) {
+          float a = 0.f, q = 0.f;
+          for (int t = 0; t < gt; ++t) {
+            const float* e8 = s_red + (size_t)((grp * gt + t) * 16 + (ch >> 2)) * 8 + (ch & 3);
+            a += e8[0];
+            q += e8[4];
+          }
+          float* dstp = p.partial + (prow * p.N + n0 + ch) * 2;
+          dstp[0] = a;
+          dstp[1] = q;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
 // rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
 // row -> for each of the 36 positions the workgroup writes RB runs of KB * 4 bytes (512 for KB = 128).  (Rounds 1-2: one
@@ -1285,23 +1498,26 @@ inline int fwd_ksplit(long long T, int cin, int cout, int tile) {
 // channels under the split arithmetic.  EXPERIMENTAL, off by default (FSD_WINO_FUSED=1 or fsd_wino_fused_mode(1) turns it on):
 // measured slower than the three launches it replaces, see the kernel's comment.
 std::atomic<int> g_fused_mode{-1};      // -1: not yet read from the environment
-inline bool fused_on() {
+inline int fused_mode() {
   int m = g_fused_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* env = getenv("FSD_WINO_FUSED");
-    m = env && env[0] == '1' ? 1 : 0;
+    m = env && (env[0] == '1' || env[0] == '2') ? env[0] - '0' : 0;
     g_fused_mode.store(m, std::memory_order_relaxed);
   }
-  return m == 1;
+  return m;
 }
-inline bool fused_ok(int cin, int cout, int tile) {
-  return fused_on() && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout >= kFusedCols &&
+inline bool fused_ok(int cin, int cout, int tile) {             // mode 1: operands from L1, all of M in LDS
+  return fused_mode() == 1 && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout >= kFusedCols &&
          cout % kFusedCols == 0;
+}
+inline bool rowfused_ok(int cin, int cout, int tile) {          // mode 2: operands staged in LDS, M one transform row at a time
+  return fused_mode() == 2 && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout % kRfCols == 0;
 }
 
 extern "C" int fsd_wino_fused_mode(int mode) {
-  const int prev = fused_on() ? 1 : 0;
-  if (mode == 0 || mode == 1) g_fused_mode.store(mode, std::memory_order_relaxed);
+  const int prev = fused_mode();
+  if (mode >= 0 && mode <= 2) g_fused_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
 
@@ -1331,6 +1547,10 @@ extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int
   if (fused_ok(cin, cout, tile)) {    // the three bf16 planes of V (whole 32-tile blocks) and of U; no fp32 V, no M
     const size_t fused = (size_t)npos(tile) * 3 * 2 * ((size_t)((T + 31) / 32 * 32) + round_up(cout, 128)) * cin;
     return fused > plain ? fused : plain;      // (a caller that brings its own V takes the three-launch pipeline)
+  }
+  if (rowfused_ok(cin, cout, tile)) {   // fp32 V, then the three bf16 planes of U where M would be
+    const size_t rf = (size_t)npos(tile) * ((size_t)pos_stride(T, cin) * sizeof(float) + 3 * 2 * (size_t)round_up(cout, 128) * cin);
+    return rf > plain ? rf : plain;
   }
   return plain;
 }
@@ -1409,7 +1629,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     // issued MFMA work as for the position GEMMs it replaces; the transform's share of the time rides in the same class
     fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * (double)T * cout * cin * P, stream);
     FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
-               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin);
+               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin, 1);
     const unsigned grid = (unsigned)((T + group - 1) / group);
     static const char* nw_env = getenv("FSD_WINO_FUSED_WAVES");        // tuning aid: 4 or 8 waves
     const bool w8 = nw_env && nw_env[0] == '8';
@@ -1470,6 +1690,30 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
       FSD_LAUNCH(wino4_input_kernel<false>, dim3((unsigned)((2 * n_in + 255) / 256)), dim3(256), 0, stream, x, x_ld, Vw,
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f, 0LL, T);
     V = Vw;
+  }
+  if (rowfused_ok(cin, cout, tile)) {
+    // weights -> row-major bf16 planes (into the space M would take); position GEMMs + output transform in one kernel
+    const long long u_plane = (long long)P * rows_pad * cin;
+    unsigned short* u3 = reinterpret_cast<unsigned short*>(Mb);
+    const int tpb = tiles_per_block(T);
+    const int group = tpb > kRfTiles ? tpb : kRfTiles;
+    RowFusedArgs a;
+    a.V = V; a.U3 = u3; a.bias = bias; a.y = y; a.partial = bn_partial;
+    a.y_ld = y_ld; a.ps_v = pos_stride(T, cin); a.plane_elems = u_plane; a.T = T;
+    a.H = height; a.W = width; a.TH = TH; a.TW = TW; a.N = cout; a.rows_pad = rows_pad; a.tpb = tpb;
+    a.slope = slope;
+    fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * (double)T * cout * cin * P, stream);
+    FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
+               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin, 0);
+    const dim3 grid((unsigned)((T + group - 1) / group), (unsigned)(cout / kRfCols));
+    auto go = [&](auto kern) -> int {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kRfLds);
+      if (e != hipSuccess) return (int)e;
+      FSD_LAUNCH(kern, grid, dim3(256), kRfLds, stream, a);
+      return (int)hipGetLastError();
+    };
+    return cin == 64 ? go(wino4_rowfused_kernel<64>) : go(wino4_rowfused_kernel<128>);
   }
   const int ks = fwd_ksplit(T, cin, cout, tile);
   const long long ss = (long long)P * pos_stride(T, cout);          // slice s of every position lies behind slice s - 1 of all

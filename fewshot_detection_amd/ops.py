@@ -807,6 +807,7 @@ def f32_gemm_mode(mode=None):
 
 
 def wino_fused_mode(on=None):
-    """EXPERIMENTAL: the fused position-GEMM + output-transform kernel for F(4x4) layers with 64 / 128 input channels
-    (include/fsdet.h fsd_wino_fused_mode; off by default, measured slower).  Returns the previous setting; None only queries."""
-    return bool(lib().fsd_wino_fused_mode(-1 if on is None else int(bool(on))))
+    """EXPERIMENTAL: the fused position-GEMM + output-transform kernels for F(4x4) layers with 64 / 128 input channels
+    (include/fsdet.h fsd_wino_fused_mode): 0 off (default), 1 operands from L1 with all of M in LDS, 2 operands staged in LDS
+    with M resident one transform row at a time.  Returns the previous setting (int); None only queries."""
+    return int(lib().fsd_wino_fused_mode(-1 if on is None else int(on)))

@@ -218,21 +218,24 @@ def test_experimental_fused_winograd_pipeline_matches_the_three_launches(dev, sh
     res = {}
     before = ops.wino_fused_mode()
     try:
-        for fused in (False, True):
+        for fused in (0, 1, 2):
             ops.wino_fused_mode(fused)
-            assert ops.wino_fused_mode() is fused
+            assert ops.wino_fused_mode() == fused
+            if fused == 2 and cout % 64:
+                continue
             keep = []
             y, part = ops.conv3x3_wino(x, u, cout, bn_partial=True, keep_v=keep, tile=4)
             ya, _ = ops.conv3x3_wino(x, u, cout, bias=bias, tile=4, slope=0.1)
             res[fused] = (ops.nhwc_to_nchw(y), part.double().sum(0), keep[0].clone(), ops.nhwc_to_nchw(ya))
     finally:
         ops.wino_fused_mode(before)
-    for fused in (False, True):
+    for fused in sorted(res):
         y, p, _, ya = res[fused]
         assert _rel(y, ref) < 5e-5, (fused, _rel(y, ref))
         flat = y.double().permute(1, 0, 2, 3).reshape(cout, -1)
         assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-5, atol=1e-3)          # the sums are of the values written
         assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-5, atol=1e-3)
         assert _rel(ya, F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.1)) < 5e-5
-    assert torch.equal(res[True][2], res[False][2])                                # the kept V: the same transform, bit for bit
-    assert _rel(res[True][0], res[False][0].double()) < 2e-6                       # two summation orders of the same products
+    for fused in sorted(res)[1:]:
+        assert torch.equal(res[fused][2], res[0][2])                               # the kept V: the same transform, bit for bit
+        assert _rel(res[fused][0], res[0][0].double()) < 2e-6                      # two summation orders of the same products
