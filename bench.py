@@ -41,6 +41,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
+YARDSTICK_BF16_TFLOPS = 1407.0     # profiles/r04_power_probe.txt: hipBLASLt bf16 8192^3, random operands, on this board (1383 W cap)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured with a float4 copy)
 
 
@@ -411,10 +412,16 @@ def roofline_block(r, dtype, ms, gemm_mode="native"):
     peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
 
     def mfma(cls):
+        # `peak` is the dense peak of the ENGINE the class issues on: the bf16 MFMA for the bf16
+        # kernels; for the fp32 GEMMs the fp32 MFMA under `native`, and under `split` the bf16 MFMA divided by the six
+        # v_mfma_f32_32x32x16_bf16 terms one fp32 product costs (2500 / 6 = 416.7 TFLOP/s of fp32 GEMM work)
         k = kp[cls]
-        pk = PEAK_BF16_MFMA_TFLOPS if cls == "gemm_bf16" else PEAK_FP32_MFMA_TFLOPS
+        split = cls != "gemm_bf16" and dtype == "f32" and gemm_mode == "split"
+        pk = PEAK_BF16_MFMA_TFLOPS if cls == "gemm_bf16" else (PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS)
         tf = k["work"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-        return {"achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk,
+        extra = {"frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS, "yardstick_frac": tf / (YARDSTICK_BF16_TFLOPS / 6.0)} if split else \
+            ({"yardstick_frac": tf / YARDSTICK_BF16_TFLOPS} if cls == "gemm_bf16" else {})
+        return {"achieved": tf, "peak": pk, "unit": "TFLOP/s", "frac": tf / pk, **extra,
                 "kernel_ms_per_step": k["ms"] / per, "launches_per_step": k["launches"] / per,
                 "avg_kernel_ms": k["ms"] / max(1, k["launches"]), "issued_gflop_per_step": k["work"] / per / 1e9}
 
@@ -461,16 +468,16 @@ def roofline_block(r, dtype, ms, gemm_mode="native"):
     if dtype == "f32":
         roof["f32_gemm_arithmetic"] = {"mode": gemm_mode, "what": F32_GEMM_WHAT[gemm_mode]}
         if gemm_mode == "split":
-            # `peak` above stays the dense fp32 MFMA peak (the dtype of the path); the instruction actually issued is the
-            # bf16 MFMA, six per fp32 product
+            # `peak` above is the ceiling of the instruction that runs: the bf16 MFMA, six per fp32 product
             roof["f32_gemm_arithmetic"].update({
                 "issued_bf16_tflops": 6.0 * roof["achieved"], "bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS,
                 "frac_of_bf16_peak_issued": 6.0 * roof["achieved"] / PEAK_BF16_MFMA_TFLOPS,
-                "fp32_equivalent_peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
-                "frac_of_fp32_equivalent_peak": roof["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0),
-                "note": "roofline.peak / frac are quoted against the dense fp32 MFMA peak (157.3 TFLOP/s, the dtype of the path); "
-                        "the same achieved figure against the ceiling of the instruction that runs (2500 / 6 = 416.7 TFLOP/s "
-                        "fp32-equivalent) is frac_of_fp32_equivalent_peak"})
+                "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                "frac_of_fp32_mfma_peak": roof["achieved"] / PEAK_FP32_MFMA_TFLOPS,
+                "note": "roofline.peak / frac are quoted against the engine the kernel issues on: 2500 / 6 = 416.7 TFLOP/s of "
+                        "fp32 GEMM work on the dense bf16 MFMA; the same achieved figure against the unused fp32 MFMA "
+                        "instruction's 157.3 TFLOP/s is frac_of_fp32_mfma_peak; yardstick_frac is against what hipBLASLt "
+                        "bf16 sustains on this power-capped board (profiles/r04_power_probe.txt, 1407 / 6 TFLOP/s)"})
         roof["wgrad_kernel"] = dict(mfma("gemm_wgrad"), kernel="wgrad_kernel: fp32 MFMA weight-gradient reduction GEMMs "
                                                                 "(direct layers and the F(3x3,4x4) Winograd batches)")
         roof["hbm"] = dict(hbm("wino_transform"), bound="hbm",
@@ -517,9 +524,9 @@ def compact_line(res, full_path=None):
     c_roof = {k: roof.get(k) for k in keep if k in roof}
     c_roof["kernel"] = _kernel_short(roof.get("kernel", ""))
     ar = roof.get("f32_gemm_arithmetic") or {}
-    if "frac_of_fp32_equivalent_peak" in ar:
-        c_roof["frac_of_fp32_equivalent_peak"] = ar["frac_of_fp32_equivalent_peak"]
-        c_roof["fp32_equivalent_peak"] = ar["fp32_equivalent_peak"]
+    for k in ("frac_of_fp32_mfma_peak", "yardstick_frac"):
+        if k in roof:
+            c_roof[k] = roof[k]
     if roof.get("traffic_source"):
         c_roof["traffic_source"] = roof["traffic_source"].split(" ")[0]
     if "traffic_algorithmic" in roof:
@@ -579,7 +586,8 @@ def compact_line(res, full_path=None):
         out["step_gpu_ms_median_max"] = [_r(sorted(sg)[len(sg) // 2]), _r(max(sg))]
     dp = res.get("dp") or {}
     if dp:
-        out["dp"] = {"world_size": dp.get("world_size"), "backend": dp.get("backend"), "buckets": dp.get("gradient_buckets"),
+        out["dp"] = {"world_size": dp.get("world_size"), "backend": dp.get("backend"), "rccl_ranks": dp.get("rccl_ranks"),
+                     "backend_reported": dp.get("backend_reported"), "buckets": dp.get("gradient_buckets"),
                      "allreduce_dtype": dp.get("allreduce_dtype"),
                      "allreduce_wait_ms_per_step": sum(dp.get("allreduce_wait_ms_per_step") or [0.0])}
         ov = dp.get("overlap")
@@ -597,6 +605,11 @@ def compact_line(res, full_path=None):
                     return None
                 d = d[k]
             return d
+        for sc in ("strong", "weak"):
+            if sc + "_scaling" in a:
+                am[sc + "_ms"] = g(a, sc + "_scaling", "ms_per_step")
+                am[sc + "_episodes_per_s"] = g(a, sc + "_scaling", "episodes_per_s")
+                am[sc + "_img_per_s"] = g(a, sc + "_scaling", "img_per_s")
         am["sustained_ms"] = g(a, "sustained_run", "ms_per_step")
         am["forward_only_ms"] = g(a, "forward_only", "ms")
         for d in ("f32", "bf16"):
@@ -787,6 +800,36 @@ def other_configs(leg, args, dev, blocks, lblocks):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- this very
+    command line under `python -m torch.distributed.run` on 127.0.0.1 and a free port, one rank per GPU -- forward what the
+    ranks print to stderr and print rank 0's ONE JSON line as the last stdout line.  Returns the launcher's exit code.
+    (The reference starts its replicas inside one process, train_meta.py:137-141 nn.DataParallel; here one process per
+    GPU over RCCL.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            last = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if last is not None:
+        sys.stdout.write(last + "\n")
+        sys.stdout.flush()
+    return rc if rc else (0 if last is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -818,6 +861,8 @@ def main():
                          "accumulate (default; error <= the native instruction's, tests/test_gpu_split.py); native = "
                          "v_mfma_f32_32x32x2_f32.  The default line also times the native arithmetic (also_measured)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     try:                                   # the boxes are shared: ask the scheduler for the host cores the ~460 launches per
         os.nice(-10)                       # step need (a no-op without the privilege)
     except (OSError, AttributeError):
@@ -834,9 +879,7 @@ def _main(args, real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus:                 # under a launcher the launcher's world size is the truth
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
     # one rank per GPU.  (Functional check of the N>1 path on a single-GPU box: FSD_BENCH_BACKEND=gloo lets several ranks
@@ -900,6 +943,28 @@ def _main(args, real_stdout):
     clock["throttled"] = bool(clock["probe_mhz_after_timing"] < 0.6 * 2400.0)
     elapsed = r["elapsed"]
 
+    # several ranks: the OTHER scaling form on the same replicas (SURVEY 8e asks for both curves; one driver call per N
+    # then yields both points).  Every rank runs it -- the steps hold the gradient all-reduce.
+    other_scaling = None
+    if world > 1 and not args.no_extras and args.mode == "train" and (strong or args.batch % world == 0):
+        alt = "weak" if strong else "strong"
+        if alt == "strong":
+            gx, metax2, mask2, gt = synth_episode(1000, args.batch, args.classes, args.size, args.support)
+            lb2 = args.batch // world
+            x2, target2 = gx[rank * lb2:(rank + 1) * lb2], gt[rank * lb2:(rank + 1) * lb2]
+            gb2, eps2 = args.batch, 1
+        else:
+            x2, metax2, mask2, target2 = synth_episode(1000 + rank, args.batch, args.classes, args.size, args.support)
+            lb2, gb2, eps2 = args.batch, args.batch * world, world
+        x2, metax2, mask2 = x2.to(dev).contiguous(), metax2.to(dev), mask2.to(dev)
+        step2 = leg.stepper(x2, metax2, mask2, target2, batch=gb2)
+        r2 = leg.run(step2, 12, 5, 0, streams_on)
+        t2 = r2["elapsed"] / r2["steps"]
+        other_scaling = {"scaling": alt, "what": "the same replicas, %s form: %d queries per rank, global batch %d, 5 warm-up + 12 "
+                                                 "timed steps, max over ranks" % (alt, lb2, gb2),
+                         "ms_per_step": t2 * 1e3, "episodes_per_s": eps2 / t2, "img_per_s": gb2 / t2, "loss": r2["loss"]}
+        del x2, metax2, mask2, step2
+
     if rank == 0:
         if args.per_layer and r["prof_steps"]:
             prof, ps = r["prof"], r["prof_steps"]
@@ -959,6 +1024,8 @@ def _main(args, real_stdout):
         if leg.opt is not None:
             o = leg.opt
             res["dp"] = {"world_size": o.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
+                         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+                         "backend_reported": (dist.get_backend() if dist is not None else None),
                          "gradient_buckets": len(o.buckets), "allreduce_dtype": str(o.grad_dtype).replace("torch.", ""),
                          "bucket_mb": [4e-6 * (hi - lo) for lo, hi in o.buckets], "bucket_launch_order": list(o.launch_order_last),
                          "allreduce_wait_ms_per_step": [v / args.steps for v in o.allreduce_wait_ms],
@@ -1018,6 +1085,8 @@ def _main(args, real_stdout):
                 del leg2, step2
                 torch.cuda.empty_cache()
             res["also_measured"] = also
+        if other_scaling is not None:
+            res.setdefault("also_measured", {})[other_scaling["scaling"] + "_scaling"] = other_scaling
         if not args.no_cpu_baseline and world == 1:
             dtypes = [args.dtype] + (["bf16" if args.dtype == "f32" else "f32"] if (args.mode == "train" and not args.no_extras) else [])
             res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes)

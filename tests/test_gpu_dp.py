@@ -125,6 +125,24 @@ def test_bench_two_ranks_one_json_line():
     assert res["value"] > 0 and "roofline" in res and "cpu_baseline" not in res
 
 
+def test_plain_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the shape of command the driver ran for
+    N=1) starts its two ranks itself; the last stdout line is rank 0's compact record, with both scaling forms in it."""
+    env = dict(os.environ, FSD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--classes", "3", "--size", "160", "--support", "160"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.stdout.count('{"metric"') == 1
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["parallelism"] == "dp2"
+    assert res["dp"]["rccl_ranks"] == 2 and res["dp"]["backend_reported"] == "gloo"
+    am = res["also_measured"]
+    assert am["strong_ms"] > 0 and am["strong_episodes_per_s"] > 0      # the strong form: 4 queries split over the 2 ranks
+
+
 def _run_bench(extra, env_extra, nproc=2):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
     for attempt in range(2):
