@@ -111,8 +111,12 @@ PROTOTYPES = {
     "fsd_launch_count": (_ll, [_i]),
     "fsd_clock_probe": (_i, [_p, _i, _p, _p]),
     "fsd_f32_gemm_mode": (_i, [_i]),
-    "fsd_wino_fused_mode": (_i, [_i]),
     "fsd_version": (C.c_char_p, []),
+}
+
+# entry points of a library built with -DFSD_EXPERIMENTS (include/fsdet.h, #ifdef FSD_EXPERIMENTS): bound when present
+EXPERIMENTAL_PROTOTYPES = {
+    "fsd_wino_fused_mode": (_i, [_i]),
 }
 
 _lib = None
@@ -144,6 +148,11 @@ def lib():
                 raise FsdetLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in EXPERIMENTAL_PROTOTYPES.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = handle
     return _lib
 

@@ -805,7 +805,7 @@ int bn_act_pool_bwd_impl(const T* dz, long long dz_ld, const T* dz_full, long lo
     }
   }
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const char* env8 = getenv("FSD_ACT_STATS8");       // tuning aid: 0 = the generic 4-channel kernel
+    static const char* env8 = FSD_TUNE("FSD_ACT_STATS8");       // tuning aid: 0 = the generic 4-channel kernel
     if (!dt && pool == 0 && !dz_full && !(env8 && env8[0] == '0') && channels % 8 == 0 && dz_ld % 8 == 0 && y_ld % 8 == 0 &&
         (reinterpret_cast<uintptr_t>(dz) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
       const int cg8 = channels / 8;
@@ -873,7 +873,7 @@ int bn_bwd_apply_impl(T* dt, const T* y, long long y_ld, const float* coef, cons
   if (!dt || !y || !coef || !mean || !invstd || (channels & 3) || (y_ld & 3)) return FSD_ERR_ARG;
   fsd_prof::Scope prof(fsd_prof::kActBwd, (double)sizeof(T) * channels * 3.0 * pixels, stream);      // read dt, y; write dy
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const char* env = getenv("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
+    static const char* env = FSD_TUNE("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
     if (channels % 8 == 0 && y_ld % 8 == 0 && !(reinterpret_cast<uintptr_t>(dt) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
         !(env && env[0] == '0')) {
       const long long total8 = pixels * (channels / 8);

@@ -714,7 +714,7 @@ int launch_split8_grid(K k, const ConvArgs& a, size_t lds, bool persist, hipStre
     n_cu = v;
   }
   const long long total = (long long)a.m_tiles * a.n_tiles * a.batches;
-  static const char* prio_env = getenv("FSD_SPLIT8_PRIO");            // tuning aid: 1 = s_setprio 1 for waves 4-7
+  static const char* prio_env = FSD_TUNE("FSD_SPLIT8_PRIO");            // tuning aid: 1 = s_setprio 1 for waves 4-7
   ConvArgs b = a;
   if (prio_env && prio_env[0] == '1' && b.wide) b.wide |= 2;      // (bit 1 rides on the wide-epilogue flag: still truthy)
   long long grid = total < n_cu || !persist ? total : n_cu;
@@ -727,7 +727,8 @@ int launch_split8_grid(K k, const ConvArgs& a, size_t lds, bool persist, hipStre
 
 template <int BM, int ACT>
 int launch_split8_t(const ConvArgs& a, size_t lds, hipStream_t stream) {
-  static const char* dbg = getenv("FSD_SPLIT8_DBG");                 // timing experiments, wrong results
+#ifdef FSD_EXPERIMENTS
+  static const char* dbg = FSD_TUNE("FSD_SPLIT8_DBG");                 // timing experiments, wrong results
   if (dbg && BM == 256 && ACT == 0) {
     switch (dbg[0]) {
       case '1': return launch_split8_grid(conv_gemm_split8_kernel<256, 128, 4, 2, true, 0, false, 1>, a, lds, false, stream);
@@ -738,8 +739,9 @@ int launch_split8_t(const ConvArgs& a, size_t lds, hipStream_t stream) {
       default: break;
     }
   }
-  static const char* env = getenv("FSD_SPLIT8_PERSIST");
+  static const char* env = FSD_TUNE("FSD_SPLIT8_PERSIST");
   if (env && env[0] == '1') return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, true>, a, lds, true, stream);
+#endif
   return launch_split8_grid(conv_gemm_split8_kernel<BM, 128, 4, 2, true, ACT, false>, a, lds, false, stream);
 }
 
@@ -792,7 +794,7 @@ int launch(const ConvArgs& a, bool nchw, hipStream_t stream) {
 
 // float4 epilogue (conv_epilogue): FSD_CONV_WIDE=0 switches it off (tuning aid)
 inline bool wide_ok(const float* y, long long y_ld, int cout) {
-  static const char* env = getenv("FSD_CONV_WIDE");
+  static const char* env = FSD_TUNE("FSD_CONV_WIDE");
   return !(env && env[0] == '0') && cout % 4 == 0 && y_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 }
 
@@ -829,7 +831,7 @@ inline RowPlan plan_rows(long long pixels, int cout, int cfg) {
 // the matrix work of a tile is a third of the native kernel's, so the operand traffic per MFMA decides.
 // 'k' (round 4, split arithmetic only): 256x128 on 8 waves, two LDS stages (conv_gemm_split8_kernel).
 inline char batched_pick(long long rows, int cin, int cout) {
-  static const char* env = getenv("FSD_WINO_TILE");
+  static const char* env = FSD_TUNE("FSD_WINO_TILE");
   if (env) {
     if (env[0] == 'k' && !fsd_conv::f32_split_on()) return 'c';
     return env[0];
@@ -842,7 +844,7 @@ inline char batched_pick(long long rows, int cin, int cout) {
     // (1 x 4 waves).  Such a launch is bound by what a CU does per k-chunk -- the split of every staged value, the MFMAs, the
     // LDS round trip (see batched_ksplit) -- and half of a 64x64 tile's rows are padding: 32x128 stages 5120 values for four
     // useful 32x32 tiles where 64x64 stages 4096 for two.  FSD_WINO_TILE32=0 keeps 64x64.
-    static const char* b_env = getenv("FSD_WINO_TILE32");
+    static const char* b_env = FSD_TUNE("FSD_WINO_TILE32");
     if (!(b_env && b_env[0] == '0') && rows <= 32 && cout >= 128 && cout % 128 == 0) return 'b';
     return rows >= 96 && cout > 64 ? 'c' : 'a';
   }
@@ -857,7 +859,7 @@ inline char batched_pick(long long rows, int cin, int cout) {
 // with two steps in flight the difference is the one above.)  The row tiling (and with it the number of BatchNorm partial rows,
 // fsd_conv_row_tiles) does not depend on the activation arguments.
 inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw) {
-  static const char* env = getenv("FSD_CONV1_SPLIT8");
+  static const char* env = FSD_TUNE("FSD_CONV1_SPLIT8");
   if (env && env[0] == '0') return false;
   // ... and only when the 256x128 tiles cover at least half of the 256 CUs (two images at 26x26 are 10 such tiles: 64x64 there)
   return fsd_conv::f32_split_on() && ksize == 1 && !nchw && cin % kBK == 0 && cin >= 256 && cout % 128 == 0 &&
@@ -867,7 +869,7 @@ inline bool split8_1x1(long long pixels, int cin, int cout, int ksize, bool nchw
 // How many of the `batches` positions of a batched launch go to the 256-row tiles (the rest: 128-row tiles, second launch).
 // Cost model: rounds of 256 co-resident workgroups; a 128-row tile takes 0.55 of a 256-row one.  FSD_SPLIT8_TAIL=0: all 256.
 inline int split8_main_positions(long long rows, int cout, int batches) {
-  static const char* env = getenv("FSD_SPLIT8_TAIL");
+  static const char* env = FSD_TUNE("FSD_SPLIT8_TAIL");
   if ((env && env[0] == '0') || batches < 2) return batches;
   const long long nt = (cout + 127) / 128;
   const long long tp256 = (rows + 255) / 256 * nt, tp128 = (rows + 127) / 128 * nt;
@@ -933,7 +935,7 @@ int fsd_conv::conv_gemm_batched_plan(long long rows, int cin, int cout, int* bm_
 // 72 chunk-tiles per CU x ~1500 cycles = 54 us.  Operands that are constant between calls (inference weights) would have to
 // arrive already split for these launches to approach the 30 us their bytes cost.
 int fsd_conv::batched_ksplit(long long rows, int cin, int cout, int batches) {
-  static const char* env = getenv("FSD_KSPLIT");
+  static const char* env = FSD_TUNE("FSD_KSPLIT");
   if (!env || cin % kBK != 0) return 1;
   const int nk = cin / kBK;
   const char pick = batched_pick(rows, cin, cout);
@@ -977,7 +979,7 @@ int fsd_conv::conv_gemm_batched(const float* x, long long x_ld, long long x_bs, 
   a.slope = 1.f;
   a.x_bs = x_bs; a.w_bs = w_bs; a.y_bs = y_bs;
   a.wide = wide_ok(y, y_ld, cout) && y_bs % 4 == 0;
-  static const char* flat_env = getenv("FSD_CONV_FLAT_XCD");        // tuning aid: 0 / 1 force the order
+  static const char* flat_env = FSD_TUNE("FSD_CONV_FLAT_XCD");        // tuning aid: 0 / 1 force the order
   a.flat_xcd = flat_env ? (flat_env[0] == '1') : (fsd_conv::f32_split_on() ? 1 : 0);
   a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
   if (pick == 'k') {
@@ -1081,9 +1083,12 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
   const bool nchw = out_nchw != 0;
   if (!in_scale && fsd_conv::halo_ok(height, width, cin, cout, ksize, nchw) && (y_ld & 3) == 0 &&
-      (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+      (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+      (!bn_partial || fsd_conv_row_tiles(pixels, cout, cin, ksize) == (int)((pixels + 127) / 128)))
     // narrow 3x3 layers (32 / 64 channels): halo patch split once per workgroup (conv_halo.hip); one BatchNorm partial row
-    // per 128 pixels, the row count fsd_conv_row_tiles reports for these channel counts (128-row tiles)
+    // per 128 pixels -- the row count fsd_conv_row_tiles reports for these channel counts (128-row tiles), which is what the
+    // caller sized bn_partial by: if a forced tiling (FSD_CONV_TILE) makes the two disagree, the layer keeps the GEMM tiles,
+    // every row of whose count is written
     return fsd_conv::conv3x3_halo(x, x_ld, w_packed, a.Kpad, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, slope,
                                   stream);
   if (split8_1x1(pixels, cin, cout, ksize, nchw)) {

@@ -471,7 +471,7 @@ inline double fill_of(const TileH& t, long long pixels, int cout) {      // used
 
 inline int pick_tile_h(long long pixels, int cin, int cout, int ksize, bool nchw, bool has_partial, int bk) {
   const char* env = getenv("FSD_CONV_H_TILE");                    // read per launch: tests / tuning flip it in-process
-  static const char* n32_env = getenv("FSD_CONV_H_N32");          // tuning aid: 0 disables the 32-channel tile
+  static const char* n32_env = FSD_TUNE("FSD_CONV_H_N32");          // tuning aid: 0 disables the 32-channel tile
   if (!nchw && cout <= 32 && !has_partial && bk == 64 && !(n32_env && n32_env[0] == '0')) return 5;
   if (!nchw && narrow_tile(pixels, cout)) return 4;
   if (nchw || bk != 64 || cin % 64) return 0;
@@ -492,7 +492,7 @@ inline int bk_of(int cin, int ksize) {
   // k-chunk: 64 elements (128-byte rows) by default; 32 for Cin = 32 and for the short reductions of the 1x1 layers
   // (K <= 512: measured 104x104 128->64 0.072 -> 0.062 ms, 26x26 512->256 0.035 -> 0.029 ms, their data gradients
   // likewise; the 3x3 layers and the K = 1024 head lose 3-20 % with it).  FSD_CONV_H_BK=32|64 forces one (tuning aid).
-  static const char* bk_env = getenv("FSD_CONV_H_BK");
+  static const char* bk_env = FSD_TUNE("FSD_CONV_H_BK");
   int bk = (cin % 64 == 0 && !(ksize == 1 && cin <= 512)) ? 64 : 32;
   if (bk_env && cin % 64 == 0) bk = atoi(bk_env) == 32 ? 32 : 64;
   return bk;
@@ -539,7 +539,7 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;
   a.bn_partial = bn_partial; a.x_ld = x_ld; a.y_ld = y_ld;
   a.slope = slope;
-  static const char* wide_env = getenv("FSD_CONV_H_WIDE");        // tuning aid: 0 = 4-byte stores straight from registers
+  static const char* wide_env = FSD_TUNE("FSD_CONV_H_WIDE");        // tuning aid: 0 = 4-byte stores straight from registers
   a.wide = (!out_nchw_f32 && cout % 8 == 0 && y_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
             !(wide_env && wide_env[0] == '0')) ? 1 : 0;            // (switched off below for the 8-wave tiles)
   a.H = height; a.W = width; a.HW = height * width; a.M = (int)pixels;
@@ -553,10 +553,11 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   // 8-wave tiles: the 96-128 KB tile would cross LDS behind one barrier for all eight waves; measured -15 % on the 13x13
   // layers they are picked for (long K: the store tail is a small share there)
   if (tile >= 1 && tile <= 3 && !(wide_env && wide_env[0] == '1')) a.wide = 0;
-  const char* ilv_env = getenv("FSD_CONV_H_ILV");                 // tuning aid: 0 / 1 forces the DMA interleave off / on
+  const char* ilv_env = FSD_TUNE("FSD_CONV_H_ILV");                 // tuning aid: 0 / 1 forces the DMA interleave off / on
   const bool ilv = ilv_env ? ilv_env[0] == '1' : (tile >= 1 && tile <= 3) || tile == 6;
-  const char* ring_env = getenv("FSD_CONV_H_RING");               // tuning aid: 1 = counted-vmcnt ring (measured slower)
+  const char* ring_env = FSD_TUNE("FSD_CONV_H_RING");               // tuning aid: 1 = counted-vmcnt ring (measured slower)
   const bool ring = ring_env && ring_env[0] == '1';
+  (void)ilv; (void)ring;
   a.m_tiles = (int)((pixels + tile_bm(tile) - 1) / tile_bm(tile));
   switch (tile) {
     case 5:   // 32 output channels (data gradient of the 32 -> 64 layer at 208x208): a 64-wide tile would issue twice the MFMAs
@@ -567,22 +568,37 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
       return bk == 64 ? launch_conv<128, 64, 64, 4, 1>(a, false, stream) : launch_conv<128, 64, 32, 4, 1>(a, false, stream);
     case 1:
       a.n_tiles = cout / 256;
+#ifdef FSD_EXPERIMENTS
       if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<256, 256, 32, 2, 4, true, 4>(a, false, stream); }
-      return ilv ? launch_conv<256, 256, 64, 2, 4, true>(a, false, stream) : launch_conv<256, 256, 64, 2, 4>(a, false, stream);
+      if (!ilv) return launch_conv<256, 256, 64, 2, 4>(a, false, stream);
+#endif
+      return launch_conv<256, 256, 64, 2, 4, true>(a, false, stream);
     case 2:
       a.n_tiles = cout / 256;
+#ifdef FSD_EXPERIMENTS
       if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<192, 256, 32, 2, 4, true, 4>(a, false, stream); }
-      return ilv ? launch_conv<192, 256, 64, 2, 4, true>(a, false, stream) : launch_conv<192, 256, 64, 2, 4>(a, false, stream);
+      if (!ilv) return launch_conv<192, 256, 64, 2, 4>(a, false, stream);
+#endif
+      return launch_conv<192, 256, 64, 2, 4, true>(a, false, stream);
     case 3:
       a.n_tiles = cout / 128;
+#ifdef FSD_EXPERIMENTS
       if (ring) return launch_conv<256, 128, 64, 4, 2, true, 3>(a, false, stream);
-      return ilv ? launch_conv<256, 128, 64, 4, 2, true>(a, false, stream) : launch_conv<256, 128, 64, 4, 2>(a, false, stream);
+      if (!ilv) return launch_conv<256, 128, 64, 4, 2>(a, false, stream);
+#endif
+      return launch_conv<256, 128, 64, 4, 2, true>(a, false, stream);
     case 6:
       a.n_tiles = cout / 128;
-      return ilv ? launch_conv<192, 128, 64, 2, 2, true>(a, false, stream) : launch_conv<192, 128, 64, 2, 2>(a, false, stream);
+#ifdef FSD_EXPERIMENTS
+      if (!ilv) return launch_conv<192, 128, 64, 2, 2>(a, false, stream);
+#endif
+      return launch_conv<192, 128, 64, 2, 2, true>(a, false, stream);
     default:
       a.n_tiles = (cout + 127) / 128;
-      if (bk == 64) return ilv ? launch_conv<128, 128, 64, 2, 2, true>(a, nchw, stream) : launch_conv<128, 128, 64, 2, 2>(a, nchw, stream);
+#ifdef FSD_EXPERIMENTS
+      if (bk == 64 && ilv) return launch_conv<128, 128, 64, 2, 2, true>(a, nchw, stream);
+#endif
+      if (bk == 64) return launch_conv<128, 128, 64, 2, 2>(a, nchw, stream);
       return launch_conv<128, 128, 32, 2, 2>(a, nchw, stream);
   }
 }
@@ -1029,7 +1045,7 @@ inline int wgrad_h_resident(int bm, int bn, long long pixels) { return (bm == 25
 inline int wgrad_h_splits(long long pixels, int tiles, int resident) {
   const long long max_s = (pixels + 1023) / 1024;     // at least 32 chunks per split
   int s;
-  static const char* env = getenv("FSD_WGRAD_H_SPLITS");          // tuning aid: force the split count of the many-tile case
+  static const char* env = FSD_TUNE("FSD_WGRAD_H_SPLITS");          // tuning aid: force the split count of the many-tile case
   if (tiles >= 256 && env && atoi(env) > 0) {
     s = atoi(env);
   } else if (tiles >= 256) {
@@ -1050,7 +1066,7 @@ inline int wgrad_h_splits(long long pixels, int tiles, int resident) {
     // Sweep of round 2 (tools/layer_bench.py wgrad, bf16, FSD_WGRAD_H_TARGET = 512 / 1024 / 1536, repeatable to 1 %):
     //   104x104 64->128 0.229 / 0.277 / 0.303 ms    52x52 128->256 0.192 / 0.211 / 0.219 ms       (64-pixel chunks)
     //   26x26 256->512  0.210 / 0.233 / 0.193 ms    208x208 32->64 0.481 / 0.325 / 0.311 ms       (32-pixel chunks)
-    static const char* env_t = getenv("FSD_WGRAD_H_TARGET");      // tuning aid
+    static const char* env_t = FSD_TUNE("FSD_WGRAD_H_TARGET");      // tuning aid
     const int target = env_t && atoi(env_t) > 0 ? atoi(env_t) : resident;
     s = target / tiles;
   }
@@ -1081,7 +1097,7 @@ inline int wgrad_h_big_splits(long long pixels, int tiles) {
 // layers and short maps do not: 26x26 512->256 1x1 has 2 tiles and 21 splits' worth of pixels).  FSD_WGRAD_H_BIG=0
 // switches it off (tuning aid).
 inline bool wgrad_h_big(int cout, int ncols, long long pixels) {
-  const char* env = getenv("FSD_WGRAD_H_BIG");
+  const char* env = FSD_TUNE("FSD_WGRAD_H_BIG");
   if ((env && env[0] == '0') || cout < 256 || ncols < 256) return false;
   const int tiles = ((cout + 255) / 256) * ((ncols + 255) / 256);
   return (long long)tiles * wgrad_h_big_splits(pixels, tiles) >= 192;
@@ -1112,7 +1128,7 @@ int launch_wgrad_h(const WgradHArgs& a, int splits, hipStream_t stream) {
 // 128->256 0.251 -> 0.227 ms; 13x13 (11 k pixels, few chunks per split) loses 4-7 %, so it keeps 32.
 // FSD_WGRAD_H_KC=32|64 forces one (tuning aid).
 inline int wgrad_h_kc(long long pixels) {
-  static const char* env = getenv("FSD_WGRAD_H_KC");
+  static const char* env = FSD_TUNE("FSD_WGRAD_H_KC");
   if (env) return atoi(env) == 32 ? 32 : 64;
   return pixels >= 32768 ? 64 : 32;       // with the one-round split rule 26x26 (43 k pixels) gains too: 0.207 -> 0.189 ms
 }

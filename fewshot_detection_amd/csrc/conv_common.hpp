@@ -3,6 +3,7 @@
 #ifndef FSD_CONV_COMMON_HPP_
 #define FSD_CONV_COMMON_HPP_
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 namespace fsd_conv {
 

@@ -192,7 +192,7 @@ int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const f
   a.H = height; a.W = width; a.cin = cin; a.Cout = cout; a.pixels = pixels;
   const long long per = (pixels + (long long)blocks * 4 - 1) / ((long long)blocks * 4);
   a.ppw = (int)((per + 63) / 64 * 64);
-  static const char* wide_env = getenv("FSD_FIRST_WIDE");           // tuning aid: 0 = narrow stores
+  static const char* wide_env = FSD_TUNE("FSD_FIRST_WIDE");           // tuning aid: 0 = narrow stores
   a.wide = (!(wide_env && wide_env[0] == '0') && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ld * sizeof(TO)) % 16 == 0) ? 1 : 0;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + (double)sizeof(TO) * cout), stream);
   FSD_LAUNCH(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);

@@ -358,7 +358,7 @@ int bn_act_pool_impl(const T* y, long long y_ld, const float* scale, const float
   // algorithmic bytes: read y once, write z once
   fsd_prof::Scope prof(fsd_prof::kActFwd, (double)sizeof(T) * channels * ((double)batch * height * width + (double)batch * OH * OW), stream);
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const char* env = getenv("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
+    static const char* env = FSD_TUNE("FSD_EW_WIDE");                  // tuning aid: 0 = 4 channels per lane
     if (channels % 8 == 0 && y_ld % 8 == 0 && z_ld % 8 == 0 && !(reinterpret_cast<uintptr_t>(y) & 15) &&
         !(reinterpret_cast<uintptr_t>(z) & 15) && !(env && env[0] == '0')) {
       const int cg8 = channels / 8;

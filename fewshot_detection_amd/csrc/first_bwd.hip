@@ -303,7 +303,7 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   a.H = height; a.W = width; a.OH = height / 2; a.OW = width / 2; a.Cout = cout; a.cells = cells;
   // cells per load group: 1 (92 VGPRs, 5 waves per SIMD) measured fastest on the L0 shape -- 0.91 ms fp32 / 0.94 ms bf16
   // against 0.92 / 1.03 (2 cells, 108-168 VGPRs) and 0.96 / 1.07 (4 cells); FSD_FB_CPG = 1|2|4 is a tuning aid
-  static const char* env = getenv("FSD_FB_CPG");
+  static const char* env = FSD_TUNE("FSD_FB_CPG");
   const int cpg = env ? atoi(env) : 1;
   a.cpw = round_up((int)((cells + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 8);
   a.slope = slope;

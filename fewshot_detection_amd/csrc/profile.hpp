@@ -5,6 +5,17 @@
 #ifndef FSD_PROFILE_HPP_
 #define FSD_PROFILE_HPP_
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+// Switches.  The default library reads a documented handful of FSD_* environment variables ("Switches") with
+// getenv(); every other knob of the measurement history is a tuning aid that exists only in a build with -DFSD_EXPERIMENTS
+// (`make EXTRA=-DFSD_EXPERIMENTS`): in the default build FSD_TUNE(name) is a null constant and the branch behind it folds away.
+#ifdef FSD_EXPERIMENTS
+#define FSD_TUNE(name) getenv(name)
+#else
+#define FSD_TUNE(name) (static_cast<const char*>(nullptr))
+#endif
+
 
 namespace fsd_prof {
 

@@ -677,7 +677,7 @@ inline int pick_splits(long long pixels, int tiles, int tile = 64) {
   // Two rounds of the 1536 co-resident 64x64 workgroups (6 per CU), rounded DOWN so that the launch does not spill a few
   // workgroups into a third round.  Measured round 2 (tools/layer_bench.py wgrad; 2048 rounded up -> 3072 rounded down):
   // 208x208 32->64 1.487 -> 1.403 ms, 104x104 0.671 -> 0.663, 52x52 0.425 -> 0.423, 26x26 0.382 -> 0.375.
-  static const char* env = getenv("FSD_WGRAD_TARGET");          // tuning aid: target number of 64x64 workgroups
+  static const char* env = FSD_TUNE("FSD_WGRAD_TARGET");          // tuning aid: target number of 64x64 workgroups
   // (128x128 tiles, split arithmetic: half the workgroups -- two per CU are co-resident; measured 26x26 256->512
   // 0.254 -> 0.205 ms against a quarter, 13x13 1280->1024 0.628 -> 0.599)
   const int target = (env && atoi(env) > 0 ? atoi(env) : 3072) / (tile == 128 ? 2 : 1);
@@ -700,7 +700,7 @@ inline int tile_of(int bf16) { return (bf16 || f32_variant() == 1 || f32_variant
 // tile of the fp32 path for a dW of cout x ncols: split arithmetic takes the 128x128 tile where both dimensions fill it
 inline int f32_tile(int cout, int ncols) {
   if (!fsd_conv::f32_split_on()) return tile_of(0);
-  static const char* env = getenv("FSD_WGRAD_SPLIT_TILE");      // tuning aid: 64 or 128
+  static const char* env = FSD_TUNE("FSD_WGRAD_SPLIT_TILE");      // tuning aid: 64 or 128
   if (env) return atoi(env) == 128 ? 128 : 64;
   return (cout % 128 == 0 && ncols >= 128) ? 128 : 64;
 }
@@ -712,7 +712,7 @@ inline int f32_tile(int cout, int ncols) {
 // holds the split arithmetic to 1.25x the native kernel's error + 2e-7: missed by 1 %).  0.06 ms per step is not worth a
 // looser gate.
 inline int split8_1x1_splits(long long pixels, int cin, int cout, int ksize) {
-  static const char* env = getenv("FSD_WGRAD1_SPLIT8");
+  static const char* env = FSD_TUNE("FSD_WGRAD1_SPLIT8");
   if (!(env && env[0] == '1')) return 0;
   if (!fsd_conv::f32_split_on() || f32_variant() != 0 || ksize != 1 || cout % 256 || cin % 128 || cin < 256) return 0;
   const long long chunks = pixels / kBK;
@@ -861,7 +861,7 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
 // are multiples of 128 (+ one extra workspace slot filled by the 64x64 kernel for the last < 32 rows), else 64x64.
 struct BatchedPlan { bool dma; int splits; int tail_rows; int slots; bool s8; };
 inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) {
-  static const char* env = getenv("FSD_WGRAD_DMA");         // tuning aid: 0 disables the DMA variant
+  static const char* env = FSD_TUNE("FSD_WGRAD_DMA");         // tuning aid: 0 disables the DMA variant
   const bool allow = !(env && env[0] == '0') && f32_variant() == 0 && !fsd_conv::f32_split_on();
   BatchedPlan pl;
   pl.s8 = false;
@@ -874,7 +874,7 @@ inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) 
     pl.dma = false;
     const int tiles = (cout / 256) * (cin / 128) * batches;
     const long long max_s = full / (8 * kBK);
-    static const char* env_t = getenv("FSD_WGRAD_S8_TARGET");
+    static const char* env_t = FSD_TUNE("FSD_WGRAD_S8_TARGET");
     const int target = env_t && atoi(env_t) > 0 ? atoi(env_t) : 1024;
     int sp = (target + tiles - 1) / tiles;
     if (sp > max_s) sp = (int)max_s;
@@ -891,7 +891,7 @@ inline BatchedPlan batched_plan(long long rows, int cin, int cout, int batches) 
     // slice for the fold kernel to read.  (Choosing the split count so that the last round of blocks is full -- 2304
     // tiles x 2 splits = 9.0 rounds instead of 4.5 -- was measured and LOSES 5-10 %: 0.721 -> 0.762 ms at 1024 -> 1024.)
     const long long max_s = full / (8 * kBK);
-    static const char* env_d = getenv("FSD_WGRAD_DMA_TARGET");      // tuning aid: target number of 128x128 workgroups
+    static const char* env_d = FSD_TUNE("FSD_WGRAD_DMA_TARGET");      // tuning aid: target number of 128x128 workgroups
     const int target_d = env_d && atoi(env_d) > 0 ? atoi(env_d) : 1536;
     int sp = (target_d + tiles - 1) / tiles;
     if (sp > max_s) sp = (int)max_s;

@@ -808,525 +808,9 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
   }
 }
 
-// Input transform for the fused kernel below: V = B^T d B as three bf16 PLANES (conv.hip's split: x = x1 + x2 + x3) in the
-// MFMA's fragment order -- [plane][position][32-tile block][k / 16][lane][8], lane = (tile & 31) + 32 * ((k >> 3) & 1) -- so the
-// A operand of a v_mfma_f32_32x32x16_bf16 is 64 lanes x 16 contiguous bytes and nobody splits V again (the first version of the
-// fused kernel read the row-major fp32 V, a lane's 32 bytes a row apart from its neighbour's: 64 cache lines per load, and
-// split it once per 32-channel output block).  A wave = 32 tiles x 8 channels, lane = (tile, channel quad): its store of one
-// plane of one position is 512 contiguous bytes.  KEEP: the fp32 V the weight gradient reads is written as well.
-template <bool ACT, bool KEEP>
-__global__ __launch_bounds__(256) void wino4_input_planes_kernel(const float* __restrict__ x, long long x_ld, float* __restrict__ V,
-                                                                uint2* __restrict__ planes, long long plane_u2, int H, int W,
-                                                                int TH, int TW, int C, long long T,
-                                                                const float* __restrict__ in_scale,
-                                                                const float* __restrict__ in_shift, float in_slope) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c8n = C >> 3;
-  const long long wv = (long long)fsd_conv::xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
-  const long long tb = wv / c8n;
-  const int c8 = (int)(wv - tb * c8n);
-  const long long TB = (T + 31) >> 5;
-  if (tb >= TB) return;
-  const int r = lane >> 1, q = lane & 1;
-  const int c = c8 * 8 + q * 4;
-  const long long tile = tb * 32 + r;
-  const bool t_ok = tile < T;
-  const unsigned utile = (unsigned)(t_ok ? tile : 0);
-  const int tx = (int)(utile % (unsigned)TW);
-  const unsigned ut2 = utile / (unsigned)TW;
-  const int ty = (int)(ut2 % (unsigned)TH);
-  const long long b = ut2 / (unsigned)TH;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = zero;
-  if constexpr (ACT) { isc = ld4(in_scale + c); ish = ld4(in_shift + c); }
-  f32x4 d[6][6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int iy = 4 * ty - 1 + i;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int ix = 4 * tx - 1 + j;
-      const bool ok = t_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      f32x4 v = ok ? ld4(x + ((b * H + iy) * (long long)W + ix) * x_ld + c) : zero;
-      if constexpr (ACT) {
-        if (ok) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {                    // the expression of bn_act_pool_kernel (elementwise.hip)
-            const float t = __builtin_fmaf(v[k], isc[k], ish[k]);
-            v[k] = t > 0.f ? t : t * in_slope;
-          }
-        }
-      }
-      d[i][j] = v;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {            // columns: t = B^T d (in place)
-    f32x4 rr[6];
-    bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], rr);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i][j] = rr[i];
-  }
-  const int KS = C >> 4;
-  // uint2 (4 bf16) index of this lane's piece inside one position of one plane
-  const long long piece = ((tb * KS + (c8 >> 1)) * 64 + r + 32 * (c8 & 1)) * 2 + q;
-  const long long pos_u2 = TB * KS * 128;                  // uint2 per position
-  float* dstv = KEEP ? V + tile * C + c : nullptr;
-  const long long ps = pos_stride(T, C);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {            // rows: V = t B
-    f32x4 rr[6];
-    bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], rr);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if constexpr (KEEP) {
-        if (t_ok) st4(dstv + (i * 6 + j) * ps, rr[j]);
-      }
-      uint2 h, m, l;
-      fsd_conv::split3(rr[j], h, m, l);
-      uint2* dp = planes + (i * 6 + j) * pos_u2 + piece;
-      dp[0] = h;
-      dp[plane_u2] = m;
-      dp[2 * plane_u2] = l;
-    }
-  }
-}
-
-// ---- fused position GEMMs + output transform for SHORT reductions (round 4; EXPERIMENTAL, off: fsd_wino_fused_mode) ---------
-// The F(4x4) layers with 64 or 128 input channels (104x104 64 <-> 128, 52x52 128 -> 256 and the reweighting net's twins) are
-// bound by their intermediates, not by arithmetic: M = 36 x tiles x Cout floats is written by the position GEMMs and read back
-// by the output transform -- 797 MB each way on 64 -> 128 at 104x104, where the layer's own input + output are 531 MB -- and
-// the GEMM launch (two k-chunks a tile: all prologue and epilogue) runs AT the HBM rate, 4.2-4.4 TB/s, with the matrix cores
-// 0.29 busy.  Here M never leaves the CU: a workgroup owns 32 tiles x 32 output channels, its four waves compute the 36
-// position products M[p] = V[p] U[p]^T (32 x 32 x K each, nine positions a wave) into LDS -- 36 x 32 x 32 floats = 144 KB --
-// and the same workgroup then runs the output transform A^T M A (+ bias, leaky, BatchNorm partial sums) out of LDS, exactly the
-// arithmetic of wino4_output4_kernel.  With LDS full of M the operands cannot be staged there: both arrive as bf16 planes in
-// the MFMA's fragment order (wino4_input_planes_kernel, wino4_split_planes_kernel: every load is 64 lanes x 16 contiguous
-// bytes, nothing is split in this kernel) and go from global memory straight into the MFMA.
-// MEASURED (64 -> 128 at 104x104, B = 64; the three launches: transform 0.12 + GEMM 0.35 + transform 0.23 = 0.70 ms):
-//   row-major fp32 V split in registers, row-major U planes      0.75 ms in the kernel (+ 0.10 input transform)
-//   + U in fragment order, rolled stage loop (18 unrolled stages of K = 128 overflow the instruction cache)   0.52
-//   + V as planes in fragment order from the input transform     0.55 (+ 0.19: the transform now writes 2.5x)
-//   8 waves instead of 4, prefetch without a branch, two accumulators: 0.52-0.60, i.e. no change.
-// PMC on that launch says why nothing moved it: MFMA-busy 0.14, the texture addresser busy 65 % of the time, the L1 stalled on
-// pending misses 65 % of the time, 19 bytes / clock / CU delivered of the L1's 64.  A 32 x 32 wave tile fed from L1 needs 1 KB
-// of operands per MFMA -- 128 bytes / clock / CU at full matrix rate, twice what the L1 can deliver even when it hits, and
-// here half of the lines come from L2 (every workgroup streams the same U planes, V once per 32-channel block).  An MFMA
-// kernel needs the operand reuse of an LDS-staged tile, and LDS is where M sits.
-// The way out (not built): the output transform is separable -- y += At[., r] x (M[r][.] A) -- so only the SIX positions of one
-// transform row have to be resident at a time (24 KB for 32 x 32, 98 KB for 64 x 64 tiles) if the 4 x 4 partial outputs stay
-// in registers across the six row groups (64 tiles x 64 channels x 16 outputs = 256 registers a thread: 32 x 64 is what fits);
-// that leaves LDS for a normally staged GEMM tile.  What it could buy: the position GEMMs of 64 -> 128 at 104x104 WITHOUT their
-// M stores take 0.23 ms on 128x128 tiles / 0.28 on 64x64 (0.37 / 0.40 with them), the output transform 0.23 -- so 0.60 ms
-// would become ~0.35; over the six launches of the step that have K <= 128 that is 0.6-1.1 ms.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-// U [36][rows_pad][K] fp32 -> three bf16 planes in FRAGMENT ORDER: [plane][position][32-row block][k / 16][lane][8], lane =
-// (row & 31) + 32 * ((k >> 3) & 1) -- the B operand of one v_mfma_f32_32x32x16_bf16 is then 64 lanes x 16 contiguous bytes.
-// (Read straight from the row-major panel, a lane's 16 bytes are a row apart from its neighbour's: 64 cache lines per load
-// instruction, and the L1 handles a line a cycle -- the first version of the kernel below spent its time there.)
-__global__ __launch_bounds__(256) void wino4_split_planes_kernel(const float* __restrict__ u, uint2* __restrict__ planes,
-                                                                 long long n4, int rows_pad, int K, int frag) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  uint2 h, m, l;
-  fsd_conv::split3(ld4(u + i * 4), h, m, l);
-  if (!frag) {                                             // row-major planes (wino4_rowfused_kernel stages them through LDS)
-    planes[i] = h;
-    planes[i + n4] = m;
-    planes[i + 2 * n4] = l;
-    return;
-  }
-  const int k4 = K >> 2;
-  const int k = (int)(i % k4) * 4;
-  const long long rowi = i / k4;                         // position * rows_pad + row
-  const int n = (int)(rowi % rows_pad);
-  const long long pos = rowi / rows_pad;
-  const long long d = ((((pos * (rows_pad >> 5) + (n >> 5)) * (K >> 4) + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)) >> 2;
-  planes[d] = h;
-  planes[d + n4] = m;
-  planes[d + 2 * n4] = l;
-}
-
-struct FusedArgs {
-  const unsigned short* V3;       // three planes of the transformed input, fragment order (wino4_input_planes_kernel)
-  const unsigned short* U3;       // three planes of the transformed weights, fragment order (wino4_split_planes_kernel)
-  const float* bias;
-  float* y;
-  float* partial;                 // [ceil(T / tpb)][N][2] or null
-  long long y_ld, v_plane_elems, plane_elems, T;
-  int H, W, TH, TW, N, rows_pad, tpb;
-  float slope;
-};
-
-constexpr int kFusedTiles = 32, kFusedCols = 32;
-constexpr size_t kFusedLds = (size_t)36 * kFusedTiles * kFusedCols * 4 + (size_t)kFusedTiles * 8 * 8 * 4;
-
-template <int K, int NW>
-__global__ __launch_bounds__(NW * 64) void wino4_gemm_out_kernel(FusedArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Ml = lds;                                   // [36][32 tiles][32 channels]
-  float* s_red = lds + 36 * kFusedTiles * kFusedCols; // [32 tiles][8 channel groups][8]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r_lane = lane & 31, kh = lane >> 5;
-  const int group = p.tpb > kFusedTiles ? p.tpb : kFusedTiles;      // tiles of this workgroup: whole BatchNorm partial rows
-  const int halves = group / kFusedTiles;
-  const long long tw0 = (long long)blockIdx.x * group;
-  const int t_tile = tid >> 3, t_cg = tid & 7;       // transform phase: one tile x 4 channels per thread
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  constexpr int SPP = K / 64;                        // 64-k stages per position
-  const int nst = (36 - wave + NW - 1) / NW * SPP;   // stages of this wave in one GEMM phase (positions wave, wave + NW, ...)
-
-  for (int n0 = 0; n0 < p.N; n0 += kFusedCols) {
-    f32x4 s1 = zero, s2 = zero;
-    for (int half = 0; half < halves; ++half) {
-      const long long t0 = tw0 + (long long)half * kFusedTiles;
-      if (t0 >= p.T) break;
-      // ---- the 36 position products of this (tile block, channel block) ----
-      {
-        const long long TBk = ((p.T + 31) >> 5) * (K / 16);                      // 1 KB fragments per position of V3
-        const unsigned short* a_base = p.V3 + ((t0 >> 5) * (K / 16)) * 512 + lane * 8;
-        const unsigned short* b_base = p.U3 + (long long)(n0 >> 5) * (K / 16) * 512 + lane * 8;
-        bf16x8_t pa[2][12], rb[2][12];
-        auto issue = [&](int st, int buf) {
-          const int pos = wave + NW * (st / SPP), kb = (st % SPP) * 64;
-          const unsigned short* a = a_base + ((long long)pos * TBk + kb / 16) * 512;
-          const unsigned short* b = b_base + ((long long)pos * (p.rows_pad >> 5) * (K / 16) + kb / 16) * 512;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              pa[buf][ks * 3 + q] = *reinterpret_cast<const bf16x8_t*>(a + q * p.v_plane_elems + ks * 512);
-              rb[buf][ks * 3 + q] = *reinterpret_cast<const bf16x8_t*>(b + q * p.plane_elems + ks * 512);
-            }
-          }
-        };
-        f32x16_t acc, acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-        auto compute = [&](int st, int buf, bool store) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            // the six terms, smallest first (conv.hip)
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-            for (int t = 0; t < 6; t += 2) {        // two accumulators: a chain of dependent MFMAs waits out each one's latency
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[buf][ks * 3 + TA[t]], rb[buf][ks * 3 + TB[t]], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[buf][ks * 3 + TA[t + 1]], rb[buf][ks * 3 + TB[t + 1]], acc2, 0, 0, 0);
-            }
-          }
-          if (store) {
-            const int pos = wave + NW * (st / SPP);
-            float* dst = Ml + pos * (kFusedTiles * kFusedCols) + (4 * kh) * kFusedCols + r_lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              dst[((r & 3) + 8 * (r >> 2)) * kFusedCols] = acc[r] + acc2[r];
-              acc[r] = 0.f;
-              acc2[r] = 0.f;
-            }
-          }
-        };
-        // two stages per trip of a ROLLED loop (static register buffers; the fully unrolled 18 stages of K = 128 are ~70 KB of
-        // code, more than the instruction cache holds: 2.3x slower than K = 64 per stage)
-        issue(0, 0);
-#pragma unroll 1
-        for (int st = 0; st + 1 < nst; st += 2) {
-          issue(st + 1, 1);
-          compute(st, 0, SPP == 1);
-          // unconditional (the last trip re-fetches its own stage): behind a branch the compiler no longer knows how many loads
-          // are in flight behind the ones it waits for and drains the queue -- s_waitcnt vmcnt(0) in front of every stage
-          issue(st + 2 < nst ? st + 2 : nst - 1, 0);
-          compute(st + 1, 1, true);
-        }
-        if (nst & 1) compute(nst - 1, 0, true);
-      }
-      __syncthreads();
-      // ---- output transform of the block out of LDS (wino4_output4_kernel's arithmetic) ----
-      const long long tile = t0 + t_tile;
-      if (tid < 256 && tile < p.T) {
-        const int g4 = n0 + t_cg * 4;                  // first of this thread's 4 output channels
-        const f32x4 bv = p.bias ? ld4(p.bias + g4) : zero;
-        const unsigned utile = (unsigned)tile;
-        const int tx = (int)(utile % (unsigned)p.TW);
-        const unsigned ut2 = utile / (unsigned)p.TW;
-        const int ty = (int)(ut2 % (unsigned)p.TH);
-        const long long b = ut2 / (unsigned)p.TH;
-        const float* src = Ml + t_tile * kFusedCols + t_cg * 4;
-        constexpr int ps = kFusedTiles * kFusedCols;
-        f32x4 o[4][4];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          f32x4 u[4];
-          at4(ld4(src + (r * 6 + 0) * ps), ld4(src + (r * 6 + 1) * ps), ld4(src + (r * 6 + 2) * ps),
-              ld4(src + (r * 6 + 3) * ps), ld4(src + (r * 6 + 4) * ps), ld4(src + (r * 6 + 5) * ps), u);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (r == 0) { o[0][j] = u[j]; }
-            else if (r == 1) { o[0][j] += u[j]; o[1][j] = u[j]; o[2][j] = u[j]; o[3][j] = u[j]; }
-            else if (r == 2) { o[0][j] += u[j]; o[1][j] -= u[j]; o[2][j] += u[j]; o[3][j] -= u[j]; }
-            else if (r == 3) { o[0][j] += u[j]; o[1][j] += 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] += 8.f * u[j]; }
-            else if (r == 4) { o[0][j] += u[j]; o[1][j] -= 2.f * u[j]; o[2][j] += 4.f * u[j]; o[3][j] -= 8.f * u[j]; }
-            else { o[3][j] += u[j]; }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int oy = 4 * ty + i;
-          if (oy >= p.H) continue;
-          float* dst = p.y + ((b * p.H + oy) * (long long)p.W + 4 * tx) * p.y_ld + g4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (4 * tx + j >= p.W) continue;
-            f32x4 v = o[i][j] + bv;
-            if (p.slope != 1.f) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.slope;
-            }
-            st4(dst + j * p.y_ld, v);
-            s1 += o[i][j];
-            s2 += o[i][j] * o[i][j];
-          }
-        }
-      }
-      __syncthreads();                                 // M is overwritten by the next GEMM phase
-    }
-    if (p.partial != nullptr) {
-      // BatchNorm partial rows of tpb tiles each: tpb <= 32 -> 32 / tpb rows of this workgroup, tpb = 64 -> one (both halves)
-      if (tid < 256) {
-        float* mine = s_red + (t_tile * 8 + t_cg) * 8;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { mine[k] = s1[k]; mine[4 + k] = s2[k]; }
-      }
-      __syncthreads();
-      const int gt = p.tpb < kFusedTiles ? p.tpb : kFusedTiles;      // tiles summed into one row
-      const int ngroups = kFusedTiles / gt;
-      if (tid < ngroups * 32) {
-        const int grp = tid >> 5, ch = tid & 31;
-        const long long prow = p.tpb < kFusedTiles ? (long long)blockIdx.x * ngroups + grp : (long long)blockIdx.x;
-        if (prow * p.tpb < p.T) {
-          float a = 0.f, q = 0.f;
-          for (int t = 0; t < gt; ++t) {
-            const float* e = s_red + ((grp * gt + t) * 8 + (ch >> 2)) * 8 + (ch & 3);
-            a += e[0];
-            q += e[4];
-          }
-          float* dst = p.partial + (prow * p.N + n0 + ch) * 2;
-          dst[0] = a;
-          dst[1] = q;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ---- row-fused variant (fsd_wino_fused_mode(2)): operands staged in LDS, M resident one transform ROW at a time -------------
-// The output transform is separable, Y = At (M A): with W_r = M[r][.] A (the six positions of transform row r -> four values)
-// a thread adds At[., r] x W_r into the 16 outputs of its (tile, 4 channels) items, which it keeps in registers across the six
-// row groups.  Only six positions of M are ever resident: [6][32 tiles][64 channels] fp32 = 48 KB, and the rest of LDS stages
-// operands like any GEMM kernel: per 32-wide k-chunk the fp32 V rows of TWO positions (32 tiles each, split into three bf16
-// planes on the way in, conv.hip) and the already split weight planes of the same two positions (64 channels each, copied).
-// Waves 0/1 multiply position c (channels 0-31 / 32-63), waves 2/3 position c + 1; after three such pairs the row is complete.
-// Plane rows are padded to 80 bytes (conv_gemm_kernel's layout: conflict-free ds_read_b128 fragment reads).
-// MEASURED (64 -> 128 at 104x104, B = 64): correct on the first run, 1.43 ms against 0.60 for GEMM + output transform.  One
-// workgroup per CU (95 KB of LDS) walks 36 dependent chunk iterations per 32-tile block, each a global load -> barrier -> LDS ->
-// barrier -> 12 MFMAs round trip of ~3 us.  A deeper pipeline would not rescue the shape: a 32-tile block re-streams all 36
-// weight planes of its 64 channels (885 KB of L2 -> LDS traffic per 0.3 MB of V), ~0.3 ms at best, and the block cannot grow --
-// the 16 partial outputs per item are 128 registers a thread at 32 x 64 already.  Kept as the record of the attempt.
-constexpr int kRfTiles = 32, kRfCols = 64;
-constexpr int kRfLd = 40;                                   // bf16 elements per plane row (32 + pad)
-constexpr int kRfRows = 2 * kRfTiles + 2 * kRfCols;         // staged rows of a chunk: A of two positions, B of two positions
-constexpr int kRfPlane = kRfRows * kRfLd;                   // bf16 elements of one plane
-constexpr size_t kRfLds = (size_t)6 * kRfTiles * kRfCols * 4 + (size_t)3 * kRfPlane * 2;
-
-struct RowFusedArgs {
-  const float* V;                 // [36][ps_v]: rows of K floats
-  const unsigned short* U3;       // three ROW-MAJOR planes of [36][rows_pad][K] bf16
-  const float* bias;
-  float* y;
-  float* partial;                 // [ceil(T / tpb)][N][2] or null
-  long long y_ld, ps_v, plane_elems, T;
-  int H, W, TH, TW, N, rows_pad, tpb;
-  float slope;
-};
-
-template <int K>
-__global__ __launch_bounds__(256) void wino4_rowfused_kernel(RowFusedArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* M6 = lds;                                                     // [6][32][64]
-  unsigned short* sp = reinterpret_cast<unsigned short*>(lds + 6 * kRfTiles * kRfCols);   // three planes of kRfRows rows
-  float* s_red = reinterpret_cast<float*>(sp);                         // BatchNorm sums re-use the staging space at the end
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pp = wave >> 1, chh = wave & 1;                            // position of the pair, channel half
-  const int n0 = blockIdx.y * kRfCols;
-  const int group = p.tpb > kRfTiles ? p.tpb : kRfTiles;
-  const int halves = group / kRfTiles;
-  const long long tw0 = (long long)blockIdx.x * group;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // staging roles: A = one float4 of V per position of the pair; B = one 16-byte piece per (position, plane)
-  const int g8 = tid >> 3, kq = tid & 7;
-  const int a_row = (g8 & ~15) | ((g8 >> 2) & 3) | ((g8 & 3) << 2);    // conv_gemm_kernel's row order (conflict-free 8-byte stores)
-  const int b_row = tid >> 2, b_piece = tid & 3;
-  f32x4 s1[2] = {zero, zero}, s2[2] = {zero, zero};                    // BatchNorm sums of this thread's two items
-
-  for (int half = 0; half < halves; ++half) {
-    const long long t0 = tw0 + (long long)half * kRfTiles;
-    if (t0 >= p.T) break;
-    long long arow = t0 + a_row;
-    arow = arow < p.T ? arow : p.T - 1;
-    const float* a_src = p.V + arow * K + kq * 4;
-    const unsigned short* b_src = p.U3 + (long long)(n0 + b_row) * K + b_piece * 8;
-    f32x4 o[2][4][4];
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[it][i][j] = zero;
-
-#pragma unroll 1
-    for (int r = 0; r < 6; ++r) {
-#pragma unroll 1
-      for (int pair = 0; pair < 3; ++pair) {
-        const int pos0 = r * 6 + pair * 2;
-        f32x16_t acc;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll 1
-        for (int kc = 0; kc < K / 32; ++kc) {
-          // global -> registers
-          f32x4 ra[2];
-          uint4 rb[2][3];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            ra[j] = ld4(a_src + (long long)(pos0 + j) * p.ps_v + kc * 32);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              rb[j][q] = *reinterpret_cast<const uint4*>(b_src + q * p.plane_elems + (long long)(pos0 + j) * p.rows_pad * K + kc * 32);
-          }
-          __syncthreads();                       // the previous chunk's fragment reads are done
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            uint2 h, m, l;
-            fsd_conv::split3(ra[j], h, m, l);
-            unsigned short* d = sp + (j * kRfTiles + a_row) * kRfLd + kq * 4;
-            *reinterpret_cast<uint2*>(d) = h;
-            *reinterpret_cast<uint2*>(d + kRfPlane) = m;
-            *reinterpret_cast<uint2*>(d + 2 * kRfPlane) = l;
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              *reinterpret_cast<uint4*>(sp + q * kRfPlane + (2 * kRfTiles + j * kRfCols + b_row) * kRfLd + b_piece * 8) = rb[j][q];
-          }
-          __syncthreads();
-          const unsigned short* sa = sp + (pp * kRfTiles + (lane & 31)) * kRfLd + (lane >> 5) * 8;
-          const unsigned short* sb = sp + (2 * kRfTiles + pp * kRfCols + chh * 32 + (lane & 31)) * kRfLd + (lane >> 5) * 8;
-#pragma unroll
-          for (int k16 = 0; k16 < 2; ++k16) {
-            bf16x8_t af[3], bf[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              af[q] = *reinterpret_cast<const bf16x8_t*>(sa + q * kRfPlane + k16 * 16);
-              bf[q] = *reinterpret_cast<const bf16x8_t*>(sb + q * kRfPlane + k16 * 16);
-            }
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};     // the six terms, smallest first (conv.hip)
-#pragma unroll
-            for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]], bf[TB[t]], acc, 0, 0, 0);
-          }
-        }
-        // this wave's 32 x 32 block of M[r][pair * 2 + pp]
-        float* dst = M6 + ((pair * 2 + pp) * kRfTiles + 4 * (lane >> 5)) * kRfCols + chh * 32 + (lane & 31);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dst[((q & 3) + 8 * (q >> 2)) * kRfCols] = acc[q];
-      }
-      __syncthreads();                           // row r of M is complete
-      // At column r: the weights of W_r in the four output rows
-      const float c1 = r == 0 || r == 5 ? 0.f : ((r & 1) ? 1.f : -1.f) * (r >= 3 ? 2.f : 1.f);
-      const float c0 = r == 5 ? 0.f : 1.f;
-      const float c2 = r == 0 || r == 5 ? 0.f : (r >= 3 ? 4.f : 1.f);
-      const float c3 = r == 0 ? 0.f : r == 5 ? 1.f : ((r & 1) ? 1.f : -1.f) * (r >= 3 ? 8.f : 1.f);
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid + 256 * it;
-        const float* src = M6 + (idx >> 4) * kRfCols + (idx & 15) * 4;
-        f32x4 u[4];
-        at4(ld4(src), ld4(src + kRfTiles * kRfCols), ld4(src + 2 * kRfTiles * kRfCols), ld4(src + 3 * kRfTiles * kRfCols),
-            ld4(src + 4 * kRfTiles * kRfCols), ld4(src + 5 * kRfTiles * kRfCols), u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[it][0][j] = fma_s(c0, u[j], o[it][0][j]);
-          o[it][1][j] = fma_s(c1, u[j], o[it][1][j]);
-          o[it][2][j] = fma_s(c2, u[j], o[it][2][j]);
-          o[it][3][j] = fma_s(c3, u[j], o[it][3][j]);
-        }
-      }
-      // (the next row's M stores come after at least one staging barrier, which every thread reaches after these reads)
-    }
-    // ---- outputs of this half ----
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = tid + 256 * it;
-      const long long tile = t0 + (idx >> 4);
-      if (tile >= p.T) continue;
-      const int g4 = n0 + (idx & 15) * 4;
-      const f32x4 bv = p.bias ? ld4(p.bias + g4) : zero;
-      const unsigned utile = (unsigned)tile;
-      const int tx = (int)(utile % (unsigned)p.TW);
-      const unsigned ut2 = utile / (unsigned)p.TW;
-      const int ty = (int)(ut2 % (unsigned)p.TH);
-      const long long b = ut2 / (unsigned)p.TH;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oy = 4 * ty + i;
-        if (oy >= p.H) continue;
-        float* dsty = p.y + ((b * p.H + oy) * (long long)p.W + 4 * tx) * p.y_ld + g4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (4 * tx + j >= p.W) continue;
-          f32x4 v = o[it][i][j] + bv;
-          if (p.slope != 1.f) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.slope;
-          }
-          st4(dsty + j * p.y_ld, v);
-          s1[it] += o[it][i][j];
-          s2[it] += o[it][i][j] * o[it][i][j];
-        }
-      }
-    }
-    if (p.partial != nullptr && (p.tpb <= kRfTiles || half == halves - 1 || t0 + kRfTiles >= p.T)) {
-      // BatchNorm partial rows of tpb tiles: tpb <= 32 -> 32 / tpb rows per half, tpb = 64 -> one row for both halves
-      __syncthreads();                           // staging space is free
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        float* mine = s_red + (size_t)(tid + 256 * it) * 8;              // [32 tiles][16 quads][8]
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { mine[k] = s1[it][k]; mine[4 + k] = s2[it][k]; }
-        s1[it] = zero;
-        s2[it] = zero;
-      }
-      __syncthreads();
-      const int gt = p.tpb < kRfTiles ? p.tpb : kRfTiles;
-      const int ngroups = kRfTiles / gt;
-      for (int e = tid; e < ngroups * kRfCols; e += 256) {
-        const int grp = e / kRfCols, ch = e - grp * kRfCols;
-        const long long prow = p.tpb < kRfTiles ? (t0 / p.tpb) + grp : (long long)blockIdx.x;
-        if (prow * p.tpb < p.T) {
-          float a = 0.f, q = 0.f;
-          for (int t = 0; t < gt; ++t) {
-            const float* e8 = s_red + (size_t)((grp * gt + t) * 16 + (ch >> 2)) * 8 + (ch & 3);
-            a += e8[0];
-            q += e8[4];
-          }
-          float* dstp = p.partial + (prow * p.N + n0 + ch) * 2;
-          dstp[0] = a;
-          dstp[1] = q;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
+#ifdef FSD_EXPERIMENTS
+#include "winograd_experiments.inc"
+#endif
 
 // U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
 // rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
@@ -1485,7 +969,7 @@ extern "C" int fsd_wino_pack_weight(const float* w_oihw, float* u_packed, int co
 }
 
 inline bool out4_on(int cout) {
-  static const char* out4_env = getenv("FSD_WINO_OUT4");
+  static const char* out4_env = FSD_TUNE("FSD_WINO_OUT4");
   return cout >= 128 && !(out4_env && out4_env[0] == '0');
 }
 
@@ -1494,6 +978,7 @@ inline int fwd_ksplit(long long T, int cin, int cout, int tile) {
   return tile == 4 && out4_on(cout) ? fsd_conv::batched_ksplit(T, cin, cout, npos(tile)) : 1;
 }
 
+#ifdef FSD_EXPERIMENTS
 // The fused position-GEMM + output-transform kernel (wino4_gemm_out_kernel) can take the F(4x4) layers with 64 / 128 input
 // channels under the split arithmetic.  EXPERIMENTAL, off by default (FSD_WINO_FUSED=1 or fsd_wino_fused_mode(1) turns it on):
 // measured slower than the three launches it replaces, see the kernel's comment.
@@ -1501,7 +986,7 @@ std::atomic<int> g_fused_mode{-1};      // -1: not yet read from the environment
 inline int fused_mode() {
   int m = g_fused_mode.load(std::memory_order_relaxed);
   if (m < 0) {
-    const char* env = getenv("FSD_WINO_FUSED");
+    const char* env = FSD_TUNE("FSD_WINO_FUSED");
     m = env && (env[0] == '1' || env[0] == '2') ? env[0] - '0' : 0;
     g_fused_mode.store(m, std::memory_order_relaxed);
   }
@@ -1528,7 +1013,7 @@ extern "C" int fsd_wino_fused_mode(int mode) {
 // bandwidth the one-pass launches run at -- and that costs more than the memory-side cache gives back (copies inside 192 MB:
 // 6.8-7.0 TB/s against 4.7-5.3 beyond 384 MB, tools/probes/mall_probe.py).
 inline long long slab_tiles(long long T, int cin, int cout, int tile, bool has_vin) {
-  static const char* env = getenv("FSD_WINO_SLAB_MB");
+  static const char* env = FSD_TUNE("FSD_WINO_SLAB_MB");
   const long long budget = (env ? atoll(env) : 0) * 1000000LL;
   if (budget <= 0 || tile != 4 || !out4_on(cout) || has_vin || fwd_ksplit(T, cin, cout, tile) > 1) return T;
   const long long per_tile = 36LL * (cin + cout) * 4;
@@ -1539,6 +1024,12 @@ inline long long slab_tiles(long long T, int cin, int cout, int tile, bool has_v
   S = ((T + n - 1) / n + 511) / 512 * 512;
   return S < T ? S : T;
 }
+
+#else
+inline bool fused_ok(int, int, int) { return false; }
+inline bool rowfused_ok(int, int, int) { return false; }
+inline long long slab_tiles(long long T, int, int, int, bool) { return T; }
+#endif
 
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
@@ -1600,6 +1091,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   const int rows_pad = round_up(cout, 128);
+#ifdef FSD_EXPERIMENTS
   if (fused_ok(cin, cout, tile) && !v_in) {
     // input transform -> bf16 planes in fragment order (+ the fp32 V for the weight gradient if asked); weights -> planes;
     // position GEMMs + output transform in one kernel
@@ -1631,7 +1123,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
                reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin, 1);
     const unsigned grid = (unsigned)((T + group - 1) / group);
-    static const char* nw_env = getenv("FSD_WINO_FUSED_WAVES");        // tuning aid: 4 or 8 waves
+    static const char* nw_env = FSD_TUNE("FSD_WINO_FUSED_WAVES");        // tuning aid: 4 or 8 waves
     const bool w8 = nw_env && nw_env[0] == '8';
     auto go = [&](auto kern, int threads) -> int {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1643,11 +1135,14 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     if (cin == 64) return w8 ? go(wino4_gemm_out_kernel<64, 8>, 512) : go(wino4_gemm_out_kernel<64, 4>, 256);
     return w8 ? go(wino4_gemm_out_kernel<128, 8>, 512) : go(wino4_gemm_out_kernel<128, 4>, 256);
   }
+#endif
   float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * pos_stride(T, cin);
   const long long n_in = T * (cin / 4);
   const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
   const long long S = slab_tiles(T, cin, cout, tile, v_in != nullptr);
+  (void)S;
+#ifdef FSD_EXPERIMENTS
   if (S < T) {
     // Slabs (opt-in, measured slower -- slab_tiles): transform -> position GEMMs -> transform for S tiles at a time.  V (36 x T x
     // Cin floats) and M (36 x T x Cout) of the 104x104 / 52x52 layers are 0.6-1.2 GB per launch, each written by one kernel and
@@ -1677,6 +1172,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     }
     return (int)hipGetLastError();
   }
+#endif
   if (!V) {
     // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
@@ -1691,6 +1187,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f, 0LL, T);
     V = Vw;
   }
+#ifdef FSD_EXPERIMENTS
   if (rowfused_ok(cin, cout, tile)) {
     // weights -> row-major bf16 planes (into the space M would take); position GEMMs + output transform in one kernel
     const long long u_plane = (long long)P * rows_pad * cin;
@@ -1715,6 +1212,7 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
     };
     return cin == 64 ? go(wino4_rowfused_kernel<64>) : go(wino4_rowfused_kernel<128>);
   }
+#endif
   const int ks = fwd_ksplit(T, cin, cout, tile);
   const long long ss = (long long)P * pos_stride(T, cout);          // slice s of every position lies behind slice s - 1 of all
   int rc = fsd_conv::conv_gemm_batched(V, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout, pos_stride(T, cout), T, cin, cout,
@@ -1728,10 +1226,13 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                        bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
+#ifdef FSD_EXPERIMENTS
     if (out4_on(cout) && ks > 1)
       FSD_LAUNCH((wino4_output4_kernel<32, true>), dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope, ks, ss, pos_stride(T, cout), 0LL);
-    else if (out4_on(cout))
+    else
+#endif
+    if (out4_on(cout))
       FSD_LAUNCH(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope, 1, 0LL, pos_stride(T, cout), 0LL);
     else if (cg <= 32)
@@ -1879,7 +1380,7 @@ extern "C" int fsd_wino_dy_bn_transform_g(const float* dz, long long dz_ld, cons
   // FSD_DY_CPT=2 (tuning aid): two channels per thread, 79 registers instead of 130 -- the kernel then fits beside an 8-wave GEMM
   // workgroup of the weight-gradient stream (112 registers of a SIMD lane are free there).  Measured in the step, four runs per
   // arm on one box: 25.84 against 25.83 ms -- co-residency alone buys nothing, the default stays four channels (16-byte accesses).
-  static const char* cpt_env = getenv("FSD_DY_CPT");
+  static const char* cpt_env = FSD_TUNE("FSD_DY_CPT");
   if (cpt_env && cpt_env[0] == '2')
     FSD_LAUNCH((wino4_dy_kernel<2, 2>), dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, stream, dy, (long long)channels,
                wt_out, height, width, TH, TW, channels, T, y, y_ld, coef, mean, invstd, gg);

@@ -258,25 +258,7 @@ class EpisodeTrainer(object):
         # a bucket that is already being reduced had all of its parameters sunk: nothing of it is left to gather
         self.gather_grads(sunk)
         self.reduce_and_step()
-        self._prepack()
         self._throttle()
-
-    # OPT-IN (FSD_PREPACK=1): the packed / Winograd-transformed copies of the weights the optimizer just changed are rebuilt
-    # right away on a side stream (engine._WeightCache.prepack) instead of one by one in front of their first reader on the
-    # next step's critical path.  Measured on one box, four runs each: 28.9 / 27.2 / 26.3 / 26.3 ms with it, 26.2 / 26.2 /
-    # 26.1 / 26.3 without -- the ~50 small kernels are cheap where they are, a fifth stream is not.
-    prepack_weights = os.environ.get("FSD_PREPACK", "0") == "1"
-
-    def _prepack(self):
-        if not (self.prepack_weights and self.grad.is_cuda and streams.ENABLED):
-            return
-        nets = [n for n in (getattr(self.net, "_det", None), getattr(self.net, "_meta", None)) if n is not None]
-        if not nets:
-            return
-        s = streams.side(self.grad.device, "pack")
-        s.wait_stream(torch.cuda.current_stream())               # the fused SGD kernels of this step
-        for n in nets:
-            n.cache.prepack(s)
 
     # How many steps the host may queue ahead of the GPU.  Unbounded, a host that enqueues a step in ~8 ms against ~25 ms of
     # GPU time is 20 steps ahead after 25 steps; tensors that crossed a stream (record_stream) cannot be re-used by the caching

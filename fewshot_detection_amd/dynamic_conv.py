@@ -45,24 +45,27 @@ class _ConvNd(nn.Module):
         return s.format(**self.__dict__) + ", bias=False"
 
 
+class DynamicConv2d(_ConvNd):
+    """The one variant the shipped cfgs build (is_first=True, partial=None).  Module-level -- the reference defines the class
+    inside its factory (dynamic_conv.py:112), which makes every model that holds one unpicklable; this one pickles."""
+    is_first = True
+    partial = None
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=False):
+        super(DynamicConv2d, self).__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
+                                            _pair(padding), _pair(dilation), False, _pair(0), groups, bias)
+
+    def forward(self, inputs):
+        x, w = inputs
+        assert tuple(w.shape[-2:]) == self.kernel_size == (1, 1)
+        assert w.shape[1] == x.shape[1], "reweighting vector width != feature channels"
+        return ops.dynamic_conv(x, w)
+
+
 def dynamic_conv2d(is_first, partial=None):
     if partial is not None:
         raise NotImplementedError("partial dynamic convolution is not used by any shipped cfg")
     if not is_first:
         raise NotImplementedError("only the first dynamic convolution of a network is supported")
-
-    class DynamicConv2d(_ConvNd):
-        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
-                     groups=1, bias=False):
-            super(DynamicConv2d, self).__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
-                                                _pair(padding), _pair(dilation), False, _pair(0), groups, bias)
-
-        def forward(self, inputs):
-            x, w = inputs
-            assert tuple(w.shape[-2:]) == self.kernel_size == (1, 1)
-            assert w.shape[1] == x.shape[1], "reweighting vector width != feature channels"
-            return ops.dynamic_conv(x, w)
-
-    DynamicConv2d.is_first = is_first
-    DynamicConv2d.partial = partial
     return DynamicConv2d

@@ -55,8 +55,7 @@ def bump_stats_epoch():
 
 class _WeightCache(object):
     """Packed (K-major) copies of conv weights, refreshed when the parameter changes.
-    Entries: key -> [tag, packed, weight, event]; `event` is set by prepack() (the copy was rebuilt on a side stream: the
-    first reader waits for it)."""
+    Entries: key -> [tag, packed, weight]."""
 
     def __init__(self):
         self._store = {}
@@ -81,39 +80,20 @@ class _WeightCache(object):
             if hit is not None and other is not None:
                 bufs = (hit[1], other[1]) if mode == 0 else (other[1], hit[1])
             pair = ops.pack_weight_bf16_pair(w.detach(), bufs)
-            self._store[(id(w), 0, dtype)] = [tag, pair[0], w, None]
-            self._store[(id(w), 1, dtype)] = [tag, pair[1], w, None]
+            self._store[(id(w), 0, dtype)] = [tag, pair[0], w]
+            self._store[(id(w), 1, dtype)] = [tag, pair[1], w]
             return pair[mode]
         if hit is None or hit[0] != tag:
-            hit = [tag, self._build(w, mode, dtype), w, None]
+            hit = [tag, self._build(w, mode, dtype), w]
             self._store[key] = hit
-        elif hit[3] is not None:
-            torch.cuda.current_stream().wait_event(hit[3])      # rebuilt by prepack() on a side stream
-            hit[1].record_stream(torch.cuda.current_stream())
-            hit[3] = None
         return hit[1]
 
-    def prepack(self, stream):
-        """Rebuild every stale fp32 copy NOW, on `stream` (a side stream that already waits for the parameter update):
-        ~50 small transform / pack kernels per step (0.7 ms of kernel time) leave the critical path of the next step's
-        forward and backward sweeps, whose first reader of each copy waits on its event instead.  -> copies rebuilt."""
-        n = 0
-        with torch.cuda.stream(stream):
-            for key, ent in self._store.items():
-                w = ent[2]
-                if key[2] == "bf16" or ent[0] == self._tag(w):
-                    continue
-                ent[1] = self._build(w, key[1], key[2])
-                ent[0] = self._tag(w)
-                ent[3] = stream.record_event()
-                n += 1
-        return n
 
 
 FOLD_EVAL_BN = True     # inference: BatchNorm folded into the conv operands, leaky in the conv epilogue (Network._conv_eval)
 # fp32 training: a conv + BatchNorm + leaky layer whose only reader is the next convolution hands over its raw output and the
-# reader forms the activation on load (Network._defers_to_consumer).  FSD_DEFER_ACT=0: every activation is materialised.
-DEFER_ACTIVATION = os.environ.get("FSD_DEFER_ACT", "1") != "0"
+# reader forms the activation on load (Network._defers_to_consumer).  DEFER_ACTIVATION = False: every activation is materialised.
+DEFER_ACTIVATION = True
 
 
 class Network(object):

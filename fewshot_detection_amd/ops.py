@@ -258,7 +258,7 @@ def wino_tile_inference(cin, cout, ksize, H, W, batch):
     """The inference form's choice (BatchNorm folded, nothing kept for a backward pass): wino_tile's, except that a position
     GEMM of at most 64 rows is bound by READING its transformed weights -- 36 x Cin x Cout floats for F(4x4) against 16 for
     F(2x2): 151 MB against 67 MB on a 1024 -> 1024 layer, 30 us against 13 at the transforms' 5 TB/s, which is more than
-    the layer's arithmetic at valid_ensemble.py's two images per batch.  OPT-IN (FSD_INFER_F2=1): measured on MI355X the
+    the layer's arithmetic at valid_ensemble.py's two images per batch.  OPT-IN (SMALL_BATCH_F2 = True): measured on MI355X the
     forward of two images went from 0.83 to 0.88 ms with it -- the F(4x4) launches are short of bytes in flight, not of
     bandwidth (fsd_conv::batched_ksplit is the fix that worked), and the F(2x2) transforms are the older, slower kernels."""
     tile = wino_tile(cin, cout, ksize, H, W)
@@ -267,13 +267,13 @@ def wino_tile_inference(cin, cout, ksize, H, W, batch):
     return tile
 
 
-SMALL_BATCH_F2 = os.environ.get("FSD_INFER_F2", "0") == "1"
+SMALL_BATCH_F2 = False
 WINOGRAD = True     # Winograd for eligible fp32 3x3 layers (forward, data gradient, weight gradient)
-WINOGRAD4 = os.environ.get("FSD_WINO4", "1") != "0"    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
+WINOGRAD4 = True    # allow F(4x4,3x3) where it needs fewer multiplications than F(2x2,3x3)
 # One-pass BN backward + both gradient transforms (fsd_wino_grad_transforms).  Bit-identical to the separate kernels but
 # MEASURED SLOWER on MI355X (3.59 vs 3.04 ms per step: 72 loads + 72 stores per thread over two overlapping 6x6 patches
 # run at 4.5 TB/s at L2 level against 7.8 TB/s for the single-tensor transforms), so it is off by default.
-FUSE_WINO_GRAD = os.environ.get("FSD_FUSE_WINO_GRAD", "0") == "1"
+FUSE_WINO_GRAD = False
 WINO4_MIN_CH = 64   # F(4x4): minimum of (Cin, Cout) (measured: pays from 64 channels at 104x104, not at 32 / 208x208)
 PROFILE = None      # bench.py sets this to a list, one entry per conv launch (forward / data gradient; a Winograd launch =
                     # transform + GEMM + transform): (start_event, end_event, algorithmic_flops, executed_mfma_flops,
@@ -401,23 +401,27 @@ def bn_finalize(partial, count, bn, training):
     return buf[0], buf[1], buf[2], buf[3]
 
 
+def _bn_counter_flush_hook(m, prefix, keep_vars):
+    n = getattr(m, "_fsd_pending_batches", 0)
+    if n and getattr(m, "num_batches_tracked", None) is not None:
+        m.num_batches_tracked += n
+    m._fsd_pending_batches = 0
+
+
+def _bn_counter_drop_hook(m, incompatible):
+    m._fsd_pending_batches = 0
+
+
 def install_bn_counter_hooks(module):
     """Every BatchNorm of `module` flushes its host-side batch count whenever ITS state is gathered (state_dict() of the
     module itself or of any parent, torch.save(model.models.state_dict()) included), and drops the pending count when a state
     is loaded into it (load_state_dict: the loaded counter is the truth, batches run before the load must not be added on
-    top; load_weights does not touch the counter -- a .weights file has none -- so the pending count stays, as in the reference)."""
-    def pre(m, prefix, keep_vars):
-        n = getattr(m, "_fsd_pending_batches", 0)
-        if n and getattr(m, "num_batches_tracked", None) is not None:
-            m.num_batches_tracked += n
-        m._fsd_pending_batches = 0
-
-    def post(m, incompatible):
-        m._fsd_pending_batches = 0
+    top; load_weights does not touch the counter -- a .weights file has none -- so the pending count stays, as in the reference).
+    The hooks are module-level functions: a model that carries them still pickles (torch.save(model), spawned workers)."""
     for m in module.modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and not getattr(m, "_fsd_counter_hooks", False):
-            m.register_state_dict_pre_hook(pre)
-            m.register_load_state_dict_post_hook(post)
+            m.register_state_dict_pre_hook(_bn_counter_flush_hook)
+            m.register_load_state_dict_post_hook(_bn_counter_drop_hook)
             m._fsd_counter_hooks = True
 
 
@@ -608,7 +612,7 @@ def conv3x3_wgrad_c4_bnfused(dt, yv, coef, mean, invstd, xv, cin, cout, param=No
     return dw
 
 
-FUSE_FIRST_BWD = os.environ.get("FSD_FUSE_FIRST_BWD", "1") != "0"     # one-sweep backward of a first conv block
+FUSE_FIRST_BWD = True     # one-sweep backward of a first conv block
 
 
 def first_bwd_eligible(xv, yv, cout, ksize, pool, dz_full):
@@ -646,8 +650,8 @@ def first_layer_bwd(dz, yv, scale, shift, mean, invstd, slope, xv, cin, cout, bn
 
 
 # fp32 BatchNorm layers: the first backward pass only takes the statistics, the second one re-forms dt from the block-output
-# gradient (bn_bwd_apply_g / wino_dy_bn_transform_g) -- dt is never written or read back.  FSD_DEFER_DT=0: the two-pass form.
-DEFER_DT = os.environ.get("FSD_DEFER_DT", "1") != "0"
+# gradient (bn_bwd_apply_g / wino_dy_bn_transform_g) -- dt is never written or read back.  DEFER_DT = False: the two-pass form.
+DEFER_DT = True
 
 
 def bn_act_pool_bwd(dz, dz_full, yv, scale, shift, mean, invstd, slope, pool, want_dt=True):
@@ -809,5 +813,14 @@ def f32_gemm_mode(mode=None):
 def wino_fused_mode(on=None):
     """EXPERIMENTAL: the fused position-GEMM + output-transform kernels for F(4x4) layers with 64 / 128 input channels
     (include/fsdet.h fsd_wino_fused_mode): 0 off (default), 1 operands from L1 with all of M in LDS, 2 operands staged in LDS
-    with M resident one transform row at a time.  Returns the previous setting (int); None only queries."""
-    return int(lib().fsd_wino_fused_mode(-1 if on is None else int(on)))
+    with M resident one transform row at a time.  Returns the previous setting (int); None only queries.  Exists only in a
+    library built with -DFSD_EXPERIMENTS (both modes measured slower than the three launches); the default library raises."""
+    fn = getattr(lib(), "fsd_wino_fused_mode", None)
+    if fn is None:
+        raise RuntimeError("this libfsdet_hip.so was built without -DFSD_EXPERIMENTS: no fused Winograd pipeline")
+    return int(fn(-1 if on is None else int(on)))
+
+
+def experiments_built():
+    """True if the loaded library carries the experimental kernels (make EXTRA=-DFSD_EXPERIMENTS)."""
+    return hasattr(lib(), "fsd_wino_fused_mode")

@@ -63,7 +63,9 @@ def autotune(step, tries=3, reps=2, slack=1.03, good=0.96):
     form, in which case everything runs on one stream (ENABLED = False).  Measured on MI355X boxes of the pool: about one
     process in eight starts with a stream set on which a step takes 36-43 ms instead of 26 (the one-stream step: 27.5), and
     now and then with one that overlaps only half as well (28.8 against 25.4 ms), for as long as those streams live.
-    -> dict(report).  A no-op when the streams are disabled."""
+    -> dict(report).  A no-op when the streams are disabled.
+    NOTE for library users: `step` is EXECUTED (1 + reps calls per timing, up to 2 * (tries + 1) timings) -- if it is a training
+    step, the weights, the optimizer state and BatchNorm's running statistics advance by that many steps and stay advanced."""
     import time
     global ENABLED
     report = {"enabled_before": ENABLED, "tries": []}

@@ -487,13 +487,14 @@ int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stre
  * first use reads the environment variable FSD_F32_SPLIT (0 / 1). */
 int fsd_f32_gemm_mode(int mode);
 
-/* EXPERIMENTAL (default 0 = off; first use reads FSD_WINO_FUSED): F(4x4) layers with 64 / 128 input channels under the split
- * arithmetic run the 36 position GEMMs and the output transform in ONE kernel (the 36 x tiles x Cout intermediate never leaves
- * the CU).  mode 1: operands as bf16 planes straight from L1, all of M in LDS (wino4_gemm_out_kernel); mode 2: operands staged
- * in LDS, M resident one transform row at a time, partial outputs in registers (wino4_rowfused_kernel).  Same results to fp32
- * round-off; both measured slower than the three launches they replace on MI355X (csrc/winograd.hip).  mode 0 / 1 / 2 sets,
- * anything else queries; returns the previous mode.  fsd_wino_workspace_bytes follows the mode: query it after switching. */
+#ifdef FSD_EXPERIMENTS
+/* Only in a library built with -DFSD_EXPERIMENTS (make EXTRA=-DFSD_EXPERIMENTS); the default library does not export it.
+ * F(4x4) layers with 64 / 128 input channels under the split arithmetic run the 36 position GEMMs and the output transform in
+ * ONE kernel (mode 1: operands as bf16 planes from L1, all of M in LDS; mode 2: operands staged in LDS, M one transform row at a
+ * time).  Same results to fp32 round-off; both measured slower than the three launches they replace.
+ * mode 0 / 1 / 2 sets, anything else queries; returns the previous mode.  The workspace size follows the mode. */
 int fsd_wino_fused_mode(int mode);
+#endif
 
 const char* fsd_version(void);
 

@@ -239,6 +239,41 @@ def test_activation_formed_on_load_is_bit_identical_to_the_materialised_one(dev,
         ops.f32_gemm_mode(before)
 
 
+@pytest.mark.parametrize("shape,slope", [
+    ((64, 13, 13, 1024, 512), 0.1),      # L19 / L21 of the detector at B = 64: 42 x 4 = 168 tiles of 256 x 128
+    ((24, 26, 26, 512, 512), 0.1),       # 63 x 4 = 252 tiles, 96 rows left over for the 64-row tail launch
+    ((24, 26, 26, 512, 256), 1.7),       # a slope outside [0, 1]: the ACT = 2 form (select instead of max)
+    ((64, 13, 13, 1024, 512), -0.3),
+])
+def test_activation_on_load_in_the_8_wave_1x1_kernel_is_bit_identical(dev, shape, slope):
+    """the 1x1 layers that go to conv_gemm_split8_kernel (>= 128 tiles of 256 x 128: split8_1x1 in csrc/conv.hip)
+    form leaky(y * scale + shift) in their hand-scheduled staging pipeline (ACT = 1: 0 <= slope <= 1 as max(t, slope * t);
+    ACT = 2: any slope).  Output and BatchNorm partial sums equal those on the materialised activation bit for bit -- the
+    small case above (507 pixels) never reaches this kernel."""
+    from fewshot_detection_amd import ops
+    before = ops.f32_gemm_mode("split")
+    try:
+        B, H, W, C, cout = shape
+        assert (B * H * W // 256) * (cout // 128) >= 128         # the launcher's condition for the 8-wave kernel
+        torch.manual_seed(sum(shape))
+        yv = ops.nchw_to_nhwc(torch.randn(B, C, H, W, device=dev))
+        scale = torch.rand(C, device=dev) + 0.5
+        shift = torch.randn(C, device=dev) * 0.3
+        lazy = ops.View(yv.t, B, H, W, C, 0, lazy=(scale, shift, slope))
+        act = ops.materialise(lazy)
+        w1 = torch.randn(cout, C, 1, 1, device=dev) * 0.05
+        pw = ops.pack_weight(w1)
+        a, pa = ops.conv2d(act, pw, cout, 1, bn_partial=True)
+        b, pb = ops.conv2d(lazy, pw, cout, 1, bn_partial=True)
+        assert torch.equal(a.t, b.t) and torch.equal(pa, pb)
+        ref = F.conv2d(F.leaky_relu(ops.nhwc_to_nchw(yv).double() * scale.double().view(1, -1, 1, 1)
+                                    + shift.double().view(1, -1, 1, 1), slope), w1.double())
+        got = ops.nhwc_to_nchw(b).double()
+        assert float((got - ref).norm() / ref.norm()) < 5e-6
+    finally:
+        ops.f32_gemm_mode(before)
+
+
 def test_training_step_with_deferred_activations_equals_the_materialised_step(dev, tmp_path, monkeypatch):
     """engine.DEFER_ACTIVATION: the step that hands raw conv outputs to their single consumer (1x1 convs and F(4x4) layers
     of the standard detector) computes, bit for bit, the output and every gradient of the step that runs each BatchNorm +

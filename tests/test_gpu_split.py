@@ -206,6 +206,8 @@ def test_experimental_fused_winograd_pipeline_matches_the_three_launches(dev, sh
     transform (csrc/winograd.hip, wino4_gemm_out_kernel; off by default).  Same contract as the three-launch pipeline: output
     (+ bias, leaky), the kept V of the weight gradient, the BatchNorm partial sums."""
     from fewshot_detection_amd import ops
+    if not ops.experiments_built():
+        pytest.skip("libfsdet_hip.so built without -DFSD_EXPERIMENTS (the default): the fused kernels are not in it")
     B, H, W, cin, cout = shape
     ops.f32_gemm_mode("split")
     torch.manual_seed(sum(shape))

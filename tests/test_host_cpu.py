@@ -19,12 +19,17 @@ import ref_shim  # noqa: E402
 def test_library_exports_every_declared_symbol():
     from fewshot_detection_amd import _lib
     header = open(os.path.join(ROOT, "include", "fsdet.h")).read()
-    declared = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 29
+    default_part = re.sub(r"#ifdef FSD_EXPERIMENTS.*?#endif", "", header, flags=re.S)     # what the default build declares
+    declared = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", default_part))
+    experimental = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", header)) - declared
+    assert len(declared) >= 29 and experimental == set(_lib.EXPERIMENTAL_PROTOTYPES)
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     lib = _lib.lib()                                   # loads without a GPU (no compute calls here)
     for name in declared:
         assert hasattr(lib, name), name
+    from fewshot_detection_amd import ops
+    for name in experimental:                          # all of them or none (one build flag)
+        assert hasattr(lib, name) == ops.experiments_built(), name
     assert lib.fsd_version().startswith(b"fsdet-hip")
     assert lib.fsd_conv_row_tiles(1000, 256, 64, 3) == 16 and lib.fsd_packed_weight_elems(30, 1024, 1) == 128 * 1024
 
@@ -348,16 +353,27 @@ def test_winograd_workspace_follows_the_arithmetic_and_the_experimental_pipeline
     """fsd_wino_workspace_bytes is host logic (no GPU): V + M of the three-launch pipeline; with the experimental fused pipeline
     on (fsd_wino_fused_mode, split arithmetic, 64 / 128 input channels) at least the bf16 operand planes of V and U as well.
     The switch reports the previous setting and only changes on 0 / 1."""
-    from fewshot_detection_amd import _lib
+    from fewshot_detection_amd import _lib, ops
     lib = _lib.lib()
+    B, H, W, cin, cout = 64, 104, 104, 64, 128
+    T = B * 26 * 26
+    plain = 36 * T * (cin + cout) * 4
+    if not ops.experiments_built():                    # the default library: one pipeline, one size, in both arithmetics
+        split_before = lib.fsd_f32_gemm_mode(-1)
+        try:
+            for mode in (0, 1):
+                lib.fsd_f32_gemm_mode(mode)
+                assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
+        finally:
+            lib.fsd_f32_gemm_mode(split_before)
+        with pytest.raises(RuntimeError, match="FSD_EXPERIMENTS"):
+            ops.wino_fused_mode()
+        return
     split_before = lib.fsd_f32_gemm_mode(-1)
     fused_before = lib.fsd_wino_fused_mode(-1)
     try:
         lib.fsd_f32_gemm_mode(1)
         assert lib.fsd_wino_fused_mode(0) == fused_before and lib.fsd_wino_fused_mode(7) == 0 and lib.fsd_wino_fused_mode(-1) == 0
-        B, H, W, cin, cout = 64, 104, 104, 64, 128
-        T = B * 26 * 26
-        plain = 36 * T * (cin + cout) * 4
         assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
         assert lib.fsd_wino_fused_mode(1) == 0 and lib.fsd_wino_fused_mode(-1) == 1
         planes = 36 * 3 * 2 * (T + 128) * cin                              # T is a multiple of 32; U rows padded to 128
@@ -368,3 +384,35 @@ def test_winograd_workspace_follows_the_arithmetic_and_the_experimental_pipeline
     finally:
         lib.fsd_wino_fused_mode(fused_before)
         lib.fsd_f32_gemm_mode(split_before)
+
+
+def test_a_constructed_model_pickles(tmp_path):
+    """the BatchNorm counter hooks were local closures (and the reference's DynamicConv2d is a class defined inside
+    its factory): torch.save(model) / handing the module to a spawned process failed.  Both are module-level now."""
+    import io
+    from fewshot_detection_amd.darknet_meta import Darknet
+    net = Darknet(os.path.join(GOLD, "mini_dynamic.cfg"), os.path.join(GOLD, "mini_reweight.cfg"))
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert type(back).__name__ == "Darknet"
+    for (ka, va), (kb, vb) in zip(net.state_dict().items(), back.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+
+
+def test_every_environment_switch_of_the_default_build_is_documented():
+    """at most 15 FSD_* environment switches in the default library + package, each with a row in
+    INTEGRATION.md's table; every other knob is FSD_TUNE(...) -- compiled in only with -DFSD_EXPERIMENTS."""
+    import glob
+    pkg = os.path.join(ROOT, "fewshot_detection_amd")
+    read = set()
+    for path in glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.hpp")) + \
+            glob.glob(os.path.join(pkg, "csrc", "*.inc")):
+        read |= set(re.findall(r'[^_A-Za-z]getenv\("(FSD_[A-Z0-9_]+)"\)', open(path).read()))
+    for path in glob.glob(os.path.join(pkg, "*.py")) + [os.path.join(ROOT, "bench.py")]:
+        read |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(FSD_[A-Z0-9_]+)"', open(path).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = set(re.findall(r"^\| `(FSD_[A-Z0-9_]+)` \|", doc, flags=re.M))
+    assert read == table, (read - table, table - read)
+    assert len(read) <= 15, sorted(read)
