@@ -219,6 +219,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 
 // halo-staged direct 3x3 convolution of the narrow layers under the split arithmetic (conv_halo.hip)
 bool halo_ok(int height, int width, int cin, int cout, int ksize, bool nchw);
+// weight gradient of the narrow 3x3 layers on 8 x 8 pixel blocks with a halo patch (wgrad_halo.hip)
+bool wgrad3x3_halo_ok(int height, int width, int cin, int cout, int ksize);
+int wgrad3x3_halo_slots(int batch, int height, int width);
+int wgrad3x3_halo(const float* dy, long long dy_ld, const float* x, long long x_ld, float* ws, int batch, int height, int width,
+                  int* slots_out, hipStream_t stream);
 int conv3x3_halo(const float* x, long long x_ld, const float* w_packed, int kpad, const float* bias, float* y, long long y_ld,
                  float* bn_partial, int batch, int height, int width, int cin, int cout, float slope, hipStream_t stream);
 

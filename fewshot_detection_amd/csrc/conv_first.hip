@@ -9,10 +9,18 @@
 //   D[pixel][co]: 32 lanes store 128 contiguous bytes per pixel.
 //   BatchNorm partial sums (sum y, sum y^2 per channel) accumulate in registers over the wave's whole pixel run and
 //   leave as ONE partial row per block.
+//
+// Round 5, split arithmetic (the default fp32 GEMM mode): conv_first_split_kernel below.  The kernel above spends ~600 issued
+// instructions per 32-pixel tile around 18 dependent fp32 MFMAs (64 cycles each: 1152 matrix cycles per tile and SIMD) and ran
+// at 1.9 TB/s.  The products move to v_mfma_f32_32x32x16_bf16 on three-way split operands (conv.hip: six cross terms, fp32
+// accurate): 12 MFMAs of 32 cycles for 3 input channels, operands SWAPPED (rows = output channels, columns = pixels) so that a
+// lane owns 4 consecutive channels of one pixel per accumulator quad and stores 16 bytes straight from registers -- no LDS
+// patch, no per-row predication (whole 32-pixel tiles inside one image row: W % 32 == 0, every darknet input size).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "fsdet.h"
+#include "conv_common.hpp"
 #include "profile.hpp"
 #include "ew_types.hpp"
 
@@ -163,6 +171,207 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
   }
 }
 
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// K-slot layout of the split kernel.  A lane half h owns SLOTS = 8 * KS consecutive-in-program-order k-slots (slot q = 8 s + j
+// is element j of its operand register in k-step s).  Half 0 carries taps 0..4, half 1 taps 5..8, CIN values per tap, zeros
+// behind: (tap, ci) of slot q in half h = (5 h + q / CIN, q % CIN) while that tap is <= (h ? 8 : 4).  A (weights) and B
+// (pixels) use the same map, so any order is a valid reduction order.
+template <int CIN> struct FirstSlots {
+  static constexpr int KS = CIN == 3 ? 2 : 3;       // k-steps of 16: 27 -> 32 slots, 36 -> 48 slots
+  static constexpr int SLOTS = 8 * KS;              // per lane half
+  static constexpr int TAPS = 5;                    // float4 loads per lane and tile
+};
+
+template <int CIN, typename TO>
+__global__ __launch_bounds__(256) void conv_first_split_kernel(FirstFwdArgs p) {
+  typedef FirstSlots<CIN> L;
+  constexpr int KS = L::KS, SLOTS = L::SLOTS;
+  __shared__ float s_red[4][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int co0 = blockIdx.y * 32;
+  // ---- A operand: the 3x3xCIN weights of output channel co0 + c, three bf16 planes, constant over the wave's run ----
+  bf16x8_t wa[3][KS];
+  {
+    float wv[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int tap = 5 * h + q / CIN, ci = q % CIN;
+      const bool ok = q < 5 * CIN && tap < 9 && ci < p.cin;
+      wv[q] = ok ? p.w[((size_t)(co0 + c) * p.cin + ci) * 9 + tap] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint2 h0, m0, l0, h1, m1, l1;
+      fsd_conv::split3(fsd_conv::f32x4{wv[8 * s], wv[8 * s + 1], wv[8 * s + 2], wv[8 * s + 3]}, h0, m0, l0);
+      fsd_conv::split3(fsd_conv::f32x4{wv[8 * s + 4], wv[8 * s + 5], wv[8 * s + 6], wv[8 * s + 7]}, h1, m1, l1);
+      wa[0][s] = __builtin_bit_cast(bf16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      wa[1][s] = __builtin_bit_cast(bf16x8_t, make_uint4(m0.x, m0.y, m1.x, m1.y));
+      wa[2][s] = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+  }
+  // bias of the block's 32 channels, read back per accumulator quad in the epilogue (accumulator r <-> channel
+  // 8 (r >> 2) + 4 h + (r & 3)); in LDS, not in 16 registers: 3 waves per SIMD instead of 2
+  __shared__ __attribute__((aligned(16))) float s_bias[32];
+  if (threadIdx.x < 32) s_bias[threadIdx.x] = p.bias ? p.bias[co0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  // ---- this wave's run of 32-pixel tiles (a tile lies inside one image row) ----
+  const long long tiles = p.pixels >> 5;
+  const long long t_begin = ((long long)blockIdx.x * 4 + wave) * (long long)(p.ppw >> 5);
+  long long t_end = t_begin + (p.ppw >> 5);
+  if (t_end > tiles) t_end = tiles;
+  // tap geometry of this lane's five loads (tile-invariant)
+  int t_dy[5], t_dx[5], t_off[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int tap = 5 * h + i;
+    t_dy[i] = tap < 9 ? tap / 3 - 1 : (1 << 20);                 // tap 9 (half 1, fifth load): never inside the image
+    t_dx[i] = tap < 9 ? tap % 3 - 1 : 0;
+    t_off[i] = tap < 9 ? (t_dy[i] * p.W + t_dx[i]) * (int)p.x_ld * 4 : 0;
+  }
+  const char* x_b = reinterpret_cast<const char*>(p.x);
+  char* y_b = reinterpret_cast<char*>(p.y);
+  const unsigned ys = p.y_ld * (unsigned)sizeof(TO);
+  const fsd_conv::f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float s1[16], s2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+
+  // position of the tile being LOADED: image row yy, first column x0, pixel index pix0 (wave-uniform)
+  const int tiles_per_row = p.W >> 5;
+  long long t_load = t_begin;
+  int x0 = (int)(t_begin % tiles_per_row) * 32;
+  int yy = (int)((t_begin / tiles_per_row) % p.H);
+  auto load = [&](fsd_conv::f32x4 (&v)[5]) {
+    const bool live = t_load < t_end;
+    const unsigned off = ((unsigned)(t_load << 5) + (unsigned)c) * p.x_ld * 4u;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const bool ok = live && (unsigned)(yy + t_dy[i]) < (unsigned)p.H && (unsigned)(x0 + c + t_dx[i]) < (unsigned)p.W;
+      const fsd_conv::f32x4 t = *reinterpret_cast<const fsd_conv::f32x4*>(x_b + (ok ? off + (unsigned)t_off[i] : 0u));
+      v[i] = ok ? t : zero4;
+    }
+    ++t_load;
+    x0 += 32;
+    if (x0 == p.W) { x0 = 0; if (++yy == p.H) yy = 0; }
+  };
+  auto compute = [&](long long tile, const fsd_conv::f32x4 (&v)[5]) {
+    // B operand: this lane's SLOTS values of pixel 32 tile + c, split into three planes
+    bf16x8_t xb[3][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      fsd_conv::f32x4 g0, g1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q0 = 8 * s + j, q1 = 8 * s + 4 + j;
+        g0[j] = q0 < 5 * CIN ? v[q0 / CIN][q0 % CIN] : 0.f;
+        g1[j] = q1 < 5 * CIN ? v[q1 / CIN][q1 % CIN] : 0.f;
+      }
+      uint2 h0, m0, l0, h1, m1, l1;
+      fsd_conv::split3(g0, h0, m0, l0);
+      fsd_conv::split3(g1, h1, m1, l1);
+      xb[0][s] = __builtin_bit_cast(bf16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      xb[1][s] = __builtin_bit_cast(bf16x8_t, make_uint4(m0.x, m0.y, m1.x, m1.y));
+      xb[2][s] = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // the six cross terms down to 2^-16 relative, smallest first (rows = channels: A = weights, columns = pixels: B = input)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[2][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2][s], xb[0][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], xb[1][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[1][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], xb[0][s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[0][s], acc, 0, 0, 0);
+    // lane (c, h): pixel 32 tile + c, channels co0 + 8 g + 4 h + (0..3) in accumulators 4 g .. 4 g + 3
+    const unsigned row = ((unsigned)(tile << 5) + (unsigned)c) * ys;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s1[r] += acc[r];
+      s2[r] = __builtin_fmaf(acc[r], acc[r], s2[r]);
+    }
+    if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const fsd_conv::f32x4 b4 = *reinterpret_cast<const fsd_conv::f32x4*>(s_bias + 8 * g + 4 * h);
+        const fsd_conv::f32x4 o = {acc[4 * g] + b4[0], acc[4 * g + 1] + b4[1], acc[4 * g + 2] + b4[2], acc[4 * g + 3] + b4[3]};
+        *reinterpret_cast<fsd_conv::f32x4*>(y_b + row + (unsigned)(co0 + 8 * g + 4 * h) * 4u) = o;
+      }
+    } else {
+      // bf16: 4 channels are 8 bytes.  The halves trade quads so that a lane stores 8 consecutive channels = 16 bytes: half 0
+      // keeps its quads g = 0, 2 and receives the partner's (channels 8 g + 4 .. + 7); half 1 keeps g = 1, 3 and receives the
+      // partner's quads (channels 8 g .. 8 g + 3).
+      unsigned pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const fsd_conv::f32x4 b4 = *reinterpret_cast<const fsd_conv::f32x4*>(s_bias + 8 * g + 4 * h);
+        pk[g][0] = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g] + b4[0]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 1] + b4[1]) << 16);
+        pk[g][1] = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 2] + b4[2]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 3] + b4[3]) << 16);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {                      // quad pair (0, 1) then (2, 3)
+        const int ga = 2 * e, gb = 2 * e + 1;
+        // half 0 sends quad gb, half 1 sends quad ga
+        const unsigned snd0 = h ? pk[ga][0] : pk[gb][0], snd1 = h ? pk[ga][1] : pk[gb][1];
+        const unsigned rcv0 = (unsigned)__shfl_xor((int)snd0, 32, 64), rcv1 = (unsigned)__shfl_xor((int)snd1, 32, 64);
+        // half 0 stores channels 8 ga .. 8 ga + 7 = own quad ga (8 ga + 0..3), partner's quad ga (8 ga + 4..7)
+        // half 1 stores channels 8 gb .. 8 gb + 7 = partner's quad gb (8 gb + 0..3), own quad gb (8 gb + 4..7)
+        const uint4 o = h ? make_uint4(rcv0, rcv1, pk[gb][0], pk[gb][1]) : make_uint4(pk[ga][0], pk[ga][1], rcv0, rcv1);
+        const int ch = h ? 8 * gb : 8 * ga;
+        *reinterpret_cast<uint4*>(y_b + row + (unsigned)(co0 + ch) * 2u) = o;
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    fsd_conv::f32x4 v0[5], v1[5];
+    load(v0);
+    for (long long t = t_begin; t < t_end; t += 2) {
+      load(v1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(t, v0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(v0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end) compute(t + 1, v1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (p.partial == nullptr) return;
+  // per-channel sums over the 32 pixel lanes of each half, then over the block's four waves
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) {
+      s1[r] += __shfl_xor(s1[r], m, 64);
+      s2[r] += __shfl_xor(s2[r], m, 64);
+    }
+  }
+  if (c == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+      s_red[wave][ch][0] = s1[r];
+      s_red[wave][ch][1] = s2[r];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float* dst = p.partial + ((size_t)blockIdx.x * p.Cout + co0 + threadIdx.x) * 2;
+    dst[0] = s_red[0][threadIdx.x][0] + s_red[1][threadIdx.x][0] + s_red[2][threadIdx.x][0] + s_red[3][threadIdx.x][0];
+    dst[1] = s_red[0][threadIdx.x][1] + s_red[1][threadIdx.x][1] + s_red[2][threadIdx.x][1] + s_red[3][threadIdx.x][1];
+  }
+}
+
 inline int first_fwd_blocks(long long pixels) {
   long long b = (pixels + 4 * 256 - 1) / (4 * 256);        // at least 256 pixels per wave
   return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
@@ -195,6 +404,14 @@ int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const f
   static const char* wide_env = FSD_TUNE("FSD_FIRST_WIDE");           // tuning aid: 0 = narrow stores
   a.wide = (!(wide_env && wide_env[0] == '0') && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_ld * sizeof(TO)) % 16 == 0) ? 1 : 0;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)batch * height * width * (16.0 + (double)sizeof(TO) * cout), stream);
+  // split arithmetic (the default of the fp32 GEMMs, FSD_F32_SPLIT): the bf16-MFMA kernel for whole 32-pixel row tiles and
+  // 16-byte stores; everything else (native arithmetic, odd widths, unaligned destinations) keeps the fp32-MFMA kernel
+  static const char* v2_env = FSD_TUNE("FSD_FIRST_SPLIT");           // tuning aid: 0 = always the fp32-MFMA kernel
+  if (!(v2_env && v2_env[0] == '0') && fsd_conv::f32_split_on() && a.wide && width % 32 == 0) {
+    if (cin == 3) FSD_LAUNCH((conv_first_split_kernel<3, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    else FSD_LAUNCH((conv_first_split_kernel<4, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   FSD_LAUNCH(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }

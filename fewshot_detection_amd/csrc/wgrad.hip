@@ -828,6 +828,24 @@ int wgrad_impl(const float* dy, long long dy_ld, const float* x, long long x_ld,
       FSD_LAUNCH(wgrad_reduce_kernel<8>, dim3((cin + 31) / 32, cout), dim3(256), 0, stream, a.ws, dw_oihw, slots, cout, cin, cin, 1, cin);
     return (int)hipGetLastError();
   }
+  if (!bf16 && !x_scale && f32_variant() == 0 && fsd_conv::wgrad3x3_halo_ok(height, width, cin, cout, ksize) &&
+      (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // 32 -> 64 channels (darknet L2, the reweighting net's second layer): 8 x 8 pixel blocks, dy and the halo patch of x
+    // fetched and split once for all nine taps (wgrad_halo.hip); one 64 x 288 partial per workgroup
+    const int ncols = 9 * cin;
+    if (workspace_bytes < (size_t)fsd_conv::wgrad3x3_halo_slots(batch, height, width) * cout * ncols * sizeof(float))
+      return FSD_ERR_WORKSPACE;
+    int slots = 0;
+    if (int rc = fsd_conv::wgrad3x3_halo(dy, dy_ld, x, x_ld, reinterpret_cast<float*>(workspace), batch, height, width, &slots, stream))
+      return rc;
+    if (slots <= 8)
+      FSD_LAUNCH(wgrad_reduce_kernel<1>, dim3((ncols + 255) / 256, cout), dim3(256), 0, stream, reinterpret_cast<const float*>(workspace),
+                 dw_oihw, slots, cout, cin, cin, 9, ncols);
+    else
+      FSD_LAUNCH(wgrad_reduce_kernel<8>, dim3((ncols + 31) / 32, cout), dim3(256), 0, stream, reinterpret_cast<const float*>(workspace),
+                 dw_oihw, slots, cout, cin, cin, 9, ncols);
+    return (int)hipGetLastError();
+  }
   const int tile = bf16 ? tile_of(bf16) : f32_tile(cout, ksize * ksize * cin4);
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
@@ -1047,6 +1065,10 @@ extern "C" size_t fsd_conv2d_wgrad_workspace_bytes(int batch, int height, int wi
   }
   const int s8 = split8_1x1_splits(pixels, cin, cout, ksize);
   if (s8 + 1 > splits) splits = s8 + 1;             // + the slot of the < 32-row side launch
+  if (ksize == 3 && cin == 32 && cout == 64 && height % 8 == 0 && width % 8 == 0) {      // wgrad_halo.hip's partials (either mode)
+    const int hs = fsd_conv::wgrad3x3_halo_slots(batch, height, width);
+    if (hs > splits) splits = hs;
+  }
   return (size_t)splits * cout * ncols * sizeof(float);
 }
 

@@ -78,6 +78,49 @@ def test_first_layer_conv_matches_fp64_reference(dev, B, H, W, cin, cout, bias):
         assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,bias", [(2, 20, 32, 3, 32, False), (1, 13, 96, 4, 64, True), (2, 5, 64, 4, 32, False),
+                                                  (1, 3, 32, 1, 32, False), (3, 64, 160, 3, 64, True), (2, 33, 224, 2, 32, False)])
+@pytest.mark.parametrize("out_dtype", ["f32", "bf16"])
+def test_first_layer_split_kernel_matches_fp64_reference(dev, B, H, W, cin, cout, bias, out_dtype):
+    """conv_first_split_kernel (round 5): widths that are multiples of 32 take the bf16-MFMA kernel on three-way split operands
+    under the split arithmetic -- swapped operands, 16-byte stores from registers, per-lane BatchNorm sums.  Same contract as the
+    fp32-MFMA kernel (which the native arithmetic keeps): output incl. bias, image borders, the padding channel, partial sums
+    of the fp32 accumulators; the bf16 store of the bf16 mode is the rounded fp32 result."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + H + W)
+    x = torch.zeros(B, 4, H, W)
+    x[:, :cin] = torch.rand(B, cin, H, W, generator=g) * 2 - 0.5
+    if cin < 4:
+        x[:, cin:] = 7.0                                   # padding channels must not leak into the result
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = F.conv2d(x[:, :cin].double(), w.double(), None if b is None else b.double(), 1, 1)
+    xv = ops.nchw_to_nhwc(x.to(dev))
+    res = {}
+    before = ops.f32_gemm_mode()
+    try:
+        for mode in ("split", "native"):
+            ops.f32_gemm_mode(mode)
+            yv, part = ops.conv3x3_c4(xv, w.to(dev), cout, bias=None if b is None else b.to(dev), bn_partial=not bias,
+                                      out_dtype=torch.bfloat16 if out_dtype == "bf16" else torch.float32)
+            res[mode] = (ops.nhwc_to_nchw(yv).double().cpu(), None if part is None else part.double().sum(0).cpu())
+    finally:
+        ops.f32_gemm_mode(before)
+    for mode, (y, p) in res.items():
+        err = float((y - ref).norm() / ref.norm())
+        assert err < (3e-3 if out_dtype == "bf16" else 2e-6), (mode, err)
+        if out_dtype == "f32":
+            assert torch.allclose(y, ref, rtol=1e-5, atol=2e-6), (mode, float((y - ref).abs().max()))
+        else:                                              # the stored value is the bf16 rounding of an fp32-accurate result
+            assert float((y - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8
+        if p is not None:
+            flat = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+            assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-5, atol=1e-3), mode
+            assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-5, atol=1e-3), mode
+    if out_dtype == "f32":                                 # two fp32-accurate kernels: they agree to round-off
+        assert float((res["split"][0] - res["native"][0]).abs().max()) < 4e-6 * float(ref.abs().max())
+
+
 def test_conv_nchw_store_and_asymmetric_weights(dev):
     """Transposed-accumulator epilogue: identity-like input with an ASYMMETRIC weight catches row/col swaps."""
     from fewshot_detection_amd import ops

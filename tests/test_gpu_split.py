@@ -35,6 +35,9 @@ SHAPES = [  # B, H, W, cin, cout, k
     (2, 104, 104, 32, 64, 3),      # direct 3x3
     (2, 112, 112, 32, 64, 3),      # direct 3x3, halo-staged under split (H % 8 == 0, W % 16 == 0): forward 32->64, data gradient 64->32
     (3, 16, 32, 64, 64, 3),        # halo-staged, two 32-channel slices each way
+    (3, 8, 8, 32, 64, 3),          # halo-staged weight gradient (wgrad_halo.hip: 32 -> 64, H % 8 == W % 8 == 0): one block per image
+    (1, 24, 40, 32, 64, 3),        # ... 3 x 5 blocks, one workgroup walks all of them
+    (6, 64, 48, 32, 64, 3),        # ... 288 blocks on 36 workgroups of 8
     (4, 26, 26, 512, 256, 1),      # 1x1 (20 tiles of 256x128: too few for the 8-wave kernel, 64x64 tiles)
     (24, 26, 26, 512, 512, 1),     # 1x1 on the 8-wave kernel: 63 whole 256-row tiles x 4 + a 96-row tail on 64x64 tiles
     (3, 7, 7, 256, 512, 3),        # small map of the reweighting net
