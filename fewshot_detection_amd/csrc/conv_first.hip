@@ -184,9 +184,16 @@ template <int CIN> struct FirstSlots {
   static constexpr int TAPS = 5;                    // float4 loads per lane and tile
 };
 
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
+template <int CIN> struct PixelVec { typedef fsd_conv::f32x4 type; };
+// three input channels: a 12-byte load.  With a 16-byte load the compiler knows the fourth component is dead, hands that register
+// to address arithmetic right behind the load and has to wait for the load first (WAW): s_waitcnt vmcnt(0) inside the load phase
+template <> struct PixelVec<3> { typedef f32x3_t type; };
+
 template <int CIN, typename TO>
 __global__ __launch_bounds__(256) void conv_first_split_kernel(FirstFwdArgs p) {
   typedef FirstSlots<CIN> L;
+  typedef typename PixelVec<CIN>::type pix_t;
   constexpr int KS = L::KS, SLOTS = L::SLOTS;
   __shared__ float s_red[4][32][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,9 +219,10 @@ __global__ __launch_bounds__(256) void conv_first_split_kernel(FirstFwdArgs p) {
       wa[2][s] = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
     }
   }
-  // bias of the block's 32 channels, read back per accumulator quad in the epilogue (accumulator r <-> channel
-  // 8 (r >> 2) + 4 h + (r & 3)); in LDS, not in 16 registers: 3 waves per SIMD instead of 2
+  // bias of the block's 32 channels, read back per accumulator quad in the bf16 epilogue (accumulator r <-> channel
+  // 8 (r >> 2) + 4 h + (r & 3)); in LDS, not in 16 registers
   __shared__ __attribute__((aligned(16))) float s_bias[32];
+  __shared__ __attribute__((aligned(16))) float s_tile[4 * 32 * 36];       // per wave: [32 px][32 ch + 4] fp32 or [32 px][16 + 4 dwords] bf16
   if (threadIdx.x < 32) s_bias[threadIdx.x] = p.bias ? p.bias[co0 + threadIdx.x] : 0.f;
   __syncthreads();
   // ---- this wave's run of 32-pixel tiles (a tile lies inside one image row) ----
@@ -234,31 +242,47 @@ __global__ __launch_bounds__(256) void conv_first_split_kernel(FirstFwdArgs p) {
   const char* x_b = reinterpret_cast<const char*>(p.x);
   char* y_b = reinterpret_cast<char*>(p.y);
   const unsigned ys = p.y_ld * (unsigned)sizeof(TO);
-  const fsd_conv::f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  float s1[16], s2[16];
+  // BatchNorm partial sums of the raw accumulators.  fp32 output: taken where the tile LEAVES the LDS patch -- a lane always stores
+  // the same four channels (4 (lane & 7) ..), so 4 + 4 accumulators instead of 16 + 16 (3 waves per SIMD instead of 2).  bf16
+  // output: the patch holds rounded values, the sums are taken from the accumulators (16 channels per lane).  (Routing the bf16
+  // output through an fp32 patch as well -- 8 + 8 sum registers -- came out at 162 registers, 2 waves per SIMD.)
+  constexpr int NS = sizeof(TO) == 4 ? 4 : 16;
+  float s1[NS], s2[NS];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  fsd_conv::f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (sizeof(TO) == 4 && p.bias) bias4 = *reinterpret_cast<const fsd_conv::f32x4*>(p.bias + co0 + 4 * (lane & 7));
 
   // position of the tile being LOADED: image row yy, first column x0, pixel index pix0 (wave-uniform)
   const int tiles_per_row = p.W >> 5;
   long long t_load = t_begin;
   int x0 = (int)(t_begin % tiles_per_row) * 32;
   int yy = (int)((t_begin / tiles_per_row) % p.H);
-  auto load = [&](fsd_conv::f32x4 (&v)[5]) {
+  // The loads are UNCONDITIONAL from clamped (always mapped) addresses and the zero-select happens at use (mask): a select right
+  // behind its load makes the compiler wait for the data inside the load phase -- s_waitcnt vmcnt(0) after the first load of every
+  // tile, which also waits for the previous tile's stores: no prefetch at all, 12 us per tile and wave (PMC: 73 % of the wave time
+  // in s_waitcnt, 3 TB/s; the fp32-MFMA kernel above has the same flaw).
+  auto load = [&](pix_t (&v)[5], unsigned& mask) {
     const bool live = t_load < t_end;
     const unsigned off = ((unsigned)(t_load << 5) + (unsigned)c) * p.x_ld * 4u;
+    mask = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const bool ok = live && (unsigned)(yy + t_dy[i]) < (unsigned)p.H && (unsigned)(x0 + c + t_dx[i]) < (unsigned)p.W;
-      const fsd_conv::f32x4 t = *reinterpret_cast<const fsd_conv::f32x4*>(x_b + (ok ? off + (unsigned)t_off[i] : 0u));
-      v[i] = ok ? t : zero4;
+      v[i] = *reinterpret_cast<const pix_t*>(x_b + (ok ? off + (unsigned)t_off[i] : 0u));
+      mask |= (ok ? 1u : 0u) << i;
     }
     ++t_load;
     x0 += 32;
     if (x0 == p.W) { x0 = 0; if (++yy == p.H) yy = 0; }
   };
-  auto compute = [&](long long tile, const fsd_conv::f32x4 (&v)[5]) {
-    // B operand: this lane's SLOTS values of pixel 32 tile + c, split into three planes
+  auto compute = [&](long long tile_i, const pix_t (&vr)[5], unsigned mask) {
+    pix_t v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) v[i][j] = (mask >> i) & 1u ? vr[i][j] : 0.f;
+    // B operand: this lane's SLOTS values of pixel 32 tile_i + c, split into three planes
     bf16x8_t xb[3][KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -276,92 +300,127 @@ __global__ __launch_bounds__(256) void conv_first_split_kernel(FirstFwdArgs p) {
       xb[1][s] = __builtin_bit_cast(bf16x8_t, make_uint4(m0.x, m0.y, m1.x, m1.y));
       xb[2][s] = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
     }
+    // the six cross terms down to 2^-16 relative, smallest first (rows = channels: A = weights, columns = pixels: B = input).
+    // (Two alternating chains into two accumulators cost 16 registers = a wave per SIMD: 0.47 -> 0.49 ms; the kernel is bound by
+    // latency per wave, occupancy is what hides it.)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // the six cross terms down to 2^-16 relative, smallest first (rows = channels: A = weights, columns = pixels: B = input)
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[2][s], acc, 0, 0, 0);
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2][s], xb[0][s], acc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], xb[1][s], acc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[1][s], acc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][s], xb[0][s], acc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][s], xb[0][s], acc, 0, 0, 0);
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[TA[t]][s], xb[TB[t]][s], acc, 0, 0, 0);
     // lane (c, h): pixel 32 tile + c, channels co0 + 8 g + 4 h + (0..3) in accumulators 4 g .. 4 g + 3
-    const unsigned row = ((unsigned)(tile << 5) + (unsigned)c) * ys;
+    if constexpr (sizeof(TO) != 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s1[r] += acc[r];
-      s2[r] = __builtin_fmaf(acc[r], acc[r], s2[r]);
+      for (int r = 0; r < 16; ++r) {
+        s1[r] += acc[r];
+        s2[r] = __builtin_fmaf(acc[r], acc[r], s2[r]);
+      }
     }
+    // The tile crosses a wave-private LDS patch so that every store instruction writes WHOLE lines: straight from the
+    // accumulators a lane holds four channel quads of one pixel, i.e. a store instruction would touch 32 lines with 32 bytes each
+    // (measured: 655 us at B = 64 against 503 for the fp32-MFMA kernel).  Quads go in as they lie (ds_write_b128 / b64, rows
+    // padded by 16 bytes: conflict-free), rows come out as 16-byte pieces, 8 (fp32) / 4 (bf16) lanes per pixel row.
     if constexpr (sizeof(TO) == 4) {
+      float* tile = s_tile + wave * (32 * 36);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const fsd_conv::f32x4 b4 = *reinterpret_cast<const fsd_conv::f32x4*>(s_bias + 8 * g + 4 * h);
-        const fsd_conv::f32x4 o = {acc[4 * g] + b4[0], acc[4 * g + 1] + b4[1], acc[4 * g + 2] + b4[2], acc[4 * g + 3] + b4[3]};
-        *reinterpret_cast<fsd_conv::f32x4*>(y_b + row + (unsigned)(co0 + 8 * g + 4 * h) * 4u) = o;
+        const fsd_conv::f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<fsd_conv::f32x4*>(tile + c * 36 + 8 * g + 4 * h) = o;
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): wave-private patch, the DS unit serves a wave in order
+      const int pc = lane & 7, pr = lane >> 3;
+      const unsigned base = (unsigned)(tile_i << 5) * ys + (unsigned)(co0 + pc * 4) * 4u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rowp = pr + 8 * q;
+        const fsd_conv::f32x4 v4 = *reinterpret_cast<const fsd_conv::f32x4*>(tile + rowp * 36 + pc * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s1[j] += v4[j];
+          s2[j] = __builtin_fmaf(v4[j], v4[j], s2[j]);
+        }
+        *reinterpret_cast<fsd_conv::f32x4*>(y_b + base + (unsigned)rowp * ys) = v4 + bias4;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);               // the patch is read before the next tile overwrites it
     } else {
-      // bf16: 4 channels are 8 bytes.  The halves trade quads so that a lane stores 8 consecutive channels = 16 bytes: half 0
-      // keeps its quads g = 0, 2 and receives the partner's (channels 8 g + 4 .. + 7); half 1 keeps g = 1, 3 and receives the
-      // partner's quads (channels 8 g .. 8 g + 3).
-      unsigned pk[4][2];
+      unsigned* tile = reinterpret_cast<unsigned*>(s_tile) + wave * (32 * 20);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const fsd_conv::f32x4 b4 = *reinterpret_cast<const fsd_conv::f32x4*>(s_bias + 8 * g + 4 * h);
-        pk[g][0] = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g] + b4[0]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 1] + b4[1]) << 16);
-        pk[g][1] = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 2] + b4[2]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 3] + b4[3]) << 16);
+        uint2 pk;
+        pk.x = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g] + b4[0]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 1] + b4[1]) << 16);
+        pk.y = (unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 2] + b4[2]) | ((unsigned)fsd_ew::f32_to_bf16(acc[4 * g + 3] + b4[3]) << 16);
+        *reinterpret_cast<uint2*>(tile + c * 20 + 4 * g + 2 * h) = pk;         // channels 8 g + 4 h .. + 3 = dwords 4 g + 2 h, + 1
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      const int pc = lane & 3, pr = lane >> 2;
+      const unsigned base = (unsigned)(tile_i << 5) * ys + (unsigned)(co0 + pc * 8) * 2u;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {                      // quad pair (0, 1) then (2, 3)
-        const int ga = 2 * e, gb = 2 * e + 1;
-        // half 0 sends quad gb, half 1 sends quad ga
-        const unsigned snd0 = h ? pk[ga][0] : pk[gb][0], snd1 = h ? pk[ga][1] : pk[gb][1];
-        const unsigned rcv0 = (unsigned)__shfl_xor((int)snd0, 32, 64), rcv1 = (unsigned)__shfl_xor((int)snd1, 32, 64);
-        // half 0 stores channels 8 ga .. 8 ga + 7 = own quad ga (8 ga + 0..3), partner's quad ga (8 ga + 4..7)
-        // half 1 stores channels 8 gb .. 8 gb + 7 = partner's quad gb (8 gb + 0..3), own quad gb (8 gb + 4..7)
-        const uint4 o = h ? make_uint4(rcv0, rcv1, pk[gb][0], pk[gb][1]) : make_uint4(pk[ga][0], pk[ga][1], rcv0, rcv1);
-        const int ch = h ? 8 * gb : 8 * ga;
-        *reinterpret_cast<uint4*>(y_b + row + (unsigned)(co0 + ch) * 2u) = o;
+      for (int q = 0; q < 2; ++q) {
+        const int rowp = pr + 16 * q;
+        const uint4 v4 = *reinterpret_cast<const uint4*>(tile + rowp * 20 + pc * 4);
+        *reinterpret_cast<uint4*>(y_b + base + (unsigned)rowp * ys) = v4;
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
     }
   };
 
   if (t_begin < t_end) {
-    fsd_conv::f32x4 v0[5], v1[5];
-    load(v0);
+    // Two tiles in flight.  (Peeling the first tile so that the loop is entered in its steady state -- the compiler's waitcnt
+    // model takes the smaller count of the entry and the back-edge path, so every other tile also waits for the previous tile's
+    // stores -- costs 8-30 registers = a wave per SIMD in the bf16 variant: not worth it.)
+    pix_t v0[5], v1[5];
+    unsigned m0 = 0, m1 = 0;
+    load(v0, m0);
     for (long long t = t_begin; t < t_end; t += 2) {
-      load(v1);
+      load(v1, m1);
       __builtin_amdgcn_sched_barrier(0);
-      compute(t, v0);
+      compute(t, v0, m0);
       __builtin_amdgcn_sched_barrier(0);
-      load(v0);
+      load(v0, m0);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_end) compute(t + 1, v1);
+      if (t + 1 < t_end) compute(t + 1, v1, m1);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (p.partial == nullptr) return;
-  // per-channel sums over the 32 pixel lanes of each half, then over the block's four waves
+  if constexpr (sizeof(TO) == 4) {
+    // lane l holds channels 4 (l & 7) .. + 3 of the pixel rows l >> 3 (+ 8 q): fold the eight row lanes
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-      s1[r] += __shfl_xor(s1[r], m, 64);
-      s2[r] += __shfl_xor(s2[r], m, 64);
+      for (int m = 8; m < 64; m <<= 1) {
+        s1[j] += __shfl_xor(s1[j], m, 64);
+        s2[j] += __shfl_xor(s2[j], m, 64);
+      }
     }
-  }
-  if (c == 0) {
+    if (lane < 8) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
-      s_red[wave][ch][0] = s1[r];
-      s_red[wave][ch][1] = s2[r];
+      for (int j = 0; j < 4; ++j) {
+        s_red[wave][4 * lane + j][0] = s1[j];
+        s_red[wave][4 * lane + j][1] = s2[j];
+      }
+    }
+  } else {
+    // per-channel sums over the 32 pixel lanes of each half
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) {
+        s1[r] += __shfl_xor(s1[r], m, 64);
+        s2[r] += __shfl_xor(s2[r], m, 64);
+      }
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int r = 0; r < NS; ++r) {
+        const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+        s_red[wave][ch][0] = s1[r];
+        s_red[wave][ch][1] = s2[r];
+      }
     }
   }
   __syncthreads();

@@ -242,7 +242,7 @@ def test_activation_formed_on_load_is_bit_identical_to_the_materialised_one(dev,
 @pytest.mark.parametrize("shape,slope", [
     ((64, 13, 13, 1024, 512), 0.1),      # L19 / L21 of the detector at B = 64: 42 x 4 = 168 tiles of 256 x 128
     ((24, 26, 26, 512, 512), 0.1),       # 63 x 4 = 252 tiles, 96 rows left over for the 64-row tail launch
-    ((24, 26, 26, 512, 256), 1.7),       # a slope outside [0, 1]: the ACT = 2 form (select instead of max)
+    ((24, 26, 26, 512, 512), 1.7),       # a slope outside [0, 1]: the ACT = 2 form (select instead of max)
     ((64, 13, 13, 1024, 512), -0.3),
 ])
 def test_activation_on_load_in_the_8_wave_1x1_kernel_is_bit_identical(dev, shape, slope):
