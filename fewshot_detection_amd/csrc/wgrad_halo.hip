@@ -15,7 +15,12 @@
 //     accumulators); a k-step = two block rows (16 pixels), per k-step 6 + 18 fragment reads feed 18 MFMAs;
 //   * a workgroup walks a contiguous run of blocks with its accumulators in registers (the next block's operands are in flight
 //     during the MFMAs) and stores ONE 64 x 288 partial; wgrad_reduce_kernel folds the partials in a fixed order.
-// 44 KB of LDS: three workgroups per CU.  Shapes: Cin = 32, Cout = 64, H % 8 == 0, W % 8 == 0; everything else stays on wgrad_kernel.
+// 44 KB of LDS, 128 registers: two workgroups per CU.  Measured at B = 64, 208x208 (tools/layer_bench.py wgrad): 0.67 ms against
+// 1.00 for wgrad_kernel (in the step 0.83 -> see DESIGN.md).  What the timing experiments of round 5 say about the rest
+// (tools/experiments_r05/gpu_r05g.sh, phases removed one at a time): the MFMAs alone run at their floor (0.35 ms), the transposing
+// fragment reads + barriers take 0.19, the split + LDS stores 0.11, the global loads 0.24 -- and the four ADD UP: one workgroup
+// per CU (256 instead of 512 workgroups) is only 1.2x slower, i.e. two co-resident workgroups hardly overlap their phases.
+// Shapes: Cin = 32, Cout = 64, H % 8 == 0, W % 8 == 0; everything else stays on wgrad_kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -68,29 +73,50 @@ __global__ __launch_bounds__(kThreadsH, 4) void wgrad3x3_halo_kernel(WgradHaloAr
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // ---- staging: global -> registers (one block ahead) -> three bf16 planes in LDS ----
+  // Addresses: everything that depends on the thread is computed ONCE -- the element offset of each of its six 16-byte pieces from
+  // the block's first pixel and which image border the piece lies beyond if the block touches that border (bits: 1 top, 2 bottom,
+  // 4 left, 8 right; 16 = no piece) -- and a block costs a uniform base pointer, four uniform edge flags and six adds.  (First
+  // version: 64-bit divisions of the block index and full per-piece coordinate arithmetic for every block -- ~450 of the ~860
+  // instructions a wave issued per block, for 72 MFMAs: the kernel ran at the same speed with its MFMAs removed.)
+  // Loads are unconditional from clamped addresses; the zero-select of the border happens in sstore (a select right behind its
+  // load makes the compiler wait for the data inside gload).
+  int xrel[kXF4], drel[kDF4];
+  unsigned xedge[kXF4];
+#pragma unroll
+  for (int i = 0; i < kXF4; ++i) {
+    const int e = tid + kThreadsH * i, hp = e >> 3, kq = e & 7;
+    const int hy = hp / kHP, hx = hp - hy * kHP;
+    xrel[i] = ((hy - 1) * p.W + (hx - 1)) * (int)p.x_ld + kq * 4;
+    xedge[i] = hp >= kHaloPx ? 16u : (hy == 0 ? 1u : 0u) | (hy == kHP - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == kHP - 1 ? 8u : 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < kDF4; ++i) {
+    const int e = tid + kThreadsH * i, px = e >> 4, cq = e & 15;
+    drel[i] = px < kBlkPx ? ((px >> 3) * p.W + (px & 7)) * (int)p.dy_ld + cq * 4 : 0;
+  }
+  // block position of the next gload (uniform), advanced block by block
+  int g_bx = (int)(pt_begin % p.bx);
+  int g_by = (int)((pt_begin / p.bx) % p.by);
+  int g_img = (int)(pt_begin / ((long long)p.bx * p.by));
   f32x4 rx[kXF4], rd[kDF4];
-  auto gload = [&](long long pt) {
-    const int bxi = (int)(pt % p.bx);
-    const long long t2 = pt / p.bx;
-    const int byi = (int)(t2 % p.by);
-    const int img = (int)(t2 / p.by);
-    const int x0 = bxi * kPB, y0 = byi * kPB;
+  unsigned xmask = 0;
+  auto gload = [&]() {
+    const long long org = ((long long)g_img * p.H + g_by * kPB) * p.W + g_bx * kPB;        // first pixel of the block
+    const float* xb = p.x + org * p.x_ld;
+    const float* db = p.dy + org * p.dy_ld;
+    const unsigned at = (g_by == 0 ? 1u : 0u) | (g_by == p.by - 1 ? 2u : 0u) | (g_bx == 0 ? 4u : 0u) | (g_bx == p.bx - 1 ? 8u : 0u) | 16u;
+    xmask = 0;
 #pragma unroll
     for (int i = 0; i < kXF4; ++i) {
-      const int e = tid + kThreadsH * i, hp = e >> 3, kq = e & 7;
-      const int hy = hp / kHP, hx = hp - hy * kHP;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      const bool ok = hp < kHaloPx && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const float* s = p.x + ((long long)(img * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * p.x_ld + kq * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(s);
-      rx[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = (xedge[i] & at) == 0;
+      rx[i] = *reinterpret_cast<const f32x4*>(xb + (ok ? xrel[i] : 0));
+      xmask |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
-    for (int i = 0; i < kDF4; ++i) {
-      const int e = tid + kThreadsH * i, px = e >> 4, cq = e & 15;
-      const bool ok = px < kBlkPx;
-      const int oy = y0 + (ok ? px >> 3 : 0), ox = x0 + (ok ? px & 7 : 0);
-      rd[i] = *reinterpret_cast<const f32x4*>(p.dy + ((long long)(img * p.H + oy) * p.W + ox) * p.dy_ld + cq * 4);
+    for (int i = 0; i < kDF4; ++i) rd[i] = *reinterpret_cast<const f32x4*>(db + drel[i]);
+    if (++g_bx == p.bx) {
+      g_bx = 0;
+      if (++g_by == p.by) { g_by = 0; ++g_img; }
     }
   };
   auto sstore = [&]() {
@@ -99,7 +125,7 @@ __global__ __launch_bounds__(kThreadsH, 4) void wgrad3x3_halo_kernel(WgradHaloAr
       const int e = tid + kThreadsH * i, hp = e >> 3, kq = e & 7;
       if (hp < kHaloPx) {
         uint2 h, m, l;
-        split3(rx[i], h, m, l);
+        split3((xmask >> i) & 1u ? rx[i] : f32x4{0.f, 0.f, 0.f, 0.f}, h, m, l);
         u16* d = sX + hp * kCin + kq * 4;
         *reinterpret_cast<uint2*>(d) = h;
         *reinterpret_cast<uint2*>(d + kXPlane) = m;
@@ -159,11 +185,11 @@ __global__ __launch_bounds__(kThreadsH, 4) void wgrad3x3_halo_kernel(WgradHaloAr
   };
 
   if (pt_begin < pt_end) {
-    gload(pt_begin);
+    gload();
     for (long long pt = pt_begin; pt < pt_end; ++pt) {
       sstore();
       __syncthreads();
-      if (pt + 1 < pt_end) gload(pt + 1);
+      if (pt + 1 < pt_end) gload();
       __builtin_amdgcn_sched_barrier(0);
       compute();
       __builtin_amdgcn_sched_barrier(0);
@@ -183,9 +209,10 @@ __global__ __launch_bounds__(kThreadsH, 4) void wgrad3x3_halo_kernel(WgradHaloAr
 }
 
 inline int halo_wg_blocks(long long patches) {
-  // three workgroups per CU (LDS), every one with at least 8 blocks to amortise its 74 KB partial
+  // two workgroups per CU are co-resident (12 of the 16 waves 128 registers allow; LDS would take three): ONE round of 512, every
+  // workgroup with at least 8 blocks to amortise its 74 KB partial.  (768 workgroups = 1.5 rounds cost the time of two.)
   long long b = patches / 8;
-  if (b > 768) b = 768;
+  if (b > 512) b = 512;
   return (int)(b < 1 ? 1 : b);
 }
 
