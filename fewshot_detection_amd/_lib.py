@@ -91,6 +91,7 @@ PROTOTYPES = {
     "fsd_conv2d_h_plan": (_i, [_ll, _i, _i, _i, _i, _i]),
     "fsd_conv2d_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_h_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "fsd_conv2d_wgrad_h_plan": (_i, [_ll, _i, _i, _i]),
     "fsd_conv2d_wgrad_h": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv3x3_c4_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _p]),
     "fsd_conv3x3_wgrad_c4_bnfused_h": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),

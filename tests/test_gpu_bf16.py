@@ -87,6 +87,12 @@ def test_conv_bf16_dma_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin
     (3, 1, 20, 20, 128, 128, 3),
     (6, 2, 26, 30, 64, 256, 3),          # 192x128, 4 waves (2 x 2, three accumulator rows), two workgroups per CU
     (6, 3, 13, 13, 1024, 1024, 1),
+    (7, 2, 26, 30, 64, 256, 3),          # 256x256 on FOUR waves of 128x128 (hand-pipelined loop), ragged M
+    (7, 1, 13, 13, 1280, 512, 3),        # ... K = 11520 (180 chunks), one partial row tile
+    (7, 3, 13, 13, 1024, 1024, 1),       # ... 1x1 (BK = 64: K = 1024), four column tiles
+    (8, 2, 26, 30, 64, 256, 3),          # 192x256 on four waves of 96x128
+    (8, 3, 13, 13, 1024, 1024, 1),
+    (8, 1, 1, 1, 64, 256, 3),            # a single pixel: one chunk per tap, every tap but the centre is padding
 ])
 def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypatch, tile, B, H, W, cin, cout, k):
     """The 8-wave tiles of conv_bf16_dma_kernel (one workgroup per CU), forced through FSD_CONV_H_TILE: forward with the
@@ -95,7 +101,7 @@ def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypa
     from fewshot_detection_amd._lib import lib
     monkeypatch.setenv("FSD_CONV_H_TILE", str(tile))
     assert lib().fsd_conv2d_h_plan(B * H * W, cin, cout, k, 0, 1) == tile
-    bm = {1: 256, 2: 192, 3: 256, 6: 192}[tile]
+    bm = {1: 256, 2: 192, 3: 256, 6: 192, 7: 256, 8: 192}[tile]
     assert lib().fsd_conv2d_h_partial_rows(B * H * W, cin, cout, k) == (B * H * W + bm - 1) // bm
     g = torch.Generator().manual_seed(tile * 100 + cin)
     x = _bf(torch.randn(B, cin, H, W, generator=g))
@@ -200,6 +206,44 @@ def test_wgrad_bf16_transpose_read_kernel_matches_fp64(dev, B, H, W, cin, cout, 
     assert dw.dtype == torch.float32 and dw.shape == (cout, cin, k, k)
     ref = w.grad
     err = float((dw.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+
+
+def _wgrad_fp64_on_device(x, gy, k):
+    """dW of a stride-1 'same' convolution in float64 on the device (one matrix product per tap): the large shapes that reach
+    the 256 x 256 weight-gradient tile would take minutes through CPU autograd."""
+    B, cin, H, W = x.shape
+    cout, pad = gy.shape[1], (k - 1) // 2
+    xp = F.pad(x.double(), (pad, pad, pad, pad))
+    g2 = gy.double().permute(1, 0, 2, 3).reshape(cout, -1)
+    dw = torch.empty(cout, cin, k, k, dtype=torch.float64, device=x.device)
+    for ky in range(k):
+        for kx in range(k):
+            xs = xp[:, :, ky:ky + H, kx:kx + W].permute(1, 0, 2, 3).reshape(cin, -1)
+            dw[:, :, ky, kx] = g2 @ xs.t()
+    return dw
+
+
+@pytest.mark.parametrize("w4", ["0", "1"])
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [
+    (16, 26, 26, 512, 512, 3),      # 2 x 18 tiles of 256 x 256, 6 splits, 64-pixel chunks that wrap image rows
+    (19, 26, 26, 264, 520, 3),      # ragged in both dimensions (520 = 2 x 256 + 8 rows, 2376 = 9 x 256 + 72 columns), 7 splits
+    (49, 26, 26, 1024, 1024, 1),    # 1x1: 16 tiles, 16 splits
+    (64, 13, 13, 512, 1024, 3),     # a timed shape (L18): image rows shorter than a chunk
+])
+def test_wgrad_bf16_256x256_both_wave_layouts_match_fp64(dev, monkeypatch, w4, B, H, W, cin, cout, k):
+    """The 256 x 256 weight-gradient tile as 2 x 4 waves of 128 x 64 (FSD_WGRAD_H_W4=0) and as 2 x 2 waves of 128 x 128 with
+    the hand-pipelined loop (inline-assembly transpose reads, counted waits, barrier in front of the last k-step)."""
+    from fewshot_detection_amd import ops
+    from fewshot_detection_amd._lib import lib
+    monkeypatch.setenv("FSD_WGRAD_H_W4", w4)
+    assert lib().fsd_conv2d_wgrad_h_plan(B * H * W, cin, cout, k) == 256256
+    g = torch.Generator().manual_seed(cin + cout + B)
+    x = _bf(torch.randn(B, cin, H, W, generator=g))
+    gy = _bf(torch.randn(B, cout, H, W, generator=g))
+    ref = _wgrad_fp64_on_device(x.to(dev), gy.to(dev), k)
+    dw = ops.conv2d_wgrad(_view_bf16(gy, dev), cout, _view_bf16(x, dev), cin, k)
+    err = float((dw.double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-5, err
 
 
