@@ -22,7 +22,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <type_traits>
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
@@ -81,18 +80,8 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // NS > 2: a ring -- chunk kc + NS - 1 is issued while chunk kc is computed, and the wait before the barrier is COUNTED
 // (only chunk kc + 1 has to have landed: (NS - 2) * PIECES newer DMA instructions may stay in flight).  Kept as a
 // tuning aid (FSD_CONV_H_RING=1): measured 5-15 % SLOWER than two drained stages (see the tile choice below).
-//
-// PIPE (round 5; the 4-wave tiles of 128x128 / 96x128 per wave, ONE wave per SIMD): a 64x64 wave tile reads 1 KB of LDS per
-// MFMA -- 128 B/clk/CU at the full matrix rate, all the LDS has, before the DMA's own writes (MI355X_MICROARCH.md) -- and
-// every tile above sits at 0.55-0.6 of what that leaves it (PMC, round 4).  A 128x128 wave tile reads half of that, but
-// its 256 accumulator registers leave room for one wave per SIMD only, so nothing else hides a wait: the loop is
-// software-pipelined by hand.  The fragments of k-step s+1 are read (second register set) before the MFMAs of step s
-// are issued; the chunk's barrier sits in front of the LAST step's MFMAs (its fragments are in registers by then, so the
-// stage is free, and the next chunk's DMA was issued in the steps before), and the first fragments of the next chunk
-// are read right behind the barrier, under those MFMAs.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT, bool ILV = false, int NS = 2, bool PIPE = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT, bool ILV = false, int NS = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(ConvHArgs p) {
-  static_assert(!PIPE || (ILV && NS == 2 && BK == 64 && !NCHW_F32_OUT), "the pipelined loop: interleaved DMA, two stages");
   static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
   static_assert(BK == 64 || BK == 32, "k-chunk of 64 or 32 bf16");
   static_assert(NS >= 2 && NS <= 6, "2 .. 6 LDS stages");
@@ -101,8 +90,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
   static_assert(TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile = whole 32x32 accumulators per wave");
-  static_assert(TN == 2 || (TN == 4 && !NCHW_F32_OUT) || (TN == 1 && WAVES_N == 1 && !NCHW_F32_OUT),
-                "a wave owns one or two even/odd pairs of 32-channel accumulators, or (32-channel outputs) a single one");
+  static_assert(TN == 2 || (TN == 1 && WAVES_N == 1 && !NCHW_F32_OUT),
+                "a wave owns one even/odd pair of 32-channel accumulators, or (32-channel outputs) a single one");
   constexpr int LPR = BK / 8;                 // lanes (16-byte groups) per tile row
   constexpr int RPP = NT / LPR;               // tile rows staged per pass of the workgroup
   constexpr int RPW = 64 / LPR;               // ... per wave instruction
@@ -141,7 +130,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
 #pragma unroll
   for (int j = 0; j < B_PER_T; ++j) {
     const int r = r0 + RPP * j;
-    const int ch = TN >= 2 ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;      // TN = 1: rows in channel order
+    const int ch = TN == 2 ? (r & ~63) + 2 * (r & 31) + ((r >> 5) & 1) : r;      // TN = 1: rows in channel order
     wrow[j] = p.w + (long long)(n0 + ch) * p.Kpad + g_src * 8;
   }
   const unsigned x_ld = (unsigned)p.x_ld;
@@ -171,19 +160,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
     } else {
       const int j = q - A_PER_T;
       dma16(wrow[j] + kc * BK, st + (BM + j * RPP + wave * RPW) * BK);
-    }
-  };
-  // the same piece, branch-free (PIPE): `live` = false fetches the zero page (the chunk past the last one).  A branch
-  // around the DMA block makes the compiler's wait-count pass fall back to lgkmcnt(0) at the join -- i.e. wait for the
-  // fragments just requested for the NEXT k-step before the MFMAs of this one.
-  auto piece_sel = [&](int q, int kc, u16* st, bool live) {
-    if (q < A_PER_T) {
-      const bool ok = live && ((tap_mask >> q) & 1u) && !(A_PARTIAL && q == A_PER_T - 1 && a_short);
-      const u16* src = ok ? p.x + (a_off[q] + (unsigned)f_cc * BK) : g_zero_page_h + pg * 8;
-      dma16(src, st + (q * RPP + wave * RPW) * BK);
-    } else {
-      const int j = q - A_PER_T;
-      dma16(live ? wrow[j] + kc * BK : g_zero_page_h + pg * 8, st + (BM + j * RPP + wave * RPW) * BK);
     }
   };
   auto advance = [&]() {                    // after the last piece of a chunk: next chunk's channel offset / tap
@@ -257,73 +233,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
     if (st_next != nullptr) advance();
   };
 
-  if constexpr (PIPE) {
-    constexpr int KS = BK / 16, PIECES = A_PER_T + B_PER_T, PPS = (PIECES + KS - 2) / (KS - 1);
-    // LDS byte addresses of this lane's fragment rows, and its 16-byte k-group of each k-step (bank swizzle undone)
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) u16*)smem_h;
-    const unsigned a_base = lds0 + (unsigned)((wm * TM * 32 + (lane & 31)) * BK * 2);
-    const unsigned b_base = lds0 + (unsigned)((BM + wn * TN * 32 + (lane & 31)) * BK * 2);
-    unsigned kob[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) kob[s] = (unsigned)((((2 * s + (lane >> 5)) ^ hl) & HMASK) * 16);
-    bf16x8 af[2][TM], bf[2][TN];
-    // The fragment reads are inline assembly and the waits are counted by hand: the compiler's own wait-count pass puts
-    // lgkmcnt(0) in front of the MFMAs of a step -- i.e. waits for the fragments just requested for the NEXT step (seen in
-    // the ISA with plain loads, whatever the control flow).  The counted wait names the registers it guards ("+v"), so no
-    // MFMA can be scheduled above it.
-    auto frags = [&](unsigned stage_bytes, int s, bf16x8* a, bf16x8* b) {
-      const unsigned aa = a_base + stage_bytes + kob[s], ba = b_base + stage_bytes + kob[s];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[i]) : "v"(aa), "n"(i * 32 * BK * 2) : "memory");
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[j]) : "v"(ba), "n"(j * 32 * BK * 2) : "memory");
-    };
-    auto landed = [&](bf16x8* a, bf16x8* b, auto pending) {      // fragments of a step are in registers; `pending` newer reads may fly
-      static_assert(TM <= 4 && TN == 4, "operand list written for TM <= 4, TN = 4");
-      constexpr int N = decltype(pending)::value;
-      if constexpr (TM == 4)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
-    };
-    auto mfmas = [&](const bf16x8* a, const bf16x8* b) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    };
-    gload_lds(0, smem_h);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    frags(0u, 0, af[0], bf[0]);
-    int cur = 0;
-    for (int kc = 0; kc < p.nk; ++kc) {
-      const bool more = kc + 1 < p.nk;
-      u16* st_next = smem_h + (cur ^ 1) * STAGE;
-#pragma unroll
-      for (int s = 0; s + 1 < KS; ++s) {
-        frags((unsigned)(cur * STAGE * 2), s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
-#pragma unroll
-        for (int q = s * PPS; q < (s + 1) * PPS && q < PIECES; ++q) piece_sel(q, kc + 1, st_next, more);
-        landed(af[s & 1], bf[s & 1], std::integral_constant<int, TM + TN>());
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(af[s & 1], bf[s & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (more) advance();
-      landed(af[(KS - 1) & 1], bf[(KS - 1) & 1], std::integral_constant<int, 0>());
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                       // every wave holds its last fragments: stage `cur` is free, the next one landed
-      frags((unsigned)((cur ^ 1) * STAGE * 2), 0, af[KS & 1], bf[KS & 1]);   // (past the last chunk: stale but mapped LDS, never used)
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(af[(KS - 1) & 1], bf[(KS - 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      cur ^= 1;
-    }
-    __syncthreads();                         // the epilogue re-uses the stages
-  } else if constexpr (NS == 2) {
+  if constexpr (NS == 2) {
     gload_lds(0, smem_h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -390,17 +300,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
           *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + nn) = odd ? pack2(got, b) : pack2(a, got);
       }
   } else if constexpr (!NCHW_F32_OUT) {
-    // lane l holds channels 2l (accumulator 2q) and 2l+1 (accumulator 2q+1) of the q-th 64-channel block of its wave
-    constexpr int NP = TN / 2;                                      // even/odd accumulator pairs per wave
-    const int nw = n0 + wn * TN * 32 + 2 * c_lane;                  // first channel of pair 0
-    bool n_ok[NP];
-    float bv0[NP], bv1[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      n_ok[q] = nw + 64 * q < p.Cout;                               // Cout is even (launcher)
-      bv0[q] = bv1[q] = 0.f;
-      if (p.bias != nullptr && n_ok[q]) { bv0[q] = p.bias[nw + 64 * q]; bv1[q] = p.bias[nw + 64 * q + 1]; }
-    }
+    // lane l holds channels 2l (accumulator 0) and 2l+1 (accumulator 1) of its wave's 64-channel block
+    const int n = n0 + wn * 64 + 2 * c_lane;
+    const bool n_ok = n < p.Cout;                                   // Cout is even (launcher)
+    float bv0 = 0.f, bv1 = 0.f;
+    if (p.bias != nullptr && n_ok) { bv0 = p.bias[n]; bv1 = p.bias[n + 1]; }
     u16* yb = static_cast<u16*>(p.y);
     if (!p.wide) {
 #pragma unroll
@@ -408,13 +312,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-#pragma unroll
-          for (int q = 0; q < NP; ++q)
-            if (n_ok[q] && m < p.M) {
-              float v0 = acc[i][2 * q][r] + bv0[q], v1 = acc[i][2 * q + 1][r] + bv1[q];
-              if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
-              *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + nw + 64 * q) = pack2(v0, v1);
-            }
+          if (n_ok && m < p.M) {
+            float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
+            if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
+            *reinterpret_cast<unsigned*>(yb + (long long)m * p.y_ld + n) = pack2(v0, v1);
+          }
         }
     }
     if (p.bn_partial != nullptr) {
@@ -434,20 +336,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
         if (lane < 32) {
-          const int col = wn * TN * 32 + (j >> 1) * 64 + 2 * c_lane + (j & 1);
+          const int col = wn * 64 + 2 * c_lane + j;
           s_stat[(wm * BN + col) * 2 + 0] = s;
           s_stat[(wm * BN + col) * 2 + 1] = q;
         }
       }
       __syncthreads();
-      for (int c = tid; c < BN; c += NT) {
+      if (tid < BN) {                                               // (BN <= 256 <= NT)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES_M; ++w) {
-          s += s_stat[(w * BN + c) * 2 + 0];
-          q += s_stat[(w * BN + c) * 2 + 1];
+          s += s_stat[(w * BN + tid) * 2 + 0];
+          q += s_stat[(w * BN + tid) * 2 + 1];
         }
-        const int nn = n0 + c;
+        const int nn = n0 + tid;
         if (nn < p.Cout) {
           float* dst = p.bn_partial + ((long long)mt * p.Cout + nn) * 2;
           dst[0] = s;
@@ -469,12 +371,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + r_lane;
-#pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            float v0 = acc[i][2 * q][r] + bv0[q], v1 = acc[i][2 * q + 1][r] + bv1[q];
-            if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
-            *reinterpret_cast<unsigned*>(s_tile + ml * BN + wn * TN * 32 + 64 * q + 2 * c_lane) = pack2(v0, v1);
-          }
+          float v0 = acc[i][0][r] + bv0, v1 = acc[i][1][r] + bv1;
+          if (p.slope != 1.f) { v0 = v0 > 0.f ? v0 : v0 * p.slope; v1 = v1 > 0.f ? v1 : v1 * p.slope; }
+          *reinterpret_cast<unsigned*>(s_tile + ml * BN + wn * 64 + 2 * c_lane) = pack2(v0, v1);
         }
       __syncthreads();
       constexpr int PPR = BN / 8;                                   // 16-byte pieces per tile row
@@ -508,14 +407,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool ILV = false, int NS = 2, bool PIPE = false>
+template <int BM, int BN, int BK, int WM, int WN, bool ILV = false, int NS = 2>
 int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
   size_t lds = NS * (size_t)(BM + BN) * BK * sizeof(u16);
   if (a.wide && lds < (size_t)BM * BN * sizeof(u16)) lds = (size_t)BM * BN * sizeof(u16);     // the epilogue's [BM][BN] tile
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.nk * BK), stream);
   if (nchw) {
-    if constexpr (BN >= 64 && WM * WN == 4 && BN / WN == 64 && !PIPE) {
+    if constexpr (BN >= 64 && WM * WN == 4) {
       auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true, ILV, NS>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
@@ -524,7 +423,7 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
       return FSD_ERR_UNSUPPORTED;
     }
   } else {
-    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS, PIPE>;
+    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     FSD_LAUNCH(k, grid, block, lds, stream, a);
@@ -559,11 +458,17 @@ inline bool narrow_tile(long long pixels, int cout) {
 //     192x256 -> 228 tiles = ONE round on 256 CUs (1006 vs 811), 192x128 -> 456 of 512 slots (957).
 //   * 192x128 (two workgroups per CU, wide stores) is the best or within 3 % of the best tile on every >= 128-channel
 //     layer with >= 43 k pixels (26x26: 829 vs 722, 52x52: 703 vs 626, 104x104: 500 vs 406).
+//   * round 5: ONE wave per SIMD on 128x128 / 96x128 wave tiles (256x256 and 192x256 on four waves; half the LDS bytes
+//     per MFMA of the 8-wave layouts), the loop software-pipelined by hand (inline-assembly fragment reads with counted
+//     lgkmcnt, next chunk's DMA spread over the k-steps, the barrier in front of the last step's MFMAs) LOSES 10-25 %:
+//     13x13 1024->1024 876 / 771 TFLOP/s against 975 for the 8-wave 192x256, 26x26 256->512 668 / 563 against 805; the
+//     same loop in the 256x256 weight gradient 640 against 679.  A DMA piece costs its wave 60-180 cycles of ISSUE
+//     (MI355X_MICROARCH.md) and a lone wave has nobody to fill the matrix pipe meanwhile: 16 pieces per 64-MFMA chunk
+//     ~ the 2400 cycles measured on top of the 2048 of the MFMAs.  Patch and numbers: tools/experiments_r05/pipe4_tiles.patch.
 struct TileH { int bm, bn, per_cu; };
-constexpr int kNumTiles = 9;
+constexpr int kNumTiles = 7;
 constexpr TileH kTiles[kNumTiles] = {{128, 128, 2}, {256, 256, 1}, {192, 256, 1}, {256, 128, 1},
-                                     {128, 64, 2}, {128, 32, 2}, {192, 128, 2},
-                                     {256, 256, 1}, {192, 256, 1}};                    // 7, 8: FOUR waves of 128x128 / 96x128
+                                     {128, 64, 2}, {128, 32, 2}, {192, 128, 2}};
 
 inline double fill_of(const TileH& t, long long pixels, int cout) {      // used slots / slots of the rounds it takes
   const long long tiles = ((pixels + t.bm - 1) / t.bm) * ((cout + t.bn - 1) / t.bn);
@@ -577,7 +482,7 @@ inline int pick_tile_h(long long pixels, int cin, int cout, int ksize, bool nchw
   if (!nchw && cout <= 32 && !has_partial && bk == 64 && !(n32_env && n32_env[0] == '0')) return 5;
   if (!nchw && narrow_tile(pixels, cout)) return 4;
   if (nchw || bk != 64 || cin % 64) return 0;
-  if (env && env[0] >= '0' && env[0] <= '8' && env[0] != '4' && env[0] != '5') {
+  if (env && env[0] >= '0' && env[0] <= '6' && env[0] != '4' && env[0] != '5') {
     const int t = env[0] - '0';
     return (cout % kTiles[t].bn == 0) ? t : 0;
   }
@@ -654,7 +559,7 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   const int tile = pick_tile_h(pixels, cin, cout, ksize, nchw, bn_partial != nullptr, bk);
   // 8-wave tiles: the 96-128 KB tile would cross LDS behind one barrier for all eight waves; measured -15 % on the 13x13
   // layers they are picked for (long K: the store tail is a small share there)
-  if (((tile >= 1 && tile <= 3) || tile >= 7) && !(wide_env && wide_env[0] == '1')) a.wide = 0;
+  if (tile >= 1 && tile <= 3 && !(wide_env && wide_env[0] == '1')) a.wide = 0;
   const char* ilv_env = FSD_TUNE("FSD_CONV_H_ILV");                 // tuning aid: 0 / 1 forces the DMA interleave off / on
   const bool ilv = ilv_env ? ilv_env[0] == '1' : (tile >= 1 && tile <= 3) || tile == 6;
   const char* ring_env = FSD_TUNE("FSD_CONV_H_RING");               // tuning aid: 1 = counted-vmcnt ring (measured slower)
@@ -695,12 +600,6 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
       if (!ilv) return launch_conv<192, 128, 64, 2, 2>(a, false, stream);
 #endif
       return launch_conv<192, 128, 64, 2, 2, true>(a, false, stream);
-    case 7:
-      a.n_tiles = cout / 256;
-      return launch_conv<256, 256, 64, 2, 2, true, 2, true>(a, false, stream);
-    case 8:
-      a.n_tiles = cout / 256;
-      return launch_conv<192, 256, 64, 2, 2, true, 2, true>(a, false, stream);
     default:
       a.n_tiles = (cout + 127) / 128;
 #ifdef FSD_EXPERIMENTS
@@ -1121,115 +1020,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_tr8_kernel(WgradHArgs
     }
   };
 
-  if constexpr (WM * WN == 4) {
-    // ONE wave per SIMD on 128 x 128 wave tiles (half the LDS bytes per MFMA of the 8-wave layout; see the PIPE loop of
-    // conv_bf16_dma_kernel): hand-pipelined -- the transpose reads of k-step s+1 are issued before the MFMAs of step s,
-    // the next chunk's DMA passes are spread over the steps before the last, the chunk's barrier stands in front of the
-    // last step's MFMAs and the first reads of the next chunk follow it.  Reads are inline assembly with counted waits
-    // (the compiler otherwise drains the DMA -- vmcnt(0) -- before the first transpose read that follows it).
-    static_assert(KC == 64 && TM == 4 && TN == 4 && PASSES == 4, "written for 64-pixel chunks, 4 x 4 accumulators");
-    constexpr int KS = KC / 16;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) u16*)smem_w8;
-    // element offset of this lane's first transpose read of a 32-channel block at k-step 0 (frag() above, krow = (G>>1)*8)
-    auto frag_off = [&](int ch0) -> unsigned {
-      const int row = (G >> 1) * 8 + (Lq >> 2);
-      const int ch = ch0 + 16 * (G & 1) + 4 * (Lq & 3);
-      const int pc = (ch >> 3) ^ GT::swz(row);
-      return (unsigned)(row * 128 + pc * 8 + (ch & 7));
-    };
-    unsigned a_addr[TM], b_addr[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int cb = (wm * TM + i) * 32;
-      a_addr[i] = lds0 + 2u * ((unsigned)((cb >> 7) * SUB) + frag_off(cb & 127));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cb = (wn * TN + j) * 32;
-      b_addr[j] = lds0 + 2u * ((unsigned)((SA + (cb >> 7)) * SUB) + frag_off(cb & 127));
-    }
-    bf16x4 fl[2][TM + TN], fh[2][TM + TN];
-    auto reads = [&](unsigned stage_bytes, int s, bf16x4* lo, bf16x4* hi) {
-#pragma unroll
-      for (int i = 0; i < TM + TN; ++i) {
-        const unsigned ad = (i < TM ? a_addr[i < TM ? i : 0] : b_addr[i < TM ? 0 : i - TM]) + stage_bytes;
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[i]) : "v"(ad), "n"(s * 16 * 128 * 2) : "memory");
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[i]) : "v"(ad), "n"(s * 16 * 128 * 2 + 4 * 128 * 2) : "memory");
-      }
-    };
-    auto landed = [&](bf16x4* lo, bf16x4* hi, auto pending) {
-      constexpr int N = decltype(pending)::value;
-      asm volatile("s_waitcnt lgkmcnt(%16)"
-                   : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
-                     "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7])
-                   : "n"(N) : "memory");
-    };
-    auto mfmas = [&](const bf16x4* lo, const bf16x4* hi) {
-      bf16x8 f[TM + TN];
-#pragma unroll
-      for (int i = 0; i < TM + TN; ++i) f[i] = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[TM + j], acc[i][j], 0, 0, 0);
-    };
-    // one staging pass (16 pixel rows of the four sub-tiles) of the NEXT chunk; past the last chunk `left` <= 0 and every
-    // piece fetches the zero page (branch-free)
-    auto stage_pass = [&](int j, u16* st) {
-      const bool row_ok = left > RPASS * j;
-      u16* dst = st + (RPASS * j + wave * GT::RPI) * 128;
-#pragma unroll
-      for (int t = 0; t < SA; ++t) {
-        dma16(row_ok && a_ok[t] ? a_ptr[t][j] : zero_src, dst + t * SUB);
-        a_ptr[t][j] += a_step;
-      }
-#pragma unroll
-      for (int t = 0; t < SB; ++t) {
-        const bool ok = row_ok && b_ok[t] && (unsigned)(b_y[j] + b_dy[t]) < (unsigned)p.H &&
-                        (unsigned)(b_x[j] + b_dx[t]) < (unsigned)p.W;
-        dma16(ok ? b_ptr[t][j] : zero_src, dst + (SA + t) * SUB);
-        b_ptr[t][j] += b_step;
-      }
-      int xx = b_x[j] + KC;
-      const int q = (int)(((float)xx + 0.5f) * inv_w);
-      xx -= q * p.W;
-      int yy = b_y[j] + q;
-      yy -= (int)(((float)yy + 0.5f) * inv_h) * p.H;
-      b_x[j] = xx;
-      b_y[j] = yy;
-    };
-    if (nk > 0) {
-      stage(smem_w8);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      reads(0u, 0, fl[0], fh[0]);
-      int cur = 0;
-      for (int kc = 0; kc < nk; ++kc) {
-        u16* st_next = smem_w8 + (cur ^ 1) * STAGE;
-        const unsigned cur_b = (unsigned)(cur * STAGE * 2), nxt_b = (unsigned)((cur ^ 1) * STAGE * 2);
-#pragma unroll
-        for (int s = 0; s + 1 < KS; ++s) {
-          reads(cur_b, s + 1, fl[(s + 1) & 1], fh[(s + 1) & 1]);
-          if (s == 0) { stage_pass(0, st_next); stage_pass(1, st_next); }
-          else stage_pass(s + 1, st_next);
-          landed(fl[s & 1], fh[s & 1], std::integral_constant<int, 15>());   // 16 newer reads in flight; the counter holds 15
-          __builtin_amdgcn_sched_barrier(0);
-          mfmas(fl[s & 1], fh[s & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        left -= KC;
-        landed(fl[(KS - 1) & 1], fh[(KS - 1) & 1], std::integral_constant<int, 0>());
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        reads(nxt_b, 0, fl[KS & 1], fh[KS & 1]);          // (past the last chunk: zeros just staged, never used)
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(fl[(KS - 1) & 1], fh[(KS - 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        cur ^= 1;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  } else if (nk > 0) {
+  if (nk > 0) {
     stage(smem_w8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1400,18 +1191,10 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   if (bm == 256 && bn == 256) {
     const size_t lds = 2 * (size_t)64 * (256 + 256) * sizeof(u16);
     fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.taps * a.Cin), stream);
-    const char* w4_env = getenv("FSD_WGRAD_H_W4");                  // 0: the 8-wave layout (2 x 4 waves of 128 x 64)
-    if (w4_env && w4_env[0] == '0') {
-      auto k = wgrad_bf16_tr8_kernel<64>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(512), lds, stream, a);
-    } else {
-      auto k = wgrad_bf16_tr8_kernel<64, 2, 2, 2, 2>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(256), lds, stream, a);
-    }
+    auto k = wgrad_bf16_tr8_kernel<64>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    FSD_LAUNCH(k, dim3(a.m_tiles * a.n_tiles, splits), dim3(512), lds, stream, a);
     rc = (int)hipGetLastError();
   }
   else if (bn == 32) rc = launch_wgrad_h<128, 32, 4, 1>(a, splits, stream);

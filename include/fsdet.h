@@ -382,9 +382,9 @@ int fsd_conv_row_tiles_h(long long pixels);          /* upper bound of the rows 
 /* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick) */
 int fsd_conv2d_h_partial_rows(long long pixels, int cin, int cout, int ksize);
 /* which tile fsd_conv2d_fwd_h will run this layer on: 0 = 128x128 (4 waves, two workgroups per CU), 1 = 256x256,
- * 2 = 192x256, 3 = 256x128 (8 waves, one workgroup per CU), 4 = 128x64, 5 = 128x32, 6 = 192x128 (4 waves); 7 = 256x256,
- * 8 = 192x256 on FOUR waves of 128x128 / 96x128 (one wave per SIMD, hand-pipelined loop).  Tests assert through it that
- * the timed shapes really take the tiles they are meant to; FSD_CONV_H_TILE=0..8 forces one. */
+ * 2 = 192x256, 3 = 256x128 (8 waves, one workgroup per CU), 4 = 128x64, 5 = 128x32, 6 = 192x128 (4 waves, two workgroups
+ * per CU).  Tests assert through it that the timed shapes really take the tiles they are meant to; FSD_CONV_H_TILE=0..6
+ * forces one. */
 int fsd_conv2d_h_plan(long long pixels, int cin, int cout, int ksize, int out_nchw_f32, int has_partial);
 /* bf16 activations x packed bf16 weights (fsd_pack_conv_weight_bf16) -> bf16 NHWC y (or float NCHW when out_nchw_f32),
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, operands staged global -> LDS by DMA.  cin % 32 == 0, cout even. */
