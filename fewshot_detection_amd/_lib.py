@@ -87,7 +87,7 @@ PROTOTYPES = {
     "fsd_head_unfold_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
     "fsd_conv_row_tiles_h": (_i, [_ll]),
-    "fsd_conv2d_h_partial_rows": (_i, [_ll, _i, _i, _i]),
+    "fsd_conv2d_h_partial_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "fsd_conv2d_h_plan": (_i, [_ll, _i, _i, _i, _i, _i]),
     "fsd_conv2d_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_h_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -515,7 +515,9 @@ extern "C" int fsd_conv2d_h_plan(long long pixels, int cin, int cout, int ksize,
   return pick_tile_h(pixels, cin, cout, ksize, out_nchw_f32 != 0, has_partial != 0, bk_of(cin, ksize));
 }
 
-extern "C" int fsd_conv2d_h_partial_rows(long long pixels, int cin, int cout, int ksize) {
+extern "C" int fsd_conv2d_h_partial_rows(int batch, int height, int width, int cin, int cout, int ksize) {
+  if (fsd_conv::halo_h_ok(height, width, cin, cout, ksize)) return fsd_conv::halo_h_rows(batch, height, width);
+  const long long pixels = (long long)batch * height * width;
   const int tile = pick_tile_h(pixels, cin, cout, ksize, false, true, bk_of(cin, ksize));
   const int bm = tile_bm(tile);
   return (int)((pixels + bm - 1) / bm);
@@ -541,6 +543,12 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   if ((reinterpret_cast<uintptr_t>(x_bf16) & 15) || (reinterpret_cast<uintptr_t>(w_packed_bf16) & 15)) return FSD_ERR_ARG;
   if (!out_nchw_f32 && (reinterpret_cast<uintptr_t>(y) & 3)) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
+  if (!out_nchw_f32 && fsd_conv::halo_h_ok(height, width, cin, cout, ksize)) {
+    const int rc = fsd_conv::conv3x3_halo_h(x_bf16, x_ld, w_packed_bf16, round_up(ksize * ksize * cin, 64), bias, y, y_ld, bn_partial,
+                                            batch, height, width, cin, cout, slope, stream);
+    if (rc != FSD_ERR_UNSUPPORTED) return rc;       // (odd strides / alignments stay on the implicit-GEMM kernel)
+    if (bn_partial) return rc;                      // ... but the caller sized bn_partial for the halo kernel
+  }
   if (pixels > 0x7fffffffLL - 512 || (pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
   ConvHArgs a;
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;

@@ -338,7 +338,7 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=
             raise ValueError("bf16 convolution needs a bf16 output view")
         y_ptr, y_ld = y.ptr, y.ld
     if bn_partial:
-        partial = torch.empty((L.fsd_conv2d_h_partial_rows(xv.pixels, xv.C, cout, ksize), cout, 2), dtype=torch.float32,
+        partial = torch.empty((L.fsd_conv2d_h_partial_rows(xv.B, xv.H, xv.W, xv.C, cout, ksize), cout, 2), dtype=torch.float32,
                               device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

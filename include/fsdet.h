@@ -379,8 +379,9 @@ int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, flo
  * arithmetic, the BatchNorm partial sums and every parameter / parameter gradient stay float.  Arguments, shapes,
  * return codes and the kernels behind them are otherwise identical (one kernel template, two instantiations). */
 int fsd_conv_row_tiles_h(long long pixels);          /* upper bound of the rows of any bn_partial array (128-row tiles) */
-/* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick) */
-int fsd_conv2d_h_partial_rows(long long pixels, int cin, int cout, int ksize);
+/* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick; one
+ * per workgroup of the persistent halo kernel of the 32 -> 64 / 64 -> 32 3x3 layers, conv_halo_h.hip) */
+int fsd_conv2d_h_partial_rows(int batch, int height, int width, int cin, int cout, int ksize);
 /* which tile fsd_conv2d_fwd_h will run this layer on: 0 = 128x128 (4 waves, two workgroups per CU), 1 = 256x256,
  * 2 = 192x256, 3 = 256x128 (8 waves, one workgroup per CU), 4 = 128x64, 5 = 128x32, 6 = 192x128 (4 waves, two workgroups
  * per CU).  Tests assert through it that the timed shapes really take the tiles they are meant to; FSD_CONV_H_TILE=0..6

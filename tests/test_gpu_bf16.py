@@ -96,7 +96,7 @@ def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypa
     monkeypatch.setenv("FSD_CONV_H_TILE", str(tile))
     assert lib().fsd_conv2d_h_plan(B * H * W, cin, cout, k, 0, 1) == tile
     bm = {1: 256, 2: 192, 3: 256, 6: 192}[tile]
-    assert lib().fsd_conv2d_h_partial_rows(B * H * W, cin, cout, k) == (B * H * W + bm - 1) // bm
+    assert lib().fsd_conv2d_h_partial_rows(B, H, W, cin, cout, k) == (B * H * W + bm - 1) // bm
     g = torch.Generator().manual_seed(tile * 100 + cin)
     x = _bf(torch.randn(B, cin, H, W, generator=g))
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -123,6 +123,52 @@ def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypa
     dx, _ = ops.conv2d(_view_bf16(gy, dev), ops.pack_weight(w.to(dev), 1, "bf16"), cin, k)
     e3 = (_nchw(dx).double() - xg.grad).abs()
     assert float((e3 - xg.grad.abs() * 2.0 ** -8).max()) < 1e-3 * max(1.0, float(xg.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [
+    (3, 24, 48, 32, 64),        # 3 x 3 blocks per image: border blocks on every side and an interior one
+    (2, 8, 16, 32, 64),         # one block per image (every halo pixel outside the image)
+    (10, 64, 128, 32, 64),      # 640 blocks on 512 persistent workgroups: runs of one and two blocks
+    (3, 24, 48, 64, 32),        # the data-gradient form: 128-byte patch rows, lane-pair stores
+    (10, 64, 128, 64, 32),
+])
+def test_conv_bf16_halo_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin, cout):
+    """conv3x3_halo_h_kernel (persistent workgroups, weights in registers, one DMA-staged halo patch per 8 x 16 block): forward
+    with BatchNorm partial sums (one row per workgroup), with bias + leaky, and through the data gradient of the twin shape."""
+    from fewshot_detection_amd import ops
+    from fewshot_detection_amd._lib import lib
+    blocks = B * (H // 8) * (W // 16)
+    assert lib().fsd_conv2d_h_partial_rows(B, H, W, cin, cout, 3) == min(blocks, 512)
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = _bf(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    ref = F.conv2d(x.double(), _bf(w).double(), None, 1, 1)
+    yv, part = ops.conv2d(_view_bf16(x, dev), ops.pack_weight(w.to(dev), 0, "bf16"), cout, 3, bn_partial=True)
+    assert part.shape[0] == min(blocks, 512)
+    err = (_nchw(yv).double() - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) < 1e-3, float(err.max())
+    assert float(err.mean()) < 2.0 ** -9 * float(ref.abs().mean()) * 1.2
+    p = part.double().sum(0).cpu()
+    flat = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+    assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=2e-4, atol=1e-2)
+    b = torch.randn(cout, generator=g)
+    y2, _ = ops.conv2d(_view_bf16(x, dev), ops.pack_weight(w.to(dev), 0, "bf16"), cout, 3, bias=b.to(dev), slope=0.1)
+    ref2 = F.leaky_relu(ref + b.double().view(1, -1, 1, 1), 0.1)
+    e2 = (_nchw(y2).double() - ref2).abs()
+    assert float((e2 - ref2.abs() * 2.0 ** -8).max()) < 1e-3
+    # the data gradient of this layer is the twin shape (cout -> cin) on mode-1 weights
+    gy = _bf(torch.randn(B, cout, H, W, generator=g))
+    xg = x.double().requires_grad_(True)
+    F.conv2d(xg, _bf(w).double(), None, 1, 1).backward(gy.double())
+    dx, _ = ops.conv2d(_view_bf16(gy, dev), ops.pack_weight(w.to(dev), 1, "bf16"), cin, 3)
+    e3 = (_nchw(dx).double() - xg.grad).abs()
+    assert float((e3 - xg.grad.abs() * 2.0 ** -8).max()) < 1e-3 * max(1.0, float(xg.grad.abs().max()))
+    # an output view with a wider pixel stride (a slice of a route buffer)
+    wide = ops.View(torch.zeros(B * H * W, cout + 16, device=dev, dtype=BF), B, H, W, cout, c0=8)
+    y3, _ = ops.conv2d(_view_bf16(x, dev), ops.pack_weight(w.to(dev), 0, "bf16"), cout, 3, out=wide)
+    assert torch.equal(_nchw(y3), _nchw(yv))
+    assert float(wide.t[:, :8].abs().max()) == 0.0 and float(wide.t[:, 8 + cout:].abs().max()) == 0.0
 
 
 def test_timed_bf16_shapes_take_the_large_tiles(dev):
