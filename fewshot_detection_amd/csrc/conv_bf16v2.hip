@@ -516,7 +516,7 @@ extern "C" int fsd_conv2d_h_plan(long long pixels, int cin, int cout, int ksize,
 }
 
 extern "C" int fsd_conv2d_h_partial_rows(int batch, int height, int width, int cin, int cout, int ksize) {
-  if (fsd_conv::halo_h_ok(height, width, cin, cout, ksize)) return fsd_conv::halo_h_rows(batch, height, width);
+  if (fsd_conv::halo_h_ok(height, width, cin, cout, ksize)) return fsd_conv::halo_h_rows(batch, height, width, cin, cout);
   const long long pixels = (long long)batch * height * width;
   const int tile = pick_tile_h(pixels, cin, cout, ksize, false, true, bk_of(cin, ksize));
   const int bm = tile_bm(tile);
