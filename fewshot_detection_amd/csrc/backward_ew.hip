@@ -157,17 +157,31 @@ __global__ __launch_bounds__(256) void act_stats_kernel(ActBwdArgsT<float> p) {
   if (g_ok) {
     long long left = p.pixels - p0;
     const int n = (int)(left < p.ppb ? left : p.ppb);
-#pragma unroll 4
-    for (int it = pl; it < n; it += NPL) {
-      const long long pix = p0 + it;
-      const f32x4 yv = ld4(p.y + pix * p.y_ld + g * 4);
-      const f32x4 gin = ld4(p.dz + pix * p.dz_ld + g * 4);
+    // UB pixels of a lane in flight at a time (`#pragma unroll 4` left the loads in their guarded bodies: four dependent
+    // round trips where one does).  Same pixels in the same order per lane: bit-identical sums.
+    constexpr int UB = 8;
+    const float* yp = p.y + p0 * p.y_ld + g * 4;
+    const float* zp = p.dz + p0 * p.dz_ld + g * 4;
+    for (int it0 = pl; it0 < n; it0 += NPL * UB) {
+      f32x4 yr[UB], zr[UB];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
-        const float d = tv > 0.f ? gin[k] : gin[k] * p.slope;
-        s1[k] += d;
-        s2[k] += d * ((yv[k] - mu[k]) * is[k]);
+      for (int u = 0; u < UB; ++u) {
+        const int it = it0 + u * NPL;
+        const int itc = it < n ? it : it0;                                // clamped: always a mapped pixel of this lane
+        yr[u] = ld4(yp + (long long)itc * p.y_ld);
+        zr[u] = ld4(zp + (long long)itc * p.dz_ld);
+      }
+      asm volatile("" ::: "memory");        // the loads stay up here
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (it0 + u * NPL >= n) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float tv = __builtin_fmaf(yr[u][k], sc[k], sh[k]);
+          const float d = tv > 0.f ? zr[u][k] : zr[u][k] * p.slope;
+          s1[k] += d;
+          s2[k] += d * ((yr[u][k] - mu[k]) * is[k]);
+        }
       }
     }
   }
@@ -200,31 +214,59 @@ __global__ __launch_bounds__(256) void act_stats8_kernel(ActBwdArgsT<bf16_t> p) 
   const int cg = p.C >> 3;
   const bool g_ok = g < cg;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+  {
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[8];                           // two 16-byte loads per vector (element loads under 32 separate branches before)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    sc[k] = (g_ok && p.scale) ? p.scale[g * 8 + k] : 1.f;
-    sh[k] = (g_ok && p.shift) ? p.shift[g * 8 + k] : 0.f;
-    mu[k] = (g_ok && p.mean) ? p.mean[g * 8 + k] : 0.f;
-    is[k] = (g_ok && p.invstd) ? p.invstd[g * 8 + k] : 1.f;
-    s1[k] = 0.f;
-    s2[k] = 0.f;
+    for (int q = 0; q < 2; ++q) {
+      v[0 + q] = (g_ok && p.scale) ? ld4(p.scale + g * 8 + 4 * q) : one;
+      v[2 + q] = (g_ok && p.shift) ? ld4(p.shift + g * 8 + 4 * q) : zero;
+      v[4 + q] = (g_ok && p.mean) ? ld4(p.mean + g * 8 + 4 * q) : zero;
+      v[6 + q] = (g_ok && p.invstd) ? ld4(p.invstd + g * 8 + 4 * q) : one;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sc[k] = v[0 + (k >> 2)][k & 3];
+      sh[k] = v[2 + (k >> 2)][k & 3];
+      mu[k] = v[4 + (k >> 2)][k & 3];
+      is[k] = v[6 + (k >> 2)][k & 3];
+      s1[k] = 0.f;
+      s2[k] = 0.f;
+    }
   }
   const long long p0 = (long long)blockIdx.x * p.ppb;
   if (g_ok) {
     long long left = p.pixels - p0;
     const int n = (int)(left < p.ppb ? left : p.ppb);
-#pragma unroll 2
-    for (int it = pl; it < n; it += NPL) {
-      const long long pix = p0 + it;
-      const fsd_ew::f32x8 yv = fsd_ew::ld8(p.y + pix * p.y_ld + g * 8);
-      const fsd_ew::f32x8 gin = fsd_ew::ld8(p.dz + pix * p.dz_ld + g * 8);
+    // UB pixels of a lane in flight at a time, as raw 16-byte words (the 13x13 / 26x26 layers run ~1.3 waves per SIMD with 16
+    // pixels per lane: two pixels at a time were eight dependent round trips to HBM -- 25 us for 44 MB).  Same pixels in
+    // the same order per lane: the sums are bit-identical to the two-at-a-time loop.
+    constexpr int UB = 8;
+    const bf16_t* yp = p.y + p0 * p.y_ld + g * 8;
+    const bf16_t* zp = p.dz + p0 * p.dz_ld + g * 8;
+    for (int it0 = pl; it0 < n; it0 += NPL * UB) {
+      uint4 yr[UB], zr[UB];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float yk = k < 4 ? yv.lo[k & 3] : yv.hi[k & 3], gk = k < 4 ? gin.lo[k & 3] : gin.hi[k & 3];
-        const float tv = __builtin_fmaf(yk, sc[k], sh[k]);
-        const float d = tv > 0.f ? gk : gk * p.slope;
-        s1[k] += d;
-        s2[k] += d * ((yk - mu[k]) * is[k]);
+      for (int u = 0; u < UB; ++u) {
+        const int it = it0 + u * NPL;
+        const int itc = it < n ? it : it0;                              // clamped: always a mapped pixel of this lane
+        yr[u] = *reinterpret_cast<const uint4*>(yp + (long long)itc * p.y_ld);
+        zr[u] = *reinterpret_cast<const uint4*>(zp + (long long)itc * p.dz_ld);
+      }
+      asm volatile("" ::: "memory");      // the loads stay up here (the compiler otherwise sinks each pair into its guarded use)
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (it0 + u * NPL >= n) break;
+        const unsigned yw[4] = {yr[u].x, yr[u].y, yr[u].z, yr[u].w}, zw[4] = {zr[u].x, zr[u].y, zr[u].z, zr[u].w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float yk = __uint_as_float((k & 1) ? (yw[k >> 1] & 0xffff0000u) : (yw[k >> 1] << 16));
+          const float gk = __uint_as_float((k & 1) ? (zw[k >> 1] & 0xffff0000u) : (zw[k >> 1] << 16));
+          const float tv = __builtin_fmaf(yk, sc[k], sh[k]);
+          const float d = tv > 0.f ? gk : gk * p.slope;
+          s1[k] += d;
+          s2[k] += d * ((yk - mu[k]) * is[k]);
+        }
       }
     }
   }
@@ -435,32 +477,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              float* __restrict__ dy, int H, int W, int OH, int OW, int C,
                                                              long long total) {
+  // POOL 0: a thread owns 4 channels of UC consecutive pixels -- the seven per-channel vectors (112 bytes, more than a
+  // pixel's own data) are fetched once per thread, and the loads of all its pixels are issued before the first use
+  // (bn_bwd_apply_g8_kernel: 27 -> 20 us per launch).  `total` = units x channel groups; per-element arithmetic unchanged.
+  constexpr int UC = POOL == 0 ? 4 : 1;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
   const int cg = C >> 2;
+  const long long units = total / cg;
   const int g = (int)(idx % cg);
-  const long long unit = idx / cg;                       // pixel (POOL 0) or cell (POOL 1)
+  const long long unit = idx / cg * UC;                  // first pixel (POOL 0) or the cell (POOL 1)
+  if (unit >= units) return;
   const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 sc = scale ? ld4(scale + g * 4) : one, sh = shift ? ld4(shift + g * 4) : zero;
   const f32x4 c1 = ld4(coef + g * 4), c2 = ld4(coef + C + g * 4), c3 = ld4(coef + 2 * C + g * 4);
   const f32x4 mu = ld4(mean + g * 4), is = ld4(invstd + g * 4);
   if constexpr (POOL == 0) {
-    const long long pix = unit;
-    const f32x4 yv = ld4(y + pix * y_ld + g * 4);
-    f32x4 gin = ld4(dz + pix * dz_ld + g * 4);
-    if (dz_full) {
-      const f32x4 gf = ld4(dz_full + pix * dzf_ld + g * 4);
+    f32x4 yv[UC], gin[UC], gf[UC];
+    bool ok[UC];
+    long long pix[UC];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gin[k] += gf[k];
+    for (int u = 0; u < UC; ++u) {
+      ok[u] = unit + u < units;
+      pix[u] = ok[u] ? unit + u : unit;
+      yv[u] = ld4(y + pix[u] * y_ld + g * 4);
+      gin[u] = ld4(dz + pix[u] * dz_ld + g * 4);
+      gf[u] = dz_full ? ld4(dz_full + pix[u] * dzf_ld + g * 4) : zero;
     }
-    f32x4 o;
+    asm volatile("" ::: "memory");          // the loads stay up here
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
-      const float d = tv > 0.f ? gin[k] : gin[k] * slope;
-      o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
+    for (int u = 0; u < UC; ++u) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gk = gin[u][k];
+        if (dz_full) gk += gf[u][k];
+        const float tv = __builtin_fmaf(yv[u][k], sc[k], sh[k]);
+        const float d = tv > 0.f ? gk : gk * slope;
+        o[k] = c1[k] * (d - c2[k] - (yv[u][k] - mu[k]) * is[k] * c3[k]);
+      }
+      if (ok[u]) st4<float>(dy + pix[u] * C + g * 4, o);
     }
-    st4<float>(dy + pix * C + g * 4, o);
   } else {
     const int CH = (H + 1) >> 1, CW = (W + 1) >> 1;
     const int cx = (int)(unit % CW);
@@ -531,12 +587,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
                                                               float slope, const float* __restrict__ coef,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               bf16_t* __restrict__ dy, int H, int W, int OH, int OW, int C,
-                                                              long long total) {
+                                                              long long units) {
+  // A thread owns 8 channels of UC consecutive units (pixels / 2x2 cells): the seven per-channel vectors (224 bytes, more
+  // than a unit's own data) are fetched once per thread instead of once per unit, and the loads of all its units are issued
+  // before the first use.  Per-element arithmetic as before (bit-identical results).
+  constexpr int UC = POOL == 0 ? 4 : 1;      // (pooled cells: 18 loads each; two per thread measured 58 -> 65 us)
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
   const int cg = C >> 3;
   const int g = (int)(idx % cg);
-  const long long unit = idx / cg;
+  const long long unit0 = idx / cg * UC;
+  if (unit0 >= units) return;
   float sc[8], sh[8], c1[8], c2[8], c3[8], mu[8], is[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
@@ -545,24 +605,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
   load8f(coef + g * 8, c1); load8f(coef + C + g * 8, c2); load8f(coef + 2 * C + g * 8, c3);
   load8f(mean + g * 8, mu); load8f(invstd + g * 8, is);
   if constexpr (POOL == 0) {
-    const long long pix = unit;
-    float yv[8], gin[8], o[8];
-    load8(y + pix * y_ld + g * 8, yv);
-    load8(dz + pix * dz_ld + g * 8, gin);
-    if (dz_full) {
-      float gf[8];
-      load8(dz_full + pix * dzf_ld + g * 8, gf);
+    float yv[UC][8], gin[UC][8], gf[UC][8];
+    bool ok[UC];
+    long long pix[UC];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) gin[k] += gf[k];
+    for (int u = 0; u < UC; ++u) {
+      ok[u] = unit0 + u < units;
+      pix[u] = ok[u] ? unit0 + u : unit0;
+      load8(y + pix[u] * y_ld + g * 8, yv[u]);
+      load8(dz + pix[u] * dz_ld + g * 8, gin[u]);
+      if (dz_full) load8(dz_full + pix[u] * dzf_ld + g * 8, gf[u]);
     }
+    asm volatile("" ::: "memory");          // the loads stay up here
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float tv = __builtin_fmaf(yv[k], sc[k], sh[k]);
-      const float d = tv > 0.f ? gin[k] : gin[k] * slope;
-      o[k] = c1[k] * (d - c2[k] - (yv[k] - mu[k]) * is[k] * c3[k]);
+    for (int u = 0; u < UC; ++u) {
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float gk = gin[u][k];
+        if (dz_full) gk += gf[u][k];
+        const float tv = __builtin_fmaf(yv[u][k], sc[k], sh[k]);
+        const float d = tv > 0.f ? gk : gk * slope;
+        o[k] = c1[k] * (d - c2[k] - (yv[u][k] - mu[k]) * is[k] * c3[k]);
+      }
+      if (ok[u]) store8(dy + pix[u] * C + g * 8, o);
     }
-    store8(dy + pix * C + g * 8, o);
   } else {
+    const long long unit = unit0;
     const int CH = (H + 1) >> 1, CW = (W + 1) >> 1;
     const int cx = (int)(unit % CW);
     const long long t = unit / CW;
@@ -958,8 +1027,8 @@ extern "C" int fsd_bn_bwd_apply_g(const float* dz, long long dz_ld, const float*
   // algorithmic bytes: read dz (+ dz_full) and y, write dy
   fsd_prof::Scope prof(fsd_prof::kActBwd, 4.0 * channels * ((double)batch * OH * OW + (dz_full ? 3.0 : 2.0) * pixels), stream);
   if (pool == 0) {
-    const long long total = pixels * (channels / 4);
-    FSD_LAUNCH(bn_bwd_apply_g_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
+    const long long total = pixels * (channels / 4);                      // 4 pixels per thread (UC in the kernel)
+    FSD_LAUNCH(bn_bwd_apply_g_kernel<0>, dim3(blocks_for((pixels + 3) / 4 * (channels / 4), 256)), dim3(256), 0, stream, dz, dz_ld, dz_full,
                        dz_full_ld, y, y_ld, scale, shift, slope, coef, mean, invstd, dy, height, width, OH, OW, channels, total);
   } else {
     const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 4);
@@ -987,14 +1056,15 @@ extern "C" int fsd_bn_bwd_apply_g_h(const void* dz, long long dz_ld, const void*
   const bf16_t* dfh = static_cast<const bf16_t*>(dz_full);
   const bf16_t* yh = static_cast<const bf16_t*>(y);
   bf16_t* dyh = static_cast<bf16_t*>(dy);
-  if (pool == 0) {
-    const long long total = pixels * (channels / 8);
-    FSD_LAUNCH(bn_bwd_apply_g8_kernel<0>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
-                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
+  if (pool == 0) {      // a thread = 8 channels of 4 consecutive pixels / of one cell (UC in the kernel)
+    const long long threads = (pixels + 3) / 4 * (channels / 8);
+    FSD_LAUNCH(bn_bwd_apply_g8_kernel<0>, dim3(blocks_for(threads, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, pixels);
   } else {
-    const long long total = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2) * (channels / 8);
-    FSD_LAUNCH(bn_bwd_apply_g8_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
-                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, total);
+    const long long cells = (long long)batch * ((height + 1) / 2) * ((width + 1) / 2);
+    const long long threads = cells * (channels / 8);
+    FSD_LAUNCH(bn_bwd_apply_g8_kernel<1>, dim3(blocks_for(threads, 256)), dim3(256), 0, stream, dzh, dz_ld, dfh, dz_full_ld,
+                       yh, y_ld, scale, shift, slope, coef, mean, invstd, dyh, height, width, OH, OW, channels, cells);
   }
   return (int)hipGetLastError();
 }
