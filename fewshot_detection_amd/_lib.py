@@ -27,7 +27,7 @@ PROTOTYPES = {
     "fsd_region_nms": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "fsd_packed_weight_elems": (_sz, [_i, _i, _i]),
     "fsd_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "fsd_conv_row_tiles": (_i, [_ll, _i, _i, _i]),
+    "fsd_conv_row_tiles": (_i, [_i, _i, _i, _i, _i, _i]),
     "fsd_conv2d_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv3x3_c4_partial_rows": (_i, [_i, _i, _i]),
     "fsd_conv3x3_c4_fwd": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _p]),

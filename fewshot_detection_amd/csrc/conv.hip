@@ -1034,7 +1034,11 @@ extern "C" int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   return (int)hipGetLastError();
 }
 
-extern "C" int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize) {
+extern "C" int fsd_conv_row_tiles(int batch, int height, int width, int cout, int cin, int ksize) {
+  // ONE plan for this query and for the launch in fsd_conv2d_fwd_ex: halo kernel (a row per 8 x 16 block), 8-wave 1x1 tiles,
+  // or the implicit-GEMM row tiles
+  if (fsd_conv::halo_ok(height, width, cin, cout, ksize, false)) return batch * (height / 8) * (width / 16);
+  const long long pixels = (long long)batch * height * width;
   if (split8_1x1(pixels, cin, cout, ksize, false)) return (int)(pixels / 256 + (pixels % 256 + 63) / 64);
   const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize, cout));
   return r.main_m_tiles + r.tail_m_tiles;
@@ -1082,15 +1086,18 @@ extern "C" int fsd_conv2d_fwd_ex(const float* x, long long x_ld, const float* w_
   a.nk = a.Kpad / kBK;
   a.cpt = (cin % kBK == 0) ? cin / kBK : 0;
   const bool nchw = out_nchw != 0;
-  if (!in_scale && fsd_conv::halo_ok(height, width, cin, cout, ksize, nchw) && (y_ld & 3) == 0 &&
-      (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-      (!bn_partial || fsd_conv_row_tiles(pixels, cout, cin, ksize) == (int)((pixels + 127) / 128)))
-    // narrow 3x3 layers (32 / 64 channels): halo patch split once per workgroup (conv_halo.hip); one BatchNorm partial row
-    // per 128 pixels -- the row count fsd_conv_row_tiles reports for these channel counts (128-row tiles), which is what the
-    // caller sized bn_partial by: if a forced tiling (FSD_CONV_TILE) makes the two disagree, the layer keeps the GEMM tiles,
-    // every row of whose count is written
-    return fsd_conv::conv3x3_halo(x, x_ld, w_packed, a.Kpad, bias, y, y_ld, bn_partial, batch, height, width, cin, cout, slope,
-                                  stream);
+  if (fsd_conv::halo_ok(height, width, cin, cout, ksize, nchw)) {
+    // narrow 3x3 layers (32 / 64 channels): halo patch split once per workgroup (conv_halo.hip); one BatchNorm
+    // partial row per 8 x 16 block -- the count fsd_conv_row_tiles reports for these shapes (the same halo_ok decides there).
+    // The implicit-GEMM tiles behind it write the same number of rows for these channel counts unless a tiling is forced:
+    // then (or for an unaligned y / an activation on load) a BatchNorm launch is refused rather than left with unwritten rows.
+    const bool aligned = (y_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (!in_scale && aligned)
+      return fsd_conv::conv3x3_halo(x, x_ld, w_packed, a.Kpad, bias, y, y_ld, bn_partial, batch, height, width, cin, cout,
+                                    slope, stream);
+    const RowPlan r = plan_rows(pixels, cout, tile_cfg(cin, ksize, cout));
+    if (bn_partial && r.main_m_tiles + r.tail_m_tiles != batch * (height / 8) * (width / 16)) return FSD_ERR_UNSUPPORTED;
+  }
   if (split8_1x1(pixels, cin, cout, ksize, nchw)) {
     // 1x1 convolution = a plain GEMM over the pixel rows: the 8-wave 256x128 split kernel on the WHOLE 256-row tiles (its
     // clamped rows past M would enter the BatchNorm sums), 64x64 tiles for the remaining < 256 rows

@@ -247,6 +247,10 @@ def wino_tile(cin, cout, ksize, H, W):
     if not (WINOGRAD and ksize == 3 and cin % 32 == 0 and cout % 4 == 0):
         return 0
     lo = min(cin, cout)
+    # (round 5: the 64 <-> 128 layers at 104x104 on a halo-staged DIRECT kernel instead -- their unfused F(4x4) pipeline moves
+    # 5.6x the layer's bytes, profiles/r05_traffic_ledger.csv -- measured: 0.49 ms forward + 0.43 ms data gradient per layer
+    # and a step 0.7 ms slower (the six-term direct arithmetic costs what the transforms' bytes cost);
+    # tools/experiments_r05/halo_direct_64_128_f32.patch)
     m2 = 16 * ((H + 1) // 2) * ((W + 1) // 2)
     m4 = 36 * ((H + 3) // 4) * ((W + 3) // 4)
     if WINOGRAD4 and lo >= WINO4_MIN_CH and m4 <= 0.85 * m2:
@@ -297,7 +301,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     if w_packed.dtype != torch.float32:
         raise ValueError("fp32 activations need fp32-packed weights (bf16 weights belong to bf16 activations)")
     if bn_partial:
-        tiles = lib().fsd_conv_row_tiles(xv.pixels, cout, xv.C, ksize)
+        tiles = lib().fsd_conv_row_tiles(xv.B, xv.H, xv.W, cout, xv.C, ksize)
         partial = torch.empty((tiles, cout, 2), dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

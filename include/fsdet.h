@@ -112,9 +112,10 @@ size_t fsd_packed_weight_elems(int rows, int red, int ksize);
 int fsd_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ksize, int mode,
                          hipStream_t stream);
 
-/* Number of row tiles the conv kernel will use for this problem (= first dimension of the BN
- * partial-sum buffer). */
-int fsd_conv_row_tiles(long long pixels, int cout, int cin, int ksize);
+/* Number of BatchNorm partial rows fsd_conv2d_fwd* writes for this problem (= first dimension of the BN partial-sum
+ * buffer): row tiles of the implicit-GEMM kernel, or one row per 8 x 16 pixel block of the halo-staged kernel of the
+ * narrow 3x3 layers (which depends on the image shape, not only on the pixel count). */
+int fsd_conv_row_tiles(int batch, int height, int width, int cout, int cin, int ksize);
 
 /* y[p, co] = sum_{tap, ci} x[p + tap, ci] * w[co, tap, ci] (+ bias[co]);  stride 1,
  * pad = (ksize-1)/2, ksize in {1, 3}.  x: NHWC, cin % 4 == 0, pixel stride x_ld (floats).

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in experimental:                          # all of them or none (one build flag)
         assert hasattr(lib, name) == ops.experiments_built(), name
     assert lib.fsd_version().startswith(b"fsdet-hip")
-    assert lib.fsd_conv_row_tiles(1000, 256, 64, 3) == 16 and lib.fsd_packed_weight_elems(30, 1024, 1) == 128 * 1024
+    assert lib.fsd_conv_row_tiles(1, 25, 40, 256, 64, 3) == 16 and lib.fsd_packed_weight_elems(30, 1024, 1) == 128 * 1024
 
 
 def test_no_cpu_fallback():
