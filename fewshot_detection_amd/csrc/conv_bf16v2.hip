@@ -1155,6 +1155,10 @@ inline int wgrad_h_kc(long long pixels) {
 }  // namespace
 
 extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int width, int cin, int cout, int ksize) {
+  if (fsd_conv::wgrad_halo_h_ok(height, width, cin, cout, ksize)) {
+    const int slots = fsd_conv::wgrad_halo_h_slots(batch, height, width, cin);
+    return (size_t)(slots + wgrad_h_fold_extra_slices(slots)) * cout * 9 * cin * sizeof(float);
+  }
   int bm, bn;
   const int ncols = ksize * ksize * cin;
   wgrad_h_tiles(cout, ncols, (long long)batch * height * width, &bm, &bn);
@@ -1165,6 +1169,8 @@ extern "C" size_t fsd_conv2d_wgrad_h_workspace_bytes(int batch, int height, int 
 }
 
 extern "C" int fsd_conv2d_wgrad_h_plan(long long pixels, int cin, int cout, int ksize) {
+  // (the halo-staged kernel of the 32 -> 64 / 64 -> 128 layers also depends on the image shape: H % 8 == 0, W % 16 == 0 --
+  // this query answers for the GEMM kernels behind it)
   int bm, bn;
   wgrad_h_tiles(cout, ksize * ksize * cin, pixels, &bm, &bn);
   return bm * 1000 + bn;
@@ -1182,6 +1188,14 @@ extern "C" int fsd_conv2d_wgrad_h(const void* dy_bf16, long long dy_ld, const vo
   const long long pixels = (long long)batch * height * width;
   if (pixels > 0x7fffffffLL - 4096) return FSD_ERR_UNSUPPORTED;
   if (workspace_bytes < fsd_conv2d_wgrad_h_workspace_bytes(batch, height, width, cin, cout, ksize)) return FSD_ERR_WORKSPACE;
+  if (fsd_conv::wgrad_halo_h_ok(height, width, cin, cout, ksize)) {
+    // narrow layers: halo-staged blocks, one partial per persistent workgroup (wgrad_halo_h.hip)
+    const int rc = fsd_conv::wgrad3x3_halo_h(dy_bf16, dy_ld, x_bf16, x_ld, static_cast<float*>(workspace), batch, height, width,
+                                             cin, cout, stream);
+    if (rc != 0) return rc;
+    return launch_wgrad_h_fold(static_cast<float*>(workspace), dw_oihw, fsd_conv::wgrad_halo_h_slots(batch, height, width, cin),
+                               cout, cin, 9, stream);
+  }
   WgradHArgs a;
   a.dy = static_cast<const u16*>(dy_bf16); a.x = static_cast<const u16*>(x_bf16); a.ws = static_cast<float*>(workspace);
   a.dy_ld = dy_ld; a.x_ld = x_ld; a.H = height; a.W = width; a.M = (int)pixels; a.Cout = cout; a.Cin = cin;

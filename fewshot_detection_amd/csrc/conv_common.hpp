@@ -225,6 +225,12 @@ bool halo_h_ok(int height, int width, int cin, int cout, int ksize);
 int halo_h_rows(int batch, int height, int width, int cin, int cout);
 int conv3x3_halo_h(const void* x, long long x_ld, const void* w_packed, int kpad, const float* bias, void* y, long long y_ld,
                    float* bn_partial, int batch, int height, int width, int cin, int cout, float slope, hipStream_t stream);
+// bf16 storage mode: weight gradient of the 32 -> 64 / 64 -> 128 3x3 layers on 8 x 16 pixel blocks with a halo patch, one
+// partial per persistent workgroup (wgrad_halo_h.hip); slots = partial slices the fold reads
+bool wgrad_halo_h_ok(int height, int width, int cin, int cout, int ksize);
+int wgrad_halo_h_slots(int batch, int height, int width, int cin);
+int wgrad3x3_halo_h(const void* dy, long long dy_ld, const void* x, long long x_ld, float* ws, int batch, int height, int width,
+                    int cin, int cout, hipStream_t stream);
 // weight gradient of the narrow 3x3 layers on 8 x 8 pixel blocks with a halo patch (wgrad_halo.hip)
 bool wgrad3x3_halo_ok(int height, int width, int cin, int cout, int ksize);
 int wgrad3x3_halo_slots(int batch, int height, int width);

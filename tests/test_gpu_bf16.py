@@ -291,6 +291,36 @@ def test_wgrad_bf16_256x256_tile_matches_fp64(dev, B, H, W, cin, cout, k):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [
+    (3, 24, 48, 32, 64),        # 3 x 3 blocks per image: border blocks on every side and an interior one
+    (2, 8, 16, 32, 64),         # one block per image
+    (10, 64, 128, 32, 64),      # 640 blocks on 512 persistent workgroups
+    (3, 24, 48, 64, 128),       # 64 -> 128: eight waves of nine accumulators
+    (9, 64, 64, 64, 128),       # 288 blocks on 256 workgroups
+    (2, 16, 24, 32, 64),        # W % 16 == 8: half of the last block of a row is outside the image
+    (3, 104, 104, 64, 128),     # the timed map size
+])
+def test_wgrad_bf16_halo_kernel_matches_fp64(dev, B, H, W, cin, cout):
+    """wgrad3x3_halo_h_kernel (persistent workgroups, dy tile + x halo patch staged once per 8 x 16 block, transposing fragment
+    reads at the taps' pixel offsets, one partial per workgroup folded in a fixed order)."""
+    from fewshot_detection_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + B)
+    x = _bf(torch.randn(B, cin, H, W, generator=g))
+    gy = _bf(torch.randn(B, cout, H, W, generator=g))
+    ref = _wgrad_fp64_on_device(x.to(dev), gy.to(dev), 3)
+    dw = ops.conv2d_wgrad(_view_bf16(gy, dev), cout, _view_bf16(x, dev), cin, 3)
+    assert dw.dtype == torch.float32 and dw.shape == (cout, cin, 3, 3)
+    err = float((dw.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+    # operands that are channel slices of wider buffers (route buffers): leading dimensions > channel counts
+    xw = ops.View(torch.randn(B * H * W, cin + 16, generator=g).to(dev).to(BF), B, H, W, cin, c0=8)
+    xw.t[:, 8:8 + cin] = _view_bf16(x, dev).t
+    gw = ops.View(torch.randn(B * H * W, cout + 8, generator=g).to(dev).to(BF), B, H, W, cout, c0=8)
+    gw.t[:, 8:8 + cout] = _view_bf16(gy, dev).t
+    dw2 = ops.conv2d_wgrad(gw, cout, xw, cin, 3)
+    assert torch.equal(dw2, dw)
+
+
 # ---- the HBM-bound kernels: one template, two storage types ------------------------------------------------------
 
 def _pair(dev, B, H, W, C, seed):
