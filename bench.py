@@ -158,7 +158,13 @@ def _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, o
         parity["forward_rel_l2_checker"] = "oracle/net.py::_walk_bf16 (the builder's definition of the bf16 storage mode), random init"
     # bf16 mode: both runs round at the same points; a rounding-boundary flip in layer 0 (2.7e-5) is amplified ~1.35x per
     # layer by this randomly initialised net (tests/test_gpu_bf16.py pins every layer to 1e-4 on identical inputs)
-    parity["ok"] = bool((parity["forward_max_abs_delta"] < 1e-3 if dtype == "f32" else parity["forward_rel_l2"] < 0.2)
+    # The bf16 bound is the measured level (0.07-0.11 over rounds 3-5, boxes and first-layer arithmetics) with margin, and it is
+    # a bound against the BUILDER'S statement of that mode -- the line says so (`qualifier`); the reference has no bf16 mode.
+    if dtype != "f32":
+        parity["qualifier"] = ("bf16 storage mode: end-to-end agreement with oracle/net.py::_walk_bf16 (this repository's own "
+                               "definition of the mode) at random initialisation, bound rel-L2 < 0.15; the per-layer pins on "
+                               "identical inputs (1e-4) and the 120-step loss trajectory against fp32 are in tests/test_gpu_bf16.py")
+    parity["ok"] = bool((parity["forward_max_abs_delta"] < 1e-3 if dtype == "f32" else parity["forward_rel_l2"] < 0.15)
                         and parity["region_loss_max_abs_delta"] < 1e-3 and parity["anchor_assignment_equal"]
                         and parity["region_loss_abs_delta"] < 1e-3 * max(1.0, abs(ref_loss)))
     del net2
@@ -448,8 +454,9 @@ def roofline_block(r, dtype, ms, gemm_mode="native"):
                    "fp32 operands split in-kernel into three bf16 planes, six v_mfma_f32_32x32x16_bf16 terms per product, fp32 "
                    "accumulate"
                    if dom == "gemm_fwd" else
-                   "conv_bf16_*_kernel + wgrad_bf16_tr_kernel: the bf16-operand MFMA (v_mfma_f32_32x32x16_bf16) implicit-GEMM "
-                   "kernels of the bf16 storage mode (forward, data gradient, weight gradient)"),
+                   "conv_bf16_*_kernel + wgrad_bf16_tr_kernel + conv3x3_halo_h_kernel + wgrad3x3_halo_h_kernel: the bf16-operand "
+                   "MFMA (v_mfma_f32_32x32x16_bf16) kernels of the bf16 storage mode (forward, data gradient, weight gradient: "
+                   "DMA-staged implicit GEMM, and the persistent halo-staged kernels of the 32 / 64 / 128-channel 3x3 layers)"),
         "note": "achieved = fp32 GEMM FLOPs this kernel really computes (2*rows*Cout*K per launch; the Winograd layers count "
                 "their (tile+2)^2 position GEMMs, i.e. 4x / 2.25x fewer multiplications than the direct algorithm) / "
                 "its own duration, HIP events recorded by the library right around every launch on the launch stream "
