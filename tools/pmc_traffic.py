@@ -25,7 +25,7 @@ CLASSES = (
                     r"wino_input_kernel|wino_output_kernel|wino4_input_kernel|wino4_output_kernel|wino4_output4_kernel|"
                     r"wino4_fused_kernel|wino4_fused_[a-z0-9_]*kernel|wino4_gemm_out_kernel|wino4_rowfused_kernel|wino4_input_planes_kernel|wino4_split_planes_kernel)\b"),
     ("grad_transform", r"^(wino_dy_kernel|wino4_dy_kernel|wino4_grad_kernel)\b"),
-    ("wgrad", r"^(wgrad_kernel|wgrad_split8_kernel|wgrad3x3_halo_kernel|wgrad_first_kernel|wgrad_reduce_kernel|wgrad_bf16_tr_kernel|wgrad_bf16_tr8_kernel|"
+    ("wgrad", r"^(wgrad_kernel|wgrad_split8_kernel|wgrad3x3_halo_kernel|wgrad3x3_halo_h_kernel|wgrad_first_kernel|wgrad_reduce_kernel|wgrad_bf16_tr_kernel|wgrad_bf16_tr8_kernel|"
               r"wgrad_bf16_kernel|wgrad_fold_h_kernel|wgrad_h_fold_kernel|wgrad_h_partial_kernel|wino_dw_kernel|wino4_dw_kernel|conv_wgrad_[a-z0-9_]*kernel)\b"),
     ("weight_pack", r"^(wino_weight_kernel|wino4_weight_kernel|wino4_weight_wide_kernel|wino4_weight_split_kernel|pack_weight_kernel|"
                     r"pack_weight_bf16_kernel|pack_weight_bf16_pair_kernel|pack_weight_split_kernel)\b"),
