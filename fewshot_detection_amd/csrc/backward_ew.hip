@@ -320,29 +320,29 @@ __global__ __launch_bounds__(256) void act_stats_pool8_kernel(ActBwdArgsT<bf16_t
       s2[k] = 0.f;
     }
   }
-  const int CH = (p.H + 1) >> 1, CW = (p.W + 1) >> 1;
-  const long long cells = (long long)(p.pixels / ((long long)p.H * p.W)) * CH * CW;
-  const long long c0 = (long long)blockIdx.x * (p.ppb / 4);
+  // 32-bit index arithmetic (cells and pixels fit: the launcher checks); the image coordinates of a lane's cell are carried
+  // from trip to trip (+NPL cells) instead of being divided out of the cell index every time
+  const unsigned CH = (unsigned)(p.H + 1) >> 1, CW = (unsigned)(p.W + 1) >> 1;
+  const unsigned cells = (unsigned)(p.pixels / ((long long)p.H * p.W)) * CH * CW;
+  const unsigned c0 = blockIdx.x * (unsigned)(p.ppb / 4);
   if (g_ok) {
     const int ncell = p.ppb / 4;
+    unsigned cx = (c0 + pl) % CW, t0 = (c0 + pl) / CW;
+    unsigned cy = t0 % CH, b = t0 / CH;
     for (int it = pl; it < ncell; it += NPL) {
-      const long long cell = c0 + it;
+      const unsigned cell = c0 + it;
       if (cell >= cells) break;
-      const int cx = (int)(cell % CW);
-      const long long t = cell / CW;
-      const int cy = (int)(t % CH);
-      const long long b = t / CH;
-      const bool win = cy < p.OH && cx < p.OW;
+      const bool win = cy < (unsigned)p.OH && cx < (unsigned)p.OW;
       uint4 yr[4], zr;
       bool in[4];
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
-        in[q] = yy < p.H && xx < p.W;
-        yr[q] = in[q] ? *reinterpret_cast<const uint4*>(p.y + ((b * p.H + yy) * (long long)p.W + xx) * p.y_ld + g * 8) : z4;
+        const unsigned yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
+        in[q] = yy < (unsigned)p.H && xx < (unsigned)p.W;
+        yr[q] = in[q] ? *reinterpret_cast<const uint4*>(p.y + (long long)((b * p.H + yy) * p.W + xx) * p.y_ld + g * 8) : z4;
       }
-      zr = win ? *reinterpret_cast<const uint4*>(p.dz + ((b * p.OH + cy) * (long long)p.OW + cx) * p.dz_ld + g * 8) : z4;
+      zr = win ? *reinterpret_cast<const uint4*>(p.dz + (long long)((b * p.OH + cy) * p.OW + cx) * p.dz_ld + g * 8) : z4;
       const unsigned zw[4] = {zr.x, zr.y, zr.z, zr.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -369,6 +369,11 @@ __global__ __launch_bounds__(256) void act_stats_pool8_kernel(ActBwdArgsT<bf16_t
           s1[k] += d;
           s2[k] += d * ((yk[q] - mu[k]) * is[k]);
         }
+      }
+      cx += NPL;                                    // next cell of this lane (NPL <= 32 cells further)
+      while (cx >= CW) {
+        cx -= CW;
+        if (++cy == CH) { cy = 0; ++b; }
       }
     }
   }
@@ -694,11 +699,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
   // than a unit's own data) are fetched once per thread instead of once per unit, and the loads of all its units are issued
   // before the first use.  Per-element arithmetic as before (bit-identical results).
   constexpr int UC = POOL == 0 ? 4 : 1;      // (pooled cells: 18 loads each; two per thread measured 58 -> 65 us)
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cg = C >> 3;
-  const int g = (int)(idx % cg);
-  const long long unit0 = idx / cg * UC;
-  if (unit0 >= units) return;
+  // 32-bit index arithmetic (the launcher checks that threads and pixels fit): the 64-bit divisions and products of the first
+  // version were ~250 of the pooled variant's 1000 instructions per thread
+  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned cg = (unsigned)C >> 3;
+  const unsigned g = idx % cg;
+  const unsigned unit0 = idx / cg * UC;
+  if (unit0 >= (unsigned)units) return;
   float sc[8], sh[8], c1[8], c2[8], c3[8], mu[8], is[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
@@ -709,14 +716,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
   if constexpr (POOL == 0) {
     float yv[UC][8], gin[UC][8], gf[UC][8];
     bool ok[UC];
-    long long pix[UC];
+    unsigned pix[UC];
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
-      ok[u] = unit0 + u < units;
+      ok[u] = unit0 + u < (unsigned)units;
       pix[u] = ok[u] ? unit0 + u : unit0;
-      load8(y + pix[u] * y_ld + g * 8, yv[u]);
-      load8(dz + pix[u] * dz_ld + g * 8, gin[u]);
-      if (dz_full) load8(dz_full + pix[u] * dzf_ld + g * 8, gf[u]);
+      load8(y + (long long)pix[u] * y_ld + g * 8, yv[u]);
+      load8(dz + (long long)pix[u] * dz_ld + g * 8, gin[u]);
+      if (dz_full) load8(dz_full + (long long)pix[u] * dzf_ld + g * 8, gf[u]);
     }
     asm volatile("" ::: "memory");          // the loads stay up here
 #pragma unroll
@@ -730,15 +737,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
         const float d = tv > 0.f ? gk : gk * slope;
         o[k] = c1[k] * (d - c2[k] - (yv[u][k] - mu[k]) * is[k] * c3[k]);
       }
-      if (ok[u]) store8(dy + pix[u] * C + g * 8, o);
+      if (ok[u]) store8(dy + (long long)pix[u] * C + g * 8, o);
     }
   } else {
-    const long long unit = unit0;
-    const int CH = (H + 1) >> 1, CW = (W + 1) >> 1;
+    const unsigned unit = unit0;
+    const unsigned CH = (unsigned)(H + 1) >> 1, CW = (unsigned)(W + 1) >> 1;
     const int cx = (int)(unit % CW);
-    const long long t = unit / CW;
+    const unsigned t = unit / CW;
     const int cy = (int)(t % CH);
-    const long long b = t / CH;
+    const unsigned b = t / CH;
     const bool win = cy < OH && cx < OW;
     float yv[4][8], tv[4][8], bv[8], gz[8];
     bool in[4];
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
       const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
       in[q] = yy < H && xx < W;
       if (in[q]) {
-        load8(y + ((b * H + yy) * (long long)W + xx) * y_ld + g * 8, yv[q]);
+        load8(y + (long long)((b * H + yy) * W + xx) * y_ld + g * 8, yv[q]);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) yv[q][k] = 0.f;
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
       }
     }
     if (win) {
-      load8(dz + ((b * OH + cy) * (long long)OW + cx) * dz_ld + g * 8, gz);
+      load8(dz + (long long)((b * OH + cy) * OW + cx) * dz_ld + g * 8, gz);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) gz[k] = 0.f;
@@ -770,10 +777,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
     for (int q = 0; q < 4; ++q) {
       if (!in[q]) continue;
       const int yy = 2 * cy + (q >> 1), xx = 2 * cx + (q & 1);
-      const long long pix = (b * H + yy) * (long long)W + xx;
+      const unsigned pix = (b * H + yy) * W + xx;
       float gin[8], o[8];
       if (dz_full) {
-        load8(dz_full + pix * dzf_ld + g * 8, gin);
+        load8(dz_full + (long long)pix * dzf_ld + g * 8, gin);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) gin[k] = 0.f;
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_g8_kernel(const bf16_t* __re
         const float d = tv[q][k] > 0.f ? gk : gk * slope;
         o[k] = c1[k] * (d - c2[k] - (yv[q][k] - mu[k]) * is[k] * c3[k]);
       }
-      store8(dy + pix * C + g * 8, o);
+      store8(dy + (long long)pix * C + g * 8, o);
     }
   }
 }
@@ -1168,6 +1175,7 @@ extern "C" int fsd_bn_bwd_apply_g_h(const void* dz, long long dz_ld, const void*
   const int OH = pool ? height / 2 : height, OW = pool ? width / 2 : width;
   const long long pixels = (long long)batch * height * width;
   fsd_prof::Scope prof(fsd_prof::kActBwd, 2.0 * channels * ((double)batch * OH * OW + (dz_full ? 3.0 : 2.0) * pixels), stream);
+  if (pixels * (channels / 8) >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;      // 32-bit thread / pixel indices in the kernels
   const bf16_t* dzh = static_cast<const bf16_t*>(dz);
   const bf16_t* dfh = static_cast<const bf16_t*>(dz_full);
   const bf16_t* yh = static_cast<const bf16_t*>(y);
