@@ -136,6 +136,8 @@ def test_conv_bf16_eight_wave_tiles_match_fp64_of_rounded_operands(dev, monkeypa
     (3, 24, 48, 64, 128),       # 8 waves (2 pixel groups x 4 channel groups), one workgroup per CU
     (2, 16, 40, 64, 128),       # ... ragged width
     (5, 104, 104, 64, 128),     # the timed map size (B = 5): 455 blocks on 256 workgroups
+    (1, 304, 304, 32, 64),      # the 608 x 608 episodes of configs[4]: layer 2 ...
+    (1, 152, 152, 64, 128),     # ... and layers 4 / 6 (152 = 9.5 blocks wide)
 ])
 def test_conv_bf16_halo_kernel_matches_fp64_of_rounded_operands(dev, B, H, W, cin, cout):
     """conv3x3_halo_h_kernel (persistent workgroups, weights in registers, one DMA-staged halo patch per 8 x 16 block): forward
@@ -299,6 +301,8 @@ def test_wgrad_bf16_256x256_tile_matches_fp64(dev, B, H, W, cin, cout, k):
     (9, 64, 64, 64, 128),       # 288 blocks on 256 workgroups
     (2, 16, 24, 32, 64),        # W % 16 == 8: half of the last block of a row is outside the image
     (3, 104, 104, 64, 128),     # the timed map size
+    (1, 304, 304, 32, 64),      # the 608 x 608 episodes of configs[4]
+    (1, 152, 152, 64, 128),
 ])
 def test_wgrad_bf16_halo_kernel_matches_fp64(dev, B, H, W, cin, cout):
     """wgrad3x3_halo_h_kernel (persistent workgroups, dy tile + x halo patch staged once per 8 x 16 block, transposing fragment
