@@ -21,6 +21,7 @@ streams those kernels run on, and its all-reduce is started there -- while the s
 running) the layers below.  Buckets start in ascending index on every rank (enforced), which is their readiness order.
 """
 import os
+import sys
 import time
 
 import torch
@@ -115,7 +116,30 @@ class EpisodeTrainer(object):
         # per-bucket time the optimizer loop spent blocked in work.wait() (exposed all-reduce), accumulated over steps
         self.allreduce_wait_ms = [0.0] * len(self.buckets)
         self.time_allreduce = False
+        self._neg_group = None
+        if self.world_size > 1:
+            self._install_global_neg_counts()
         self.sync_replicas()
+
+    def _install_global_neg_counts(self):
+        """neg_filter's keep ratio over the WHOLE batch, as the reference computes it on the gathered outputs
+        (region_loss.GLOBAL_NEG_COUNTS): two integers per step, summed over the ranks on a gloo group of their own -- host
+        tensors, so the call neither touches nor waits for a GPU stream (an .item() behind an RCCL all-reduce would drain the
+        two steps the trainer keeps in flight).  Every rank calls the loss once per step, in step order: the collective
+        matches up by construction."""
+        from . import region_loss
+        try:
+            self._neg_group = self.dist.new_group(backend="gloo")
+        except Exception as e:           # no gloo in this build / rendezvous without TCP: keep the per-rank ratio (documented)
+            print("EpisodeTrainer: global neg_filter ratio unavailable (%s); per-rank ratio" % e, file=sys.stderr)
+            return
+        buf = torch.zeros(2, dtype=torch.int64)
+
+        def reduce_counts(n_pos, n_rows):
+            buf[0], buf[1] = int(n_pos), int(n_rows)
+            self.dist.all_reduce(buf, group=self._neg_group)
+            return int(buf[0]), int(buf[1])
+        region_loss.GLOBAL_NEG_COUNTS = reduce_counts
 
     def sync_replicas(self):
         """Every replica starts from rank 0's parameters, momentum and BatchNorm running statistics (the reference's

@@ -17,6 +17,14 @@ from ._lib import check, lib
 from .cfg import cfg
 
 
+# Data parallelism: the reference computes the keep ratio on the GATHERED batch (nn.DataParallel hands RegionLossV2 the outputs
+# of every replica, train_meta.py:137-141 -> region_loss.py:269), one process per GPU sees only its shard.  A trainer over
+# several ranks installs a reducer here -- (n_pos, n_rows) of this rank -> their sums over all ranks (dp.EpisodeTrainer: a
+# two-integer all-reduce on a host-side gloo group, off the GPU streams) -- so that every rank drops negatives with the
+# reference's probability 1 - neg_ratio * N_pos / N_neg of the whole batch.  None: the local counts are the batch's.
+GLOBAL_NEG_COUNTS = None
+
+
 def neg_filter_indices(target_rows):
     """Host half of reference neg_filter (region_loss.py:15-34): which (image, class) rows keep
     their box/objectness loss.  `target_rows`: (R, L) array on the host.  python's global
@@ -28,9 +36,10 @@ def neg_filter_indices(target_rows):
         raise NotImplementedError("neg_ratio not recognized")
     pos = (np.asarray(target_rows, dtype=np.float64).sum(axis=1) != 0).tolist()
     n_pos = sum(pos)
-    if n_pos == n_rows:
+    g_pos, g_rows = (n_pos, n_rows) if GLOBAL_NEG_COUNTS is None else GLOBAL_NEG_COUNTS(n_pos, n_rows)
+    if g_pos == g_rows:
         return list(range(n_rows))
-    ratio = cfg.neg_ratio * n_pos * 1.0 / (n_rows - n_pos)
+    ratio = cfg.neg_ratio * g_pos * 1.0 / (g_rows - g_pos)
     if ratio >= 1:
         return list(range(n_rows))
     return [i for i, p in enumerate(pos) if p or not (random() > ratio)]

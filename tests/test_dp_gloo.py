@@ -154,3 +154,46 @@ def test_replicas_start_from_rank0_state_and_bucket_order_is_enforced(tmp_path):
     assert torch.equal(a["flat"], torch.cat([p.detach().reshape(-1) for p in ref.parameters()]))
     assert float(a["mean"][0]) == 1.0 and float(b["var"][0]) == 2.0      # rank 0's statistics everywhere
     assert torch.load(os.path.join(str(tmp_path), "order0.pt")) and torch.load(os.path.join(str(tmp_path), "order1.pt"))
+
+
+def _neg_worker(rank, world, port, out_dir):
+    import random
+    import numpy as np
+    from fewshot_detection_amd import region_loss
+    from fewshot_detection_amd.cfg import cfg
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    EpisodeTrainer(_Tiny(), 0.001, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
+    assert region_loss.GLOBAL_NEG_COUNTS is not None
+    # rank 0: 2 positive rows of 10; rank 1: 6 of 10 -> the batch: 8 positive, 12 negative
+    rows = np.zeros((10, 250))
+    rows[:2 if rank == 0 else 6, 1] = 0.5
+    assert region_loss.GLOBAL_NEG_COUNTS(int((rows.sum(1) != 0).sum()), 10) == (8, 20)
+    keep = cfg.neg_ratio
+    try:
+        cfg.neg_ratio = 1                      # ratio = 8 / 12 everywhere (per rank it would be 2/8 and 6/4 -> "keep all")
+        random.seed(100 + rank)
+        inds = region_loss.neg_filter_indices(rows)
+        random.seed(100 + rank)
+        n_pos = 2 if rank == 0 else 6
+        want = [i for i in range(10) if i < n_pos or not (random.random() > 8.0 / 12.0)]
+        assert inds == want, (rank, inds, want)
+        cfg.neg_ratio = 2                      # 2 * 8 / 12 >= 1: every rank keeps every row
+        assert region_loss.neg_filter_indices(rows) == list(range(10))
+        cfg.neg_ratio = "full"                 # no collective, no change
+        assert region_loss.neg_filter_indices(rows) == list(range(10))
+    finally:
+        cfg.neg_ratio = keep
+    open(os.path.join(out_dir, "neg%d.ok" % rank), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_neg_filter_ratio_is_the_gathered_batchs_under_data_parallelism(tmp_path):
+    """The reference drops negative (image, class) rows with probability 1 - neg_ratio * n_pos / n_neg of the batch that
+    nn.DataParallel GATHERS (region_loss.py:15-34 on train_meta.py:137-141's outputs).  With one process per GPU the trainer
+    sums the two counts over the ranks (host-side gloo group): every rank uses the batch's ratio, not its shard's."""
+    port = _free_port()
+    mp.spawn(_neg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "neg%d.ok" % r)) for r in (0, 1))
