@@ -104,8 +104,31 @@ def episode_flops(blocks, lblocks, B, N, S, Sm):
 
 
 
-def _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora, fp32_out=None):
-    """The HIP path on the oracle's weights and inputs: forward, end-to-end loss, and RegionLoss on IDENTICAL inputs."""
+OTHER_SHAPES = [     # key, B, N, S, Sm, neg_ratio, what -- the other BASELINE configs' shapes (other_configs() times them)
+    ("configs1_cfg_episode", 64, 15, 416, 416, 1, "BASELINE configs[1] with the cfg's own 416x416 supports and 15 base classes"),
+    ("configs3_tuning_C4", 32, 20, 416, 416, 0, "BASELINE configs[3]: 5-shot fine-tune shape, B=32, 20-way, neg_ratio=0"),
+    ("configs4_shape_C5", 64, 80, 608, 416, 1, "BASELINE configs[4] shape on ONE GPU: 64 queries 608x608, 80-way (COCO)"),
+]
+
+
+def _forward_delta(net2, dtype, dev, sample, ref, fp32_ref=None):
+    """Forward of the HIP model `net2` (train-mode BatchNorm) on `sample` against the oracle's output `ref`."""
+    x, metax, mask, _ = sample
+    with torch.no_grad():
+        out = net2(x.to(dev), metax.to(dev), mask.to(dev)).detach().cpu()
+    d = {"B": int(x.shape[0]), "N": int(metax.shape[0]), "size": int(x.shape[2]), "support": int(metax.shape[2]),
+         "forward_max_abs_delta": float((out - ref).abs().max()), "forward_max_abs": float(ref.abs().max()),
+         "forward_rel_l2": float((out - ref).norm() / ref.norm()),
+         "checker": "oracle fp32 forward" if dtype == "f32" else "oracle/net.py::_walk_bf16 (this repository's statement of the mode)"}
+    d["ok"] = bool(d["forward_max_abs_delta"] < 1e-3) if dtype == "f32" else bool(d["forward_rel_l2"] < 0.15)
+    if fp32_ref is not None:
+        d["forward_rel_l2_vs_fp32_oracle"] = float((out - fp32_ref).norm() / fp32_ref.norm())
+    return d
+
+
+def _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora, fp32_out=None, extra=None):
+    """The HIP path on the oracle's weights and inputs: forward, end-to-end loss, and RegionLoss on IDENTICAL inputs.
+    `extra`: callable yielding (key, sample, ref, fp32_ref) of further launch configurations -- forward only."""
     from oracle.region import region_loss_v2
     from fewshot_detection_amd.cfg import cfg
     from fewshot_detection_amd.darknet_meta import Darknet
@@ -167,12 +190,18 @@ def _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, o
     parity["ok"] = bool((parity["forward_max_abs_delta"] < 1e-3 if dtype == "f32" else parity["forward_rel_l2"] < 0.15)
                         and parity["region_loss_max_abs_delta"] < 1e-3 and parity["anchor_assignment_equal"]
                         and parity["region_loss_abs_delta"] < 1e-3 * max(1.0, abs(ref_loss)))
+    if extra is not None:
+        # every OTHER launch configuration this run times: a quoted c4_ms / c5_ms is never a number without a check
+        parity["other_shapes"] = {}
+        for key, smp, ref, fref in extra(dtype):
+            parity["other_shapes"][key] = _forward_delta(net2, dtype, dev, smp, ref, fref)
+        parity["ok"] = bool(parity["ok"] and all(v["ok"] for v in parity["other_shapes"].values()))
     del net2
     torch.cuda.empty_cache()
     return parity
 
 
-def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes):
+def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes, world=1):
     """The oracle (PyTorch-CPU fp32 restatement of the reference) timed on this host on a bounded sample of the same
     workload, then used as the checker of the HIP path on the same weights and inputs (BASELINE.json's metric names
     "RegionLoss max|delta| vs ref").  On a host with >= 32 cores the sample is the timed query batch itself (B = 64: one
@@ -220,6 +249,33 @@ def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes):
         return base, {}
     parity = {}
     ref_out, ref_loss = out.detach(), float(r["loss"].detach())
+    refs = {}
+
+    def extra(dtype):
+        """(key, sample, oracle output in `dtype`'s arithmetic, fp32 oracle output) of the other timed shapes -- the episodes
+        other_configs() times (same seeds), forward only, the oracle's weights; the references are computed once."""
+        if args.no_extras or args.mode != "train":
+            return
+        shapes = list(OTHER_SHAPES)
+        if world > 1 and args.batch % world == 0:
+            # what ONE RANK of the strong-scaling form launches: its slice of the global episode, every support
+            shapes = [("strong_scaling_rank_slice", args.batch // world, args.classes, args.size, args.support, 1, "")]
+        for key, B, N, S, Sm, _neg, _what in shapes:
+            if (B, N, S, Sm) == (args.batch, args.classes, args.size, args.support):
+                key, B, N, S, Sm = "metric_string_episode", 64, 20, 416, 224      # (as other_configs() substitutes it)
+            Bc = B if cores >= 32 else min(B, 4)          # (small hosts: a reduced batch, stated in the record)
+            if key not in refs:
+                smp = synth_episode(2000 + N, Bc, N, S, Sm)
+                with torch.no_grad():
+                    ora.load_state_dict(state)
+                    refs[key] = [smp, ora(smp[0], smp[1], smp[2]).detach(), None]
+            if dtype == "bf16" and refs[key][2] is None:
+                with torch.no_grad():
+                    ora.load_state_dict(state)
+                    refs[key][2] = ora.forward_bf16(*refs[key][0][:3])[0].detach()
+            smp, r32, r16 = refs[key]
+            yield (key, smp, r32, None) if dtype == "f32" else (key, smp, r16, r32)
+
     for dtype in dtypes:
         if dtype == "bf16":                  # the checker of the bf16 mode is the oracle's restatement of that mode
             ora.load_state_dict(state)
@@ -227,9 +283,9 @@ def cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes):
                 out_h, _ = ora.forward_bf16(x, metax, mask)
             r_h = region_loss_v2(out_h, tgt, ora.region.anchors, seen=0)
             parity[dtype] = _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, out_h.detach(), float(r_h["loss"].detach()), ora,
-                                         fp32_out=ref_out)
+                                         fp32_out=ref_out, extra=extra)
         else:
-            parity[dtype] = _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora)
+            parity[dtype] = _hip_parity(dyn_cfg, rw_cfg, state, dtype, dev, sample, ref_out, ref_loss, ora, extra=extra)
     return base, parity
 
 
@@ -573,6 +629,8 @@ def compact_line(res, full_path=None):
                          "region_loss_abs_delta": p.get("region_loss_abs_delta"),
                          "grad_max_abs_delta": p.get("region_loss_max_abs_delta"),
                          "anchor_assignment_equal": p.get("anchor_assignment_equal"), "tolerance": p.get("tolerance")}
+        if p.get("other_shapes"):
+            out["parity"]["other_shapes_ok"] = all(v.get("ok") for v in p["other_shapes"].values())
     gc_ = res.get("gpu_clock") or {}
     if gc_:
         out["gpu_clock_mhz"] = [gc_.get("probe_mhz_start"), gc_.get("probe_mhz_after_timing")]
@@ -630,6 +688,11 @@ def compact_line(res, full_path=None):
         am["c1cfg_ms"] = g(a, "configs1_cfg_episode", "ms_per_step") or g(a, "metric_string_episode", "ms_per_step")
         am["c4_ms"] = g(a, "configs3_tuning_C4", "ms_per_step")
         am["c5_ms"] = g(a, "configs4_shape_C5", "ms_per_step")
+        # forward max|delta| against the oracle at those shapes (fp32) -- [c1cfg, c4, c5]
+        am["other_fwd_delta"] = [g(a, k, "parity", "forward_max_abs_delta") for k in
+                                 ("configs1_cfg_episode", "configs3_tuning_C4", "configs4_shape_C5")]
+        if all(v is None for v in am["other_fwd_delta"]):
+            am["other_fwd_delta"] = None
         for alt in ("native", "split"):
             if "f32_gemm_" + alt in a:
                 am[alt + "_ms"] = g(a, "f32_gemm_" + alt, "ms_per_step")
@@ -644,6 +707,10 @@ def compact_line(res, full_path=None):
             am[other + "_c1cfg_ms"] = g(o, "other_configs", "configs1_cfg_episode", "ms_per_step")
             am[other + "_c4_ms"] = g(o, "other_configs", "configs3_tuning_C4", "ms_per_step")
             am[other + "_c5_ms"] = g(o, "other_configs", "configs4_shape_C5", "ms_per_step")
+            am[other + "_other_fwd_rel_l2"] = [g(o, "other_configs", k, "parity", "forward_rel_l2") for k in
+                                               ("configs1_cfg_episode", "configs3_tuning_C4", "configs4_shape_C5")]
+            if all(v is None for v in am[other + "_other_fwd_rel_l2"]):
+                am[other + "_other_fwd_rel_l2"] = None
         out["also_measured"] = {k: v for k, v in am.items() if v is not None}
     if full_path:
         out["full_record"] = full_path
@@ -776,11 +843,8 @@ def other_configs(leg, args, dev, blocks, lblocks):
     from fewshot_detection_amd.cfg import cfg
     out = {}
     keep = cfg.neg_ratio
-    shapes = [("configs1_cfg_episode", 64, 15, 416, 416, 1, "BASELINE configs[1] with the cfg's own 416x416 supports and 15 base classes"),
-              ("configs3_tuning_C4", 32, 20, 416, 416, 0, "BASELINE configs[3]: 5-shot fine-tune shape, B=32, 20-way, neg_ratio=0"),
-              ("configs4_shape_C5", 64, 80, 608, 416, 1, "BASELINE configs[4] shape on ONE GPU: 64 queries 608x608, 80-way (COCO)")]
     try:
-        for key, B, N, S, Sm, neg, what in shapes:
+        for key, B, N, S, Sm, neg, what in OTHER_SHAPES:
             if (B, N, S, Sm) == (args.batch, args.classes, args.size, args.support):
                 key, B, N, S, Sm, neg, what = ("metric_string_episode", 64, 20, 416, 224, 1, "the shape in BASELINE.json's metric string")
             cfg.neg_ratio = neg
@@ -972,6 +1036,17 @@ def _main(args, real_stdout):
                          "ms_per_step": t2 * 1e3, "episodes_per_s": eps2 / t2, "img_per_s": gb2 / t2, "loss": r2["loss"]}
         del x2, metax2, mask2, step2
 
+    # Several ranks: the data path is done.  Every rank leaves the process group NOW (after a barrier), so that rank 0 can
+    # spend the CPU-baseline / parity leg alone on the host cores while the other ranks exit (a line from a
+    # multi-GPU run without cpu_baseline reads as "unmeasured").
+    dist_world, dist_backend = (dist.get_world_size(), dist.get_backend()) if dist is not None else (1, None)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        if leg.opt is not None:
+            leg.opt.close()                # hands the loss module back (whole-batch neg_filter reducer), frees its host group
+        dist.destroy_process_group()
+        dist = None
     if rank == 0:
         if args.per_layer and r["prof_steps"]:
             prof, ps = r["prof"], r["prof_steps"]
@@ -1031,8 +1106,7 @@ def _main(args, real_stdout):
         if leg.opt is not None:
             o = leg.opt
             res["dp"] = {"world_size": o.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
-                         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
-                         "backend_reported": (dist.get_backend() if dist is not None else None),
+                         "rccl_ranks": dist_world, "backend_reported": dist_backend,
                          "gradient_buckets": len(o.buckets), "allreduce_dtype": str(o.grad_dtype).replace("torch.", ""),
                          "bucket_mb": [4e-6 * (hi - lo) for lo, hi in o.buckets], "bucket_launch_order": list(o.launch_order_last),
                          "allreduce_wait_ms_per_step": [v / args.steps for v in o.allreduce_wait_ms],
@@ -1094,17 +1168,27 @@ def _main(args, real_stdout):
             res["also_measured"] = also
         if other_scaling is not None:
             res.setdefault("also_measured", {})[other_scaling["scaling"] + "_scaling"] = other_scaling
-        if not args.no_cpu_baseline and world == 1:
-            dtypes = [args.dtype] + (["bf16" if args.dtype == "f32" else "f32"] if (args.mode == "train" and not args.no_extras) else [])
-            res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, full_flops, dev, dtypes)
+        if not args.no_cpu_baseline:
+            dtypes = [args.dtype] + (["bf16" if args.dtype == "f32" else "f32"]
+                                     if (args.mode == "train" and not args.no_extras and world == 1) else [])
+            # (several ranks: the baseline is ONE episode of --batch queries on this host's cores, timed after the ranks left
+            # the process group; the parity sample is the weak form's per-rank batch, the strong form's slice rides along)
+            cpu_flops = episode_flops(blocks, lblocks, args.batch, args.classes, args.size, args.support)
+            res["cpu_baseline"], parity = cpu_baseline_and_parity(dyn_cfg, rw_cfg, args, cpu_flops, dev, dtypes, world)
+            if world > 1:
+                res["cpu_baseline"]["sample"] += "; timed on rank 0 after the %d ranks left the process group" % world
             if args.dtype in parity:
                 res["parity"] = parity[args.dtype]
             for d in parity:
                 if d != args.dtype and (d + "_mode") in res.get("also_measured", {}):
                     res["also_measured"][d + "_mode"]["parity"] = parity[d]
+                # the forward check of every other timed shape sits next to that shape's time
+                home = res.get("also_measured", {}) if d == args.dtype else \
+                    res.get("also_measured", {}).get(d + "_mode", {}).get("other_configs", {})
+                for key, chk in (parity[d].get("other_shapes") or {}).items():
+                    if key in home:
+                        home[key]["parity"] = chk
         emit(res, stream=real_stdout)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "fsd_fill": (_i, [_p, _f, _ll, _p]),
     "fsd_reorg_fwd": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
     "fsd_global_maxpool_fwd": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_global_avgpool_fwd": (_i, [_p, _i, _ll, _p, _i, _i, _i, _i, _p]),
+    "fsd_global_avgpool_bwd": (_i, [_p, _p, _i, _ll, _i, _i, _i, _i, _p]),
     "fsd_dynamic_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fsd_fold_reweight_head": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -88,6 +90,7 @@ PROTOTYPES = {
     "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
     "fsd_conv_row_tiles_h": (_i, [_ll]),
     "fsd_conv2d_h_partial_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "fsd_conv2d_h_partial_rows_at": (_i, [_i, _i, _i, _i, _i, _i, _p, _ll, _p, _ll]),
     "fsd_conv2d_h_plan": (_i, [_ll, _i, _i, _i, _i, _i]),
     "fsd_conv2d_fwd_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fsd_conv2d_wgrad_h_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -113,11 +116,6 @@ PROTOTYPES = {
     "fsd_clock_probe": (_i, [_p, _i, _p, _p]),
     "fsd_f32_gemm_mode": (_i, [_i]),
     "fsd_version": (C.c_char_p, []),
-}
-
-# entry points of a library built with -DFSD_EXPERIMENTS (include/fsdet.h, #ifdef FSD_EXPERIMENTS): bound when present
-EXPERIMENTAL_PROTOTYPES = {
-    "fsd_wino_fused_mode": (_i, [_i]),
 }
 
 _lib = None
@@ -149,11 +147,6 @@ def lib():
                 raise FsdetLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
-        for name, (res, args) in EXPERIMENTAL_PROTOTYPES.items():
-            fn = getattr(handle, name, None)
-            if fn is not None:
-                fn.restype = res
-                fn.argtypes = args
         _lib = handle
     return _lib
 

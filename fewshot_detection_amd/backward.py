@@ -249,6 +249,9 @@ def run(net, tape, grad_out, params, wgrad_stream=True):
         elif kind == "globalmax":
             x = rec["x"]
             _accumulate(grads, x, ops.global_maxpool_bwd(grad_out.reshape(x.B, x.C), rec["arg"], x))
+        elif kind == "globalavg":
+            x = rec["x"]
+            _accumulate(grads, x, ops.global_avgpool_bwd(grad_out.reshape(x.B, x.C), x))
         elif kind == "route":
             if len(rec["src"]) == 2:
                 g = grads.pop(id(rec["z"]), None)

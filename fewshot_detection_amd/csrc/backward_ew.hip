@@ -874,6 +874,16 @@ __global__ void global_max_bwd_kernel(const float* __restrict__ dout, const int*
 }
 
 template <typename T>
+__global__ void global_avg_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dx, long long dx_ld, int HW, int C,
+                                      float inv_hw, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, pixel, c)
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long t = idx / C;
+  st1<T>(dx + t * dx_ld + c, dout[(t / HW) * C + c] * inv_hw);
+}
+
+template <typename T>
 __global__ void add_inplace_kernel(T* __restrict__ dst, long long dst_ld, const T* __restrict__ src, long long src_ld,
                                    int C, long long total) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1219,6 +1229,21 @@ extern "C" int fsd_global_maxpool_bwd(const float* dout, const int* argmax, floa
 extern "C" int fsd_global_maxpool_bwd_h(const float* dout, const int* argmax, void* dx, long long dx_ld, int batch,
                                         int height, int width, int channels, hipStream_t stream) {
   return global_maxpool_bwd_impl<bf16_t>(dout, argmax, static_cast<bf16_t*>(dx), dx_ld, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_global_avgpool_bwd(const float* dout, void* dx, int dx_bf16, long long dx_ld, int batch, int height, int width,
+                                      int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!dout || !dx || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
+  const int hw = height * width;
+  const long long total = (long long)batch * hw * channels;
+  if (dx_bf16)
+    FSD_LAUNCH(global_avg_bwd_kernel<bf16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, static_cast<bf16_t*>(dx),
+               dx_ld, hw, channels, 1.f / (float)hw, total);
+  else
+    FSD_LAUNCH(global_avg_bwd_kernel<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, dout, static_cast<float*>(dx),
+               dx_ld, hw, channels, 1.f / (float)hw, total);
+  return (int)hipGetLastError();
 }
 
 extern "C" int fsd_add_inplace(float* dst, long long dst_ld, const float* src, long long src_ld, long long rows,

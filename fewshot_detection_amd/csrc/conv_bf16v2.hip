@@ -523,6 +523,19 @@ extern "C" int fsd_conv2d_h_partial_rows(int batch, int height, int width, int c
   return (int)((pixels + bm - 1) / bm);
 }
 
+extern "C" int fsd_conv2d_h_partial_rows_at(int batch, int height, int width, int cin, int cout, int ksize, const void* x_bf16,
+                                           long long x_ld, const void* y, long long y_ld) {
+  // the rows of exactly the launch fsd_conv2d_fwd[_act]_h makes for THESE operands: the halo-staged kernel needs 16-byte
+  // aligned rows on both sides, anything else takes the implicit-GEMM kernel (and its row tiles)
+  if (fsd_conv::halo_h_ok(height, width, cin, cout, ksize) &&
+      fsd_conv::halo_h_layout_ok(x_bf16, x_ld, y, y_ld, batch, height, width, cin, cout))
+    return fsd_conv::halo_h_rows(batch, height, width, cin, cout);
+  const long long pixels = (long long)batch * height * width;
+  const int tile = pick_tile_h(pixels, cin, cout, ksize, false, true, bk_of(cin, ksize));
+  const int bm = tile_bm(tile);
+  return (int)((pixels + bm - 1) / bm);
+}
+
 extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
                                 long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
                                 int ksize, int out_nchw_f32, hipStream_t stream) {
@@ -543,12 +556,11 @@ extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const vo
   if ((reinterpret_cast<uintptr_t>(x_bf16) & 15) || (reinterpret_cast<uintptr_t>(w_packed_bf16) & 15)) return FSD_ERR_ARG;
   if (!out_nchw_f32 && (reinterpret_cast<uintptr_t>(y) & 3)) return FSD_ERR_ARG;
   const long long pixels = (long long)batch * height * width;
-  if (!out_nchw_f32 && fsd_conv::halo_h_ok(height, width, cin, cout, ksize)) {
-    const int rc = fsd_conv::conv3x3_halo_h(x_bf16, x_ld, w_packed_bf16, round_up(ksize * ksize * cin, 64), bias, y, y_ld, bn_partial,
-                                            batch, height, width, cin, cout, slope, stream);
-    if (rc != FSD_ERR_UNSUPPORTED) return rc;       // (odd strides / alignments stay on the implicit-GEMM kernel)
-    if (bn_partial) return rc;                      // ... but the caller sized bn_partial for the halo kernel
-  }
+  // (odd strides / alignments stay on the implicit-GEMM kernel; bn_partial must hold fsd_conv2d_h_partial_rows_at() rows)
+  if (!out_nchw_f32 && fsd_conv::halo_h_ok(height, width, cin, cout, ksize) &&
+      fsd_conv::halo_h_layout_ok(x_bf16, x_ld, y, y_ld, batch, height, width, cin, cout))
+    return fsd_conv::conv3x3_halo_h(x_bf16, x_ld, w_packed_bf16, round_up(ksize * ksize * cin, 64), bias, y, y_ld, bn_partial,
+                                    batch, height, width, cin, cout, slope, stream);
   if (pixels > 0x7fffffffLL - 512 || (pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
   ConvHArgs a;
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;

@@ -222,6 +222,8 @@ bool halo_ok(int height, int width, int cin, int cout, int ksize, bool nchw);
 // bf16 storage mode: persistent halo-staged 3x3 convolution of the 32 -> 64 / 64 -> 32 layers, weights in registers
 // (conv_halo_h.hip); halo_h_rows = BatchNorm partial rows it writes (one per workgroup)
 bool halo_h_ok(int height, int width, int cin, int cout, int ksize);
+bool halo_h_layout_ok(const void* x, long long x_ld, const void* y, long long y_ld, int batch, int height, int width, int cin,
+                      int cout);
 int halo_h_rows(int batch, int height, int width, int cin, int cout);
 int conv3x3_halo_h(const void* x, long long x_ld, const void* w_packed, int kpad, const float* bias, void* y, long long y_ld,
                    float* bn_partial, int batch, int height, int width, int cin, int cout, float slope, hipStream_t stream);

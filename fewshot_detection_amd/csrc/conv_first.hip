@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
   const long long p_begin = ((long long)blockIdx.x * 4 + wave) * p.ppw;
   const long long p_end = p_begin + p.ppw < p.pixels ? p_begin + p.ppw : p.pixels;
   const char* x_b = reinterpret_cast<const char*>(p.x);
-  const f32x2 zero2 = {0.f, 0.f};
+  const bool ch0_ok = 2 * h < p.cin, ch1_ok = 2 * h + 1 < p.cin;       // this half's channel pair inside the true cin
   const unsigned hw = (unsigned)(p.H * p.W);
   float s1 = 0.f, s2 = 0.f;
 
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(FirstFwdArgs p) {
       const int dy = t / 3 - 1, dx = t % 3 - 1;
       const bool ok = valid && (unsigned)(yy + dy) < (unsigned)p.H && (unsigned)(xx + dx) < (unsigned)p.W;
       const f32x2 v = *reinterpret_cast<const f32x2*>(x_b + (ok ? off + (unsigned)((dy * p.W + dx) * (int)p.x_ld * 4) : 0u));
-      pt[t] = ok ? v : zero2;
+      // (padding channels beyond cin carry a zero WEIGHT, but 0 * NaN of an uninitialised pad would still poison the sum:
+      // they are masked like the out-of-image taps)
+      pt[t] = f32x2{ok && ch0_ok ? v[0] : 0.f, ok && ch1_ok ? v[1] : 0.f};
     }
   };
   auto compute = [&](long long base, const f32x2 (&pt)[9]) {
@@ -467,9 +469,16 @@ int conv_first_impl(const float* x, long long x_ld, const float* w_oihw, const f
   // 16-byte stores; everything else (native arithmetic, odd widths, unaligned destinations) keeps the fp32-MFMA kernel
   static const char* v2_env = FSD_TUNE("FSD_FIRST_SPLIT");           // tuning aid: 0 = always the fp32-MFMA kernel
   if (!(v2_env && v2_env[0] == '0') && fsd_conv::f32_split_on() && a.wide && width % 32 == 0) {
-    if (cin == 3) FSD_LAUNCH((conv_first_split_kernel<3, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-    else FSD_LAUNCH((conv_first_split_kernel<4, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
-    return (int)hipGetLastError();
+    // <3> never reads the fourth component; <4> multiplies every component it loads, so it takes the full pixel only
+    // (cin = 1, 2: the fp32-MFMA kernel below, which masks the padding channels -- ADVICE r5)
+    if (cin == 3) {
+      FSD_LAUNCH((conv_first_split_kernel<3, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+      return (int)hipGetLastError();
+    }
+    if (cin == 4) {
+      FSD_LAUNCH((conv_first_split_kernel<4, TO>), dim3(blocks, cout / 32), dim3(256), 0, stream, a);
+      return (int)hipGetLastError();
+    }
   }
   FSD_LAUNCH(conv_first_kernel<TO>, dim3(blocks, cout / 32), dim3(256), 0, stream, a);
   return (int)hipGetLastError();

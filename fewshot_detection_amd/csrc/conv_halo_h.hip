@@ -23,8 +23,9 @@
 //     workgroup (fsd_conv2d_h_partial_rows reports min(blocks, 512) rows for these shapes).
 // The 64 -> 128 layers (darknet L4 / L6 at 104 x 104) run the same loop on 8 waves (2 pixel groups x 4 channel groups, one
 // workgroup per CU): every wave still holds 144 registers of weights.
-// Shapes: ksize 3, (Cin, Cout) = (32, 64), (64, 32) or (64, 128), H % 8 == 0, W % 8 == 0 (the last block of a row may be half
-// outside: W = 104), bf16 NHWC output; everything else stays on conv_bf16_dma_kernel.  FSD_CONV_HALO=0 switches it off (the
+// Shapes: ksize 3, (Cin, Cout) = (32, 64), (64, 32) or (64, 128), H % 8 == 0, W % 16 == 0 -- for 64 -> 128 also W % 16 == 8 (the
+// last block of a row is then half outside: W = 104; see halo_h_ok for why only there) -- bf16 NHWC output; everything else
+// stays on conv_bf16_dma_kernel.  FSD_CONV_HALO=0 switches it off (the
 // switch of the fp32 twin).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -424,8 +425,24 @@ int launch_halo_h(const HaloHArgs& a, int wgs, int lds, hipStream_t stream) {
 bool fsd_conv::halo_h_ok(int height, int width, int cin, int cout, int ksize) {
   static const char* env = getenv("FSD_CONV_HALO");
   if (env && env[0] == '0') return false;
-  return ksize == 3 && ((cin == 32 && cout == 64) || (cin == 64 && cout == 32) || (cin == 64 && cout == 128)) &&
-         height % kBH == 0 && width % 8 == 0;
+  if (!(ksize == 3 && ((cin == 32 && cout == 64) || (cin == 64 && cout == 32) || (cin == 64 && cout == 128)))) return false;
+  // A ragged last block (W % 16 == 8) is taken by the 64 -> 128 configuration only: its epilogue issues every store under a
+  // per-lane predicate, so the store count behind the COUNTED vmcnt wait is the same for every block.  The 32 -> 64 and
+  // 64 -> 32 epilogues skip whole (wave-uniform) store instructions on a ragged block -- with more than D blocks per
+  // workgroup the wait for a patch could then be satisfied while its own LDS-DMA pieces are still in flight -- so they take
+  // whole blocks only (every stock size: these layers sit at S / 2, a multiple of 16); other widths stay on the GEMM kernel.
+  return height % kBH == 0 && width % ((cin == 64 && cout == 128) ? 8 : kBW) == 0;
+}
+
+// strides / alignments the kernel's 16-byte DMA pieces and stores need (the plan queries and the launch agree on this)
+bool fsd_conv::halo_h_layout_ok(const void* x, long long x_ld, const void* y, long long y_ld, int batch, int height, int width,
+                                int cin, int cout) {
+  const long long pixels = (long long)batch * height * width;
+  if ((y_ld & 1) || (reinterpret_cast<uintptr_t>(y) & 3) || (x_ld & 7) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      pixels >= 0x7fffffffLL || (width + 2) * x_ld >= 0x7fffffffLL || (4LL * width + 16) * y_ld >= 0x7fffffffLL)
+    return false;
+  if (!(cin == 64 && cout == 32) && ((y_ld & 7) || (reinterpret_cast<uintptr_t>(y) & 15))) return false;      // 16-byte stores
+  return true;
 }
 
 // one BatchNorm partial row per persistent workgroup: two 4-wave workgroups per CU, or one 8-wave workgroup (64 -> 128)
@@ -439,9 +456,7 @@ int fsd_conv::conv3x3_halo_h(const void* x, long long x_ld, const void* w_packed
                              long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
                              float slope, hipStream_t stream) {
   const long long pixels = (long long)batch * height * width;
-  if ((y_ld & 1) || (reinterpret_cast<uintptr_t>(y) & 3) || (x_ld & 7) || (reinterpret_cast<uintptr_t>(x) & 15) ||
-      pixels >= 0x7fffffffLL || (width + 2) * x_ld >= 0x7fffffffLL || (4LL * width + 16) * y_ld >= 0x7fffffffLL)
-    return FSD_ERR_UNSUPPORTED;
+  if (!halo_h_layout_ok(x, x_ld, y, y_ld, batch, height, width, cin, cout)) return FSD_ERR_UNSUPPORTED;
   HaloHArgs a;
   a.x = static_cast<const u16*>(x); a.w = static_cast<const u16*>(w_packed); a.bias = bias; a.y = static_cast<u16*>(y);
   a.bn_partial = bn_partial; a.x_ld = (unsigned)x_ld; a.y_ld = (unsigned)y_ld;
@@ -457,7 +472,6 @@ int fsd_conv::conv3x3_halo_h(const void* x, long long x_ld, const void* w_packed
     const int lds = 3 * 6 * 4096;
     return epi ? launch_halo_h<64, 32, 4, 1, true>(a, wgs, lds, stream) : launch_halo_h<64, 32, 4, 1, false>(a, wgs, lds, stream);
   }
-  if ((y_ld & 7) || (reinterpret_cast<uintptr_t>(y) & 15)) return FSD_ERR_UNSUPPORTED;      // 16-byte stores
   if (cin == 32) {
     const int lds = 5 * 3 * 4096 + 4 * 4096;
     return epi ? launch_halo_h<32, 64, 4, 1, true>(a, wgs, lds, stream) : launch_halo_h<32, 64, 4, 1, false>(a, wgs, lds, stream);

@@ -286,6 +286,20 @@ __global__ void global_max_kernel(const T* __restrict__ x, long long x_ld, float
   if (argmax) argmax[idx] = arg;
 }
 
+// ---- global average pool: (B, HW, C) -> (B, C), F.adaptive_avg_pool2d(x, 1) of pooling.py:29-45 (fp64 sum, one rounding) ----
+template <typename T>
+__global__ void global_avg_kernel(const T* __restrict__ x, long long x_ld, float* __restrict__ out, int HW, int C,
+                                  long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long b = idx / C;
+  const T* p = x + b * HW * x_ld + c;      // consecutive lanes = consecutive channels of one pixel: coalesced rows
+  double s = 0.0;
+  for (int i = 0; i < HW; ++i) s += (double)ld1<T>(p + (long long)i * x_ld);
+  out[idx] = (float)(s / (double)HW);
+}
+
 // ---- channel reweighting ------------------------------------------------------------------
 __global__ void dynamic_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
                                     int n_cls, int C, int hw, long long total) {
@@ -505,6 +519,20 @@ extern "C" int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out
 extern "C" int fsd_global_maxpool_fwd_h(const void* x, long long x_ld, float* out, int* argmax, int batch, int height,
                                         int width, int channels, hipStream_t stream) {
   return global_maxpool_impl<bf16_t>(static_cast<const bf16_t*>(x), x_ld, out, argmax, batch, height, width, channels, stream);
+}
+
+extern "C" int fsd_global_avgpool_fwd(const void* x, int x_bf16, long long x_ld, float* out, int batch, int height, int width,
+                                      int channels, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!x || !out || batch < 1 || height < 1 || width < 1 || channels < 1) return FSD_ERR_ARG;
+  const long long total = (long long)batch * channels;
+  if (x_bf16)
+    FSD_LAUNCH(global_avg_kernel<bf16_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, static_cast<const bf16_t*>(x), x_ld,
+               out, height * width, channels, total);
+  else
+    FSD_LAUNCH(global_avg_kernel<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, static_cast<const float*>(x), x_ld,
+               out, height * width, channels, total);
+  return (int)hipGetLastError();
 }
 
 extern "C" int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,

@@ -808,9 +808,6 @@ __global__ FSD_XFORM_LB void wino4_output4_kernel(const float* __restrict__ Mb, 
   }
 }
 
-#ifdef FSD_EXPERIMENTS
-#include "winograd_experiments.inc"
-#endif
 
 // U[p][row][k] = (G g G^T)[p] for the 36 positions, packed like the F(2x2) variant.  The stores are laid along the packed
 // rows: a workgroup owns RB rows x KB consecutive k of U (KB = 128: 8 rows, KB = 32: 32 rows), a thread 4 consecutive k of one
@@ -978,72 +975,10 @@ inline int fwd_ksplit(long long T, int cin, int cout, int tile) {
   return tile == 4 && out4_on(cout) ? fsd_conv::batched_ksplit(T, cin, cout, npos(tile)) : 1;
 }
 
-#ifdef FSD_EXPERIMENTS
-// The fused position-GEMM + output-transform kernel (wino4_gemm_out_kernel) can take the F(4x4) layers with 64 / 128 input
-// channels under the split arithmetic.  EXPERIMENTAL, off by default (FSD_WINO_FUSED=1 or fsd_wino_fused_mode(1) turns it on):
-// measured slower than the three launches it replaces, see the kernel's comment.
-std::atomic<int> g_fused_mode{-1};      // -1: not yet read from the environment
-inline int fused_mode() {
-  int m = g_fused_mode.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char* env = FSD_TUNE("FSD_WINO_FUSED");
-    m = env && (env[0] == '1' || env[0] == '2') ? env[0] - '0' : 0;
-    g_fused_mode.store(m, std::memory_order_relaxed);
-  }
-  return m;
-}
-inline bool fused_ok(int cin, int cout, int tile) {             // mode 1: operands from L1, all of M in LDS
-  return fused_mode() == 1 && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout >= kFusedCols &&
-         cout % kFusedCols == 0;
-}
-inline bool rowfused_ok(int cin, int cout, int tile) {          // mode 2: operands staged in LDS, M one transform row at a time
-  return fused_mode() == 2 && fsd_conv::f32_split_on() && tile == 4 && (cin == 64 || cin == 128) && cout % kRfCols == 0;
-}
-
-extern "C" int fsd_wino_fused_mode(int mode) {
-  const int prev = fused_mode();
-  if (mode >= 0 && mode <= 2) g_fused_mode.store(mode, std::memory_order_relaxed);
-  return prev;
-}
-
-// Tiles per slab of the forward / data-gradient pipeline (T = one pass).  OPT-IN: FSD_WINO_SLAB_MB = budget for a slab's V + M
-// in MB (default 0 = never slab); a multiple of 512 tiles (whole 256-row GEMM tiles and BatchNorm partial rows), slabs evened
-// out.  MEASURED SLOWER: 64 -> 128 at 104x104 0.66 ms in one pass, 0.79 / 1.04 / 1.56 ms with 160 / 96 / 48 MB slabs (8 / 13 / 25
-// of them); train step 25.5 -> 29.0 ms at 96 MB.  A slab's transforms are a few hundred workgroups -- too few to reach the
-// bandwidth the one-pass launches run at -- and that costs more than the memory-side cache gives back (copies inside 192 MB:
-// 6.8-7.0 TB/s against 4.7-5.3 beyond 384 MB, tools/probes/mall_probe.py).
-inline long long slab_tiles(long long T, int cin, int cout, int tile, bool has_vin) {
-  static const char* env = FSD_TUNE("FSD_WINO_SLAB_MB");
-  const long long budget = (env ? atoll(env) : 0) * 1000000LL;
-  if (budget <= 0 || tile != 4 || !out4_on(cout) || has_vin || fwd_ksplit(T, cin, cout, tile) > 1) return T;
-  const long long per_tile = 36LL * (cin + cout) * 4;
-  if (T * per_tile <= budget * 3 / 2) return T;
-  long long S = budget / per_tile / 512 * 512;
-  if (S < 512) S = 512;
-  const long long n = (T + S - 1) / S;
-  S = ((T + n - 1) / n + 511) / 512 * 512;
-  return S < T ? S : T;
-}
-
-#else
-inline bool fused_ok(int, int, int) { return false; }
-inline bool rowfused_ok(int, int, int) { return false; }
-inline long long slab_tiles(long long T, int, int, int, bool) { return T; }
-#endif
-
 extern "C" size_t fsd_wino_workspace_bytes(int batch, int height, int width, int cin, int cout, int tile) {
   const long long T = tiles_of(batch, height, width, tile);
   const int ks = fwd_ksplit(T, cin, cout, tile);
-  const size_t plain = (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + ks * pos_stride(T, cout)) * sizeof(float);
-  if (fused_ok(cin, cout, tile)) {    // the three bf16 planes of V (whole 32-tile blocks) and of U; no fp32 V, no M
-    const size_t fused = (size_t)npos(tile) * 3 * 2 * ((size_t)((T + 31) / 32 * 32) + round_up(cout, 128)) * cin;
-    return fused > plain ? fused : plain;      // (a caller that brings its own V takes the three-launch pipeline)
-  }
-  if (rowfused_ok(cin, cout, tile)) {   // fp32 V, then the three bf16 planes of U where M would be
-    const size_t rf = (size_t)npos(tile) * ((size_t)pos_stride(T, cin) * sizeof(float) + 3 * 2 * (size_t)round_up(cout, 128) * cin);
-    return rf > plain ? rf : plain;
-  }
-  return plain;
+  return (size_t)npos(tile) * (size_t)(pos_stride(T, cin) + ks * pos_stride(T, cout)) * sizeof(float);
 }
 
 extern "C" int fsd_wino_partial_rows(int batch, int height, int width, int tile) {
@@ -1091,88 +1026,10 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
   if (T * (long long)(cin > cout ? cin : cout) >= 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;   // 32-bit tile/channel indices
   const int P = npos(tile);
   const int rows_pad = round_up(cout, 128);
-#ifdef FSD_EXPERIMENTS
-  if (fused_ok(cin, cout, tile) && !v_in) {
-    // input transform -> bf16 planes in fragment order (+ the fp32 V for the weight gradient if asked); weights -> planes;
-    // position GEMMs + output transform in one kernel
-    const long long TB = (T + 31) / 32;
-    const long long v_plane = (long long)P * TB * 32 * cin, u_plane = (long long)P * rows_pad * cin;   // bf16 elements
-    unsigned short* v3 = reinterpret_cast<unsigned short*>(workspace);
-    unsigned short* u3 = v3 + 3 * v_plane;
-    {
-      fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width) + (v_keep ? 10.0 : 6.0) * cin * (double)P * T,
-                           stream);
-      const unsigned blocks = (unsigned)((TB * (cin / 8) + 3) / 4);
-      uint2* pl = reinterpret_cast<uint2*>(v3);
-#define FSD_INP(ACT, KEEP)                                                                                                   \
-  FSD_LAUNCH((wino4_input_planes_kernel<ACT, KEEP>), dim3(blocks), dim3(256), 0, stream, x, x_ld, v_keep, pl, v_plane / 4,    \
-             height, width, TH, TW, cin, T, in_scale, in_shift, in_slope)
-      if (in_scale) { if (v_keep) FSD_INP(true, true); else FSD_INP(true, false); }
-      else { if (v_keep) FSD_INP(false, true); else FSD_INP(false, false); }
-#undef FSD_INP
-    }
-    const int tpb = tiles_per_block(T);
-    const int group = tpb > kFusedTiles ? tpb : kFusedTiles;
-    FusedArgs a;
-    a.V3 = v3; a.U3 = u3; a.bias = bias; a.y = y; a.partial = bn_partial;
-    a.y_ld = y_ld; a.v_plane_elems = v_plane; a.plane_elems = u_plane; a.T = T;
-    a.H = height; a.W = width; a.TH = TH; a.TW = TW; a.N = cout; a.rows_pad = rows_pad; a.tpb = tpb;
-    a.slope = slope;
-    // issued MFMA work as for the position GEMMs it replaces; the transform's share of the time rides in the same class
-    fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * (double)T * cout * cin * P, stream);
-    FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
-               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin, 1);
-    const unsigned grid = (unsigned)((T + group - 1) / group);
-    static const char* nw_env = FSD_TUNE("FSD_WINO_FUSED_WAVES");        // tuning aid: 4 or 8 waves
-    const bool w8 = nw_env && nw_env[0] == '8';
-    auto go = [&](auto kern, int threads) -> int {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kFusedLds);
-      if (e != hipSuccess) return (int)e;
-      FSD_LAUNCH(kern, dim3(grid), dim3(threads), kFusedLds, stream, a);
-      return (int)hipGetLastError();
-    };
-    if (cin == 64) return w8 ? go(wino4_gemm_out_kernel<64, 8>, 512) : go(wino4_gemm_out_kernel<64, 4>, 256);
-    return w8 ? go(wino4_gemm_out_kernel<128, 8>, 512) : go(wino4_gemm_out_kernel<128, 4>, 256);
-  }
-#endif
   float* Vw = v_keep ? v_keep : reinterpret_cast<float*>(workspace);    // kept for the weight gradient if asked
   float* Mb = reinterpret_cast<float*>(workspace) + (size_t)P * pos_stride(T, cin);
   const long long n_in = T * (cin / 4);
   const float* V = v_in;                                                 // already transformed (fsd_wino_grad_transforms)
-  const long long S = slab_tiles(T, cin, cout, tile, v_in != nullptr);
-  (void)S;
-#ifdef FSD_EXPERIMENTS
-  if (S < T) {
-    // Slabs (opt-in, measured slower -- slab_tiles): transform -> position GEMMs -> transform for S tiles at a time.  V (36 x T x
-    // Cin floats) and M (36 x T x Cout) of the 104x104 / 52x52 layers are 0.6-1.2 GB per launch, each written by one kernel and
-    // read by the next -- from HBM, because the 256 MB memory-side cache has long been overwritten by then.  A slab's V + M fit
-    // it, and the M buffer is the same for every slab.
-    const int tpb = tiles_per_block(T);
-    const long long m_ps = pos_stride(S, cout);
-    for (long long t0 = 0; t0 < T; t0 += S) {
-      const long long cnt = T - t0 < S ? T - t0 : S;
-      {
-        fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)cnt * tile * tile + (double)P * cnt), stream);
-        const unsigned blocks = (unsigned)((cnt * (cin / 2) + 255) / 256);
-        if (in_scale)
-          FSD_LAUNCH(wino4_input_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, x_ld, Vw, height, width, TH, TW, cin, T,
-                     in_scale, in_shift, in_slope, t0, cnt);
-        else
-          FSD_LAUNCH(wino4_input_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, x_ld, Vw, height, width, TH, TW, cin, T,
-                     (const float*)nullptr, (const float*)nullptr, 1.f, t0, cnt);
-      }
-      int rc = fsd_conv::conv_gemm_batched(Vw + t0 * cin, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout,
-                                           m_ps, cnt, cin, cout, P, stream, 1, 0);
-      if (rc != 0) return rc;
-      fsd_prof::Scope prof_out(fsd_prof::kWinoXform, 4.0 * cout * ((double)cnt * tile * tile + (double)P * cnt), stream);
-      FSD_LAUNCH(wino4_output4_kernel<32>, dim3((unsigned)((cnt + tpb - 1) / tpb), (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb,
-                 bias, y, y_ld, bn_partial ? bn_partial + (t0 / tpb) * cout * 2 : nullptr, height, width, TH, TW, cout, t0 + cnt,
-                 tpb, slope, 1, 0LL, m_ps, t0);
-    }
-    return (int)hipGetLastError();
-  }
-#endif
   if (!V) {
     // algorithmic bytes of a transform: the activation once + the (tile+2)^2 transformed positions once
     fsd_prof::Scope prof(fsd_prof::kWinoXform, 4.0 * cin * ((double)batch * height * width + (double)P * T), stream);
@@ -1187,32 +1044,6 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                          height, width, TH, TW, cin, T, (const float*)nullptr, (const float*)nullptr, 1.f, 0LL, T);
     V = Vw;
   }
-#ifdef FSD_EXPERIMENTS
-  if (rowfused_ok(cin, cout, tile)) {
-    // weights -> row-major bf16 planes (into the space M would take); position GEMMs + output transform in one kernel
-    const long long u_plane = (long long)P * rows_pad * cin;
-    unsigned short* u3 = reinterpret_cast<unsigned short*>(Mb);
-    const int tpb = tiles_per_block(T);
-    const int group = tpb > kRfTiles ? tpb : kRfTiles;
-    RowFusedArgs a;
-    a.V = V; a.U3 = u3; a.bias = bias; a.y = y; a.partial = bn_partial;
-    a.y_ld = y_ld; a.ps_v = pos_stride(T, cin); a.plane_elems = u_plane; a.T = T;
-    a.H = height; a.W = width; a.TH = TH; a.TW = TW; a.N = cout; a.rows_pad = rows_pad; a.tpb = tpb;
-    a.slope = slope;
-    fsd_prof::Scope prof(fsd_prof::kGemmFwd, 2.0 * (double)T * cout * cin * P, stream);
-    FSD_LAUNCH(wino4_split_planes_kernel, dim3((unsigned)((u_plane / 4 + 255) / 256)), dim3(256), 0, stream, u_packed,
-               reinterpret_cast<uint2*>(u3), u_plane / 4, rows_pad, cin, 0);
-    const dim3 grid((unsigned)((T + group - 1) / group), (unsigned)(cout / kRfCols));
-    auto go = [&](auto kern) -> int {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kRfLds);
-      if (e != hipSuccess) return (int)e;
-      FSD_LAUNCH(kern, grid, dim3(256), kRfLds, stream, a);
-      return (int)hipGetLastError();
-    };
-    return cin == 64 ? go(wino4_rowfused_kernel<64>) : go(wino4_rowfused_kernel<128>);
-  }
-#endif
   const int ks = fwd_ksplit(T, cin, cout, tile);
   const long long ss = (long long)P * pos_stride(T, cout);          // slice s of every position lies behind slice s - 1 of all
   int rc = fsd_conv::conv_gemm_batched(V, cin, pos_stride(T, cin), u_packed, (long long)rows_pad * cin, Mb, cout, pos_stride(T, cout), T, cin, cout,
@@ -1226,12 +1057,6 @@ extern "C" int fsd_wino_conv3x3_fwd_ex(const float* x, long long x_ld, const flo
                        bn_partial, height, width, TH, TW, cout, T, tpb, slope);
   } else {
     const int cg = cout / 2;                                 // channel pairs
-#ifdef FSD_EXPERIMENTS
-    if (out4_on(cout) && ks > 1)
-      FSD_LAUNCH((wino4_output4_kernel<32, true>), dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
-                         bn_partial, height, width, TH, TW, cout, T, tpb, slope, ks, ss, pos_stride(T, cout), 0LL);
-    else
-#endif
     if (out4_on(cout))
       FSD_LAUNCH(wino4_output4_kernel<32>, dim3(bx, (cout / 4 + 31) / 32), dim3(256), 0, stream, Mb, bias, y, y_ld,
                          bn_partial, height, width, TH, TW, cout, T, tpb, slope, 1, 0LL, pos_stride(T, cout), 0LL);

@@ -117,29 +117,76 @@ class EpisodeTrainer(object):
         self.allreduce_wait_ms = [0.0] * len(self.buckets)
         self.time_allreduce = False
         self._neg_group = None
+        self.neg_counts = None               # (n_pos, n_rows) -> sums over the ranks; None: the local counts are the batch's
+        self._loss_modules = []
         if self.world_size > 1:
             self._install_global_neg_counts()
         self.sync_replicas()
 
     def _install_global_neg_counts(self):
         """neg_filter's keep ratio over the WHOLE batch, as the reference computes it on the gathered outputs
-        (region_loss.GLOBAL_NEG_COUNTS): two integers per step, summed over the ranks on a gloo group of their own -- host
-        tensors, so the call neither touches nor waits for a GPU stream (an .item() behind an RCCL all-reduce would drain the
-        two steps the trainer keeps in flight).  Every rank calls the loss once per step, in step order: the collective
-        matches up by construction."""
-        from . import region_loss
+        (region_loss.py:15-34 on train_meta.py:137-141): two integers per step, summed over the ranks on a gloo group of their
+        own -- host tensors, so the call neither touches nor waits for a GPU stream (an .item() behind an RCCL all-reduce would
+        drain the two steps the trainer keeps in flight).  The reducer is handed to the loss modules of THIS trainer's model
+        (`module.neg_counts`) and to nothing else; they call it only in training mode with gradients enabled.
+        CONTRACT: every rank calls its model's loss exactly once per training step, in step order -- the collective matches
+        up by construction.  close() (or the trainer's destruction) removes the reducer again."""
+        from .region_loss import _RegionBase
+        mods = [m for m in self.net.modules() if isinstance(m, _RegionBase)]
+        for m in mods:
+            if m.neg_counts is not None:
+                raise RuntimeError("this model's loss module already belongs to a live EpisodeTrainer (close() it first): two "
+                                   "trainers would pair their neg_filter collectives with each other")
+        group, err = None, None
         try:
-            self._neg_group = self.dist.new_group(backend="gloo")
-        except Exception as e:           # no gloo in this build / rendezvous without TCP: keep the per-rank ratio (documented)
-            print("EpisodeTrainer: global neg_filter ratio unavailable (%s); per-rank ratio" % e, file=sys.stderr)
+            group = self.dist.new_group(backend="gloo")
+        except Exception as e:           # no gloo in this build / rendezvous without TCP
+            err = e
+        # the fallback is a COLLECTIVE decision: a rank that could not build the group must not leave the others waiting in
+        # its all-reduce, and ranks must not mix the global with the per-rank ratio
+        ok = torch.tensor([0 if group is None else 1], dtype=torch.int32, device=self.flat.device)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            print("EpisodeTrainer: global neg_filter ratio unavailable on some rank (%s); every rank keeps its per-rank ratio"
+                  % (err,), file=sys.stderr)
+            if group is not None:
+                self.dist.destroy_process_group(group)
             return
+        self._neg_group = group
         buf = torch.zeros(2, dtype=torch.int64)
 
         def reduce_counts(n_pos, n_rows):
+            if self._neg_group is None:
+                raise RuntimeError("EpisodeTrainer.close() was called: this reducer is gone")
             buf[0], buf[1] = int(n_pos), int(n_rows)
             self.dist.all_reduce(buf, group=self._neg_group)
             return int(buf[0]), int(buf[1])
-        region_loss.GLOBAL_NEG_COUNTS = reduce_counts
+        self.neg_counts = reduce_counts
+        self._loss_modules = mods
+        for m in mods:
+            m.neg_counts = reduce_counts
+
+    def close(self):
+        """Give the model back: remove the whole-batch neg_filter reducer from its loss modules (they use the local ratio
+        again) and drop the host-side group.  Idempotent; call it on every rank before destroy_process_group()."""
+        for m in self._loss_modules:
+            if m.neg_counts is self.neg_counts:
+                m.neg_counts = None
+        self._loss_modules = []
+        self.neg_counts = None
+        group, self._neg_group = self._neg_group, None
+        if group is not None:
+            try:
+                if self.dist.is_initialized():
+                    self.dist.destroy_process_group(group)
+            except Exception:            # the default group is already gone: nothing left to free
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def sync_replicas(self):
         """Every replica starts from rank 0's parameters, momentum and BatchNorm running statistics (the reference's

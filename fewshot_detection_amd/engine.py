@@ -9,7 +9,7 @@ Here the same walk drives a small set of fused device ops:
   [reorg]              ->  space-to-depth straight into its slice of the concat buffer
   dynamic [convolutional] + 1x1 head  ->  ONE GEMM with the reweighting vectors folded into the
                                           head weights (the (B*N,1024,H,W) tensor never exists)
-  [globalmax]          ->  per-channel max over the support feature map
+  [globalmax] / [globalavg]  ->  per-channel max / mean over the support feature map
 
 A forward pass records a tape (views + per-channel statistics) that `backward` replays in reverse.
 """
@@ -440,6 +440,12 @@ class Network(object):
             elif kind == "globalmax":
                 vals, arg = ops.global_maxpool(x, want_argmax=True)
                 tape.append(dict(kind="globalmax", x=x, arg=arg))
+                result = vals.view(x.B, x.C, 1, 1)
+                x = None
+            elif kind in ("globalavg", "avgpool"):
+                # reference create_network maps both to GlobalAvgPool2d (darknet_meta.py:281-286 -> pooling.py:29-45)
+                vals = ops.global_avgpool(x)
+                tape.append(dict(kind="globalavg", x=x))
                 result = vals.view(x.B, x.C, 1, 1)
                 x = None
             elif kind in ("region", "cost"):

@@ -342,8 +342,9 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=
             raise ValueError("bf16 convolution needs a bf16 output view")
         y_ptr, y_ld = y.ptr, y.ld
     if bn_partial:
-        partial = torch.empty((L.fsd_conv2d_h_partial_rows(xv.B, xv.H, xv.W, xv.C, cout, ksize), cout, 2), dtype=torch.float32,
-                              device=dev)
+        # (the plan for THESE operands: a view with an odd pixel stride takes the GEMM kernel's row tiles)
+        partial = torch.empty((L.fsd_conv2d_h_partial_rows_at(xv.B, xv.H, xv.W, xv.C, cout, ksize, xv.ptr, xv.ld, y_ptr, y_ld),
+                               cout, 2), dtype=torch.float32, device=dev)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -465,6 +466,22 @@ def global_maxpool(xv, want_argmax=False):
     fn = lib().fsd_global_maxpool_fwd_h if xv.bf16 else lib().fsd_global_maxpool_fwd
     check(fn(xv.ptr, xv.ld, out.data_ptr(), _ptr(arg), xv.B, xv.H, xv.W, xv.C, _stream()), "fsd_global_maxpool_fwd")
     return out, arg
+
+
+def global_avgpool(xv):
+    """(B,H,W,C) view -> (B,C) float: the mean over the map (pooling.GlobalAvgPool2d, [globalavg] / [avgpool] blocks)."""
+    _plain(xv)
+    out = torch.empty((xv.B, xv.C), dtype=torch.float32, device=xv.t.device)
+    check(lib().fsd_global_avgpool_fwd(xv.ptr, 1 if xv.bf16 else 0, xv.ld, out.data_ptr(), xv.B, xv.H, xv.W, xv.C, _stream()),
+          "fsd_global_avgpool_fwd")
+    return out
+
+
+def global_avgpool_bwd(dout, xv):
+    dx = like_view(xv)
+    check(lib().fsd_global_avgpool_bwd(dout.contiguous().data_ptr(), dx.ptr, 1 if dx.bf16 else 0, dx.ld, xv.B, xv.H, xv.W, xv.C,
+                                       _stream()), "fsd_global_avgpool_bwd")
+    return dx
 
 
 def dynamic_conv(x, w):
@@ -812,19 +829,3 @@ def f32_gemm_mode(mode=None):
     operands, fp32-accurate; include/fsdet.h fsd_f32_gemm_mode).  Returns the previous mode; None only queries."""
     prev = lib().fsd_f32_gemm_mode(-1 if mode is None else {"native": 0, "split": 1}[mode])
     return "split" if prev else "native"
-
-
-def wino_fused_mode(on=None):
-    """EXPERIMENTAL: the fused position-GEMM + output-transform kernels for F(4x4) layers with 64 / 128 input channels
-    (include/fsdet.h fsd_wino_fused_mode): 0 off (default), 1 operands from L1 with all of M in LDS, 2 operands staged in LDS
-    with M resident one transform row at a time.  Returns the previous setting (int); None only queries.  Exists only in a
-    library built with -DFSD_EXPERIMENTS (both modes measured slower than the three launches); the default library raises."""
-    fn = getattr(lib(), "fsd_wino_fused_mode", None)
-    if fn is None:
-        raise RuntimeError("this libfsdet_hip.so was built without -DFSD_EXPERIMENTS: no fused Winograd pipeline")
-    return int(fn(-1 if on is None else int(on)))
-
-
-def experiments_built():
-    """True if the loaded library carries the experimental kernels (make EXTRA=-DFSD_EXPERIMENTS)."""
-    return hasattr(lib(), "fsd_wino_fused_mode")

@@ -26,13 +26,24 @@ class GlobalMaxPool2d(nn.Module):
 
 
 class GlobalAvgPool2d(nn.Module):
-    """Present for cfg compatibility ([globalavg] is commented out in cfg/reweighting_net.cfg)."""
+    """mean over the whole feature map: (B,C,H,W) -> (B,C,1,1)   (pooling.py:29-45, F.adaptive_avg_pool2d(x, 1)); the
+    [globalavg] / [avgpool] cfg blocks.  Inside a cfg network the engine calls the kernel on its NHWC view (forward and
+    backward); this module form serves direct callers."""
+
+    def __init__(self, stride=None, padding=0, dilation=1, return_indices=False, ceil_mode=False):
+        super(GlobalAvgPool2d, self).__init__()
+        self.stride = stride or 1
+        self.padding = padding
+        self.dilation = dilation
+        self.return_indices = return_indices
+        self.ceil_mode = ceil_mode
 
     def extra_repr(self):
         return "global avg pooling"
 
     def forward(self, input):
-        raise NotImplementedError("[globalavg] is not on the MI355X hot path (no shipped cfg uses it)")
+        vals = ops.global_avgpool(ops.nchw_to_nhwc(input, pad_to=1))
+        return vals.view(input.shape[0], input.shape[1], 1, 1)
 
 
 class Split(nn.Module):

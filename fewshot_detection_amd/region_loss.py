@@ -18,17 +18,20 @@ from .cfg import cfg
 
 
 # Data parallelism: the reference computes the keep ratio on the GATHERED batch (nn.DataParallel hands RegionLossV2 the outputs
-# of every replica, train_meta.py:137-141 -> region_loss.py:269), one process per GPU sees only its shard.  A trainer over
-# several ranks installs a reducer here -- (n_pos, n_rows) of this rank -> their sums over all ranks (dp.EpisodeTrainer: a
-# two-integer all-reduce on a host-side gloo group, off the GPU streams) -- so that every rank drops negatives with the
-# reference's probability 1 - neg_ratio * N_pos / N_neg of the whole batch.  None: the local counts are the batch's.
-GLOBAL_NEG_COUNTS = None
+# of every replica, train_meta.py:137-141 -> region_loss.py:269); one process per GPU sees only its shard.  A trainer over
+# several ranks therefore gives ITS model's loss module a reducer (`module.neg_counts`: (n_pos, n_rows) of this rank -> their
+# sums over all ranks; dp.EpisodeTrainer, a two-integer all-reduce on a host-side gloo group, off the GPU streams), so that
+# every rank drops negatives with the reference's probability 1 - neg_ratio * N_pos / N_neg of the whole batch.  The reducer is
+# a COLLECTIVE: it belongs to the one loss module the trainer owns, runs only for a training-mode call with gradients enabled
+# (every rank makes exactly one such call per step), and is removed by EpisodeTrainer.close().  Validation under
+# torch.no_grad() / .eval(), another model's loss and the free functions below never touch it.
 
 
-def neg_filter_indices(target_rows):
+def neg_filter_indices(target_rows, counts=None):
     """Host half of reference neg_filter (region_loss.py:15-34): which (image, class) rows keep
     their box/objectness loss.  `target_rows`: (R, L) array on the host.  python's global
-    `random()` is consumed once per negative row, in row order, exactly like the reference."""
+    `random()` is consumed once per negative row, in row order, exactly like the reference.
+    `counts`: optional reducer (n_pos, n_rows) -> the sums over the whole data-parallel batch."""
     n_rows = target_rows.shape[0]
     if cfg.neg_ratio == "full":
         return list(range(n_rows))
@@ -36,7 +39,7 @@ def neg_filter_indices(target_rows):
         raise NotImplementedError("neg_ratio not recognized")
     pos = (np.asarray(target_rows, dtype=np.float64).sum(axis=1) != 0).tolist()
     n_pos = sum(pos)
-    g_pos, g_rows = (n_pos, n_rows) if GLOBAL_NEG_COUNTS is None else GLOBAL_NEG_COUNTS(n_pos, n_rows)
+    g_pos, g_rows = (n_pos, n_rows) if counts is None else counts(n_pos, n_rows)
     if g_pos == g_rows:
         return list(range(n_rows))
     ratio = cfg.neg_ratio * g_pos * 1.0 / (g_rows - g_pos)
@@ -171,6 +174,7 @@ class _RegionBase(nn.Module):
         self.debug_targets = False      # tests: also emit build_targets' nine tensors
         self.last_targets = None
         self.last_keep = None
+        self.neg_counts = None          # data parallelism: whole-batch (n_pos, n_rows) reducer, owned by dp.EpisodeTrainer
 
     def stats(self):
         """(dict) loss parts + nGT / nCorrect / nProposals of the last call (synchronises)."""
@@ -187,7 +191,9 @@ class _RegionBase(nn.Module):
         if tr.shape[0] != rows:
             raise ValueError("target has %d rows, output has %d" % (tr.shape[0], rows))
         _validate_targets(tr, None if zero_tcls else (rows_per_image if softmax_over_rows else self.num_classes))
-        keep = neg_filter_indices(tr)
+        # the whole-batch ratio is a collective: only the training step's call takes part in it (see the note at the top)
+        counts = self.neg_counts if (self.training and torch.is_grad_enabled()) else None
+        keep = neg_filter_indices(tr, counts)
         keep_map = np.full(rows, -1, np.int32)
         keep_map[keep] = np.arange(len(keep), dtype=np.int32)
         dev = output.device

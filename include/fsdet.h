@@ -301,6 +301,12 @@ int fsd_reorg_fwd(const float* x, long long x_ld, float* out, long long out_ld, 
 /* GlobalMaxPool2d (pooling.py:8-27): (B,H,W,C) -> (B,C).  argmax (optional) records the pixel. */
 int fsd_global_maxpool_fwd(const float* x, long long x_ld, float* out, int* argmax, int batch,
                            int height, int width, int channels, hipStream_t stream);
+/* GlobalAvgPool2d (pooling.py:29-45, F.adaptive_avg_pool2d(x, 1); the [globalavg] / [avgpool] cfg block): (B,H,W,C) -> (B,C),
+ * fp64 sum over the map, one rounding.  x float (x_bf16 = 0) or bfloat16 bits (1).  _bwd: dx[b,p,c] = dout[b,c] / (H*W). */
+int fsd_global_avgpool_fwd(const void* x, int x_bf16, long long x_ld, float* out, int batch, int height, int width,
+                           int channels, hipStream_t stream);
+int fsd_global_avgpool_bwd(const float* dout, void* dx, int dx_bf16, long long dx_ld, int batch, int height, int width,
+                           int channels, hipStream_t stream);
 
 /* ---- channel-wise reweighting (dynamic_conv.py:125-164) ----------------------------------- */
 /* Materialising form, NCHW like the reference module: out[b*N+n, c, hw] = x[b, c, hw] * w[n, c]. */
@@ -383,6 +389,12 @@ int fsd_conv_row_tiles_h(long long pixels);          /* upper bound of the rows 
 /* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick; one
  * per workgroup of the persistent halo kernel of the 32 -> 64 / 64 -> 32 3x3 layers, conv_halo_h.hip) */
 int fsd_conv2d_h_partial_rows(int batch, int height, int width, int cin, int cout, int ksize);
+/* ... for exactly these operands: the halo-staged kernel additionally needs 16-byte aligned pixel rows on both sides
+ * (x_ld % 8 == 0, y_ld % 8 == 0, aligned base pointers); a launch whose strides it cannot take runs on the implicit-GEMM
+ * kernel and fills one row per 128-row tile.  fsd_conv2d_fwd[_act]_h follows the same rule, so a bn_partial array sized by
+ * this query is always the one the launch fills (with the default dense views both queries agree). */
+int fsd_conv2d_h_partial_rows_at(int batch, int height, int width, int cin, int cout, int ksize, const void* x_bf16,
+                                 long long x_ld, const void* y, long long y_ld);
 /* which tile fsd_conv2d_fwd_h will run this layer on: 0 = 128x128 (4 waves, two workgroups per CU), 1 = 256x256,
  * 2 = 192x256, 3 = 256x128 (8 waves, one workgroup per CU), 4 = 128x64, 5 = 128x32, 6 = 192x128 (4 waves, two workgroups
  * per CU).  Tests assert through it that the timed shapes really take the tiles they are meant to; FSD_CONV_H_TILE=0..6
@@ -493,15 +505,6 @@ int fsd_clock_probe(float* scratch, int iters, double* mhz_out, hipStream_t stre
  * captured earlier replays the arithmetic it was captured in (the Python layer keys its inference graphs on the mode); the
  * first use reads the environment variable FSD_F32_SPLIT (0 / 1). */
 int fsd_f32_gemm_mode(int mode);
-
-#ifdef FSD_EXPERIMENTS
-/* Only in a library built with -DFSD_EXPERIMENTS (make EXTRA=-DFSD_EXPERIMENTS); the default library does not export it.
- * F(4x4) layers with 64 / 128 input channels under the split arithmetic run the 36 position GEMMs and the output transform in
- * ONE kernel (mode 1: operands as bf16 planes from L1, all of M in LDS; mode 2: operands staged in LDS, M one transform row at a
- * time).  Same results to fp32 round-off; both measured slower than the three launches they replace.
- * mode 0 / 1 / 2 sets, anything else queries; returns the previous mode.  The workspace size follows the mode. */
-int fsd_wino_fused_mode(int mode);
-#endif
 
 const char* fsd_version(void);
 

@@ -156,6 +156,15 @@ def test_replicas_start_from_rank0_state_and_bucket_order_is_enforced(tmp_path):
     assert torch.load(os.path.join(str(tmp_path), "order0.pt")) and torch.load(os.path.join(str(tmp_path), "order1.pt"))
 
 
+class _TinyWithLoss(_Tiny):
+    """A replica that owns a region-loss module, like darknet_meta.Darknet (models[-1])."""
+
+    def __init__(self):
+        super().__init__()
+        from fewshot_detection_amd.region_loss import RegionLossV2
+        self.loss = RegionLossV2(1, [1.0, 1.0], 1)
+
+
 def _neg_worker(rank, world, port, out_dir):
     import random
     import numpy as np
@@ -165,35 +174,68 @@ def _neg_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    EpisodeTrainer(_Tiny(), 0.001, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
-    assert region_loss.GLOBAL_NEG_COUNTS is not None
+    net, other = _TinyWithLoss(), _TinyWithLoss()
+    tr = EpisodeTrainer(net, 0.001, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
+    # the reducer belongs to THIS trainer's loss module and to nothing else (no process-global hook)
+    assert tr.neg_counts is not None and net.loss.neg_counts is tr.neg_counts and other.loss.neg_counts is None
+    assert not hasattr(region_loss, "GLOBAL_NEG_COUNTS")
     # rank 0: 2 positive rows of 10; rank 1: 6 of 10 -> the batch: 8 positive, 12 negative
     rows = np.zeros((10, 250))
     rows[:2 if rank == 0 else 6, 1] = 0.5
-    assert region_loss.GLOBAL_NEG_COUNTS(int((rows.sum(1) != 0).sum()), 10) == (8, 20)
+    assert tr.neg_counts(int((rows.sum(1) != 0).sum()), 10) == (8, 20)
     keep = cfg.neg_ratio
     try:
         cfg.neg_ratio = 1                      # ratio = 8 / 12 everywhere (per rank it would be 2/8 and 6/4 -> "keep all")
         random.seed(100 + rank)
-        inds = region_loss.neg_filter_indices(rows)
+        inds = region_loss.neg_filter_indices(rows, tr.neg_counts)
         random.seed(100 + rank)
         n_pos = 2 if rank == 0 else 6
         want = [i for i in range(10) if i < n_pos or not (random.random() > 8.0 / 12.0)]
         assert inds == want, (rank, inds, want)
         cfg.neg_ratio = 2                      # 2 * 8 / 12 >= 1: every rank keeps every row
-        assert region_loss.neg_filter_indices(rows) == list(range(10))
+        assert region_loss.neg_filter_indices(rows, tr.neg_counts) == list(range(10))
         cfg.neg_ratio = "full"                 # no collective, no change
-        assert region_loss.neg_filter_indices(rows) == list(range(10))
+        assert region_loss.neg_filter_indices(rows, tr.neg_counts) == list(range(10))
+        # a free-standing call (rank-0-only validation, another model's loss, utils callers) is NOT a collective: it uses
+        # the shard's own ratio and cannot block -- only rank 0 makes this call
+        cfg.neg_ratio = 1
+        if rank == 0:
+            random.seed(7)
+            local = region_loss.neg_filter_indices(rows)
+            random.seed(7)
+            assert local == [i for i in range(10) if i < 2 or not (random.random() > 2.0 / 8.0)]
+        # a second live trainer on the same model would pair its collectives with the first one's: refused
+        try:
+            EpisodeTrainer(net, 0.001, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
+            raise AssertionError("a second live trainer was accepted")
+        except RuntimeError as e:
+            assert "live EpisodeTrainer" in str(e)
+        # close(): the model's loss is back on the local ratio, the reducer is dead, a new trainer may take the model
+        reducer = tr.neg_counts
+        tr.close()
+        tr.close()                             # idempotent
+        assert net.loss.neg_counts is None and tr.neg_counts is None
+        try:
+            reducer(1, 2)
+            raise AssertionError("the reducer outlived its trainer")
+        except RuntimeError:
+            pass
+        tr2 = EpisodeTrainer(net, 0.001, 0.9, 0.0, process_group=dist, n_buckets=2, step_fn=lambda lo, hi: None)
+        assert net.loss.neg_counts is tr2.neg_counts and tr2.neg_counts(1, 10) == (2, 20)
+        tr2.close()
     finally:
         cfg.neg_ratio = keep
     open(os.path.join(out_dir, "neg%d.ok" % rank), "w").write("ok")
     dist.destroy_process_group()
+    tr2.close()                                # after the default group is gone: still harmless
 
 
 def test_neg_filter_ratio_is_the_gathered_batchs_under_data_parallelism(tmp_path):
     """The reference drops negative (image, class) rows with probability 1 - neg_ratio * n_pos / n_neg of the batch that
     nn.DataParallel GATHERS (region_loss.py:15-34 on train_meta.py:137-141's outputs).  With one process per GPU the trainer
-    sums the two counts over the ranks (host-side gloo group): every rank uses the batch's ratio, not its shard's."""
+    sums the two counts over the ranks (host-side gloo group): every rank uses the batch's ratio, not its shard's.  The
+    reducer is owned by the trainer (VERDICT r5 / ADVICE r5): scoped to its model's loss module, removed by close(), a second
+    live trainer refused, free-standing neg_filter calls local."""
     port = _free_port()
     mp.spawn(_neg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "neg%d.ok" % r)) for r in (0, 1))

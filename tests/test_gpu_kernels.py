@@ -63,7 +63,7 @@ def test_first_layer_conv_matches_fp64_reference(dev, B, H, W, cin, cout, bias):
     x = torch.zeros(B, 4, H, W)
     x[:, :cin] = torch.randn(B, cin, H, W, generator=g)
     if cin == 3:
-        x[:, 3] = 7.0                                      # the padding channel must not leak into the result
+        x[:, 3] = float("nan")                             # the padding channel must not leak into the result (not even as 0 * NaN)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     b = torch.randn(cout, generator=g) if bias else None
     ref = F.conv2d(x[:, :cin].double(), w.double(), None if b is None else b.double(), 1, 1).float()
@@ -91,7 +91,7 @@ def test_first_layer_split_kernel_matches_fp64_reference(dev, B, H, W, cin, cout
     x = torch.zeros(B, 4, H, W)
     x[:, :cin] = torch.rand(B, cin, H, W, generator=g) * 2 - 0.5
     if cin < 4:
-        x[:, cin:] = 7.0                                   # padding channels must not leak into the result
+        x[:, cin:] = float("nan")                          # padding channels must not leak into the result (not even as 0 * NaN)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     b = torch.randn(cout, generator=g) if bias else None
     ref = F.conv2d(x[:, :cin].double(), w.double(), None if b is None else b.double(), 1, 1)
@@ -194,6 +194,47 @@ def test_reorg_globalmax_dynamic_conv(dev):
     out = ops.dynamic_conv(torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["w"]).to(dev))
     assert torch.equal(out.cpu(), torch.from_numpy(d["out"]))
     assert torch.equal(out.cpu(), reweight(torch.from_numpy(d["x"]), torch.from_numpy(d["w"])))
+
+
+def test_global_avg_pool_module_and_cfg_block_forward_backward(dev, tmp_path):
+    """pooling.GlobalAvgPool2d (pooling.py:29-45, F.adaptive_avg_pool2d(x, 1)) and the [globalavg] cfg block the reference's
+    reweighting_net.cfg keeps as the commented-out alternative of [globalmax]: module form, and a reweighting net that ends in
+    [globalavg] through meta_forward + backward against the oracle (fp32) -- VERDICT r5 #8 (was NotImplementedError)."""
+    from fewshot_detection_amd import ops
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from fewshot_detection_amd.pooling import GlobalAvgPool2d
+    from oracle.net import OracleDarknet
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 10, 7, 7, generator=g)
+    ref = F.adaptive_avg_pool2d(x.double(), 1)
+    got = GlobalAvgPool2d()(x.to(dev)).cpu()
+    assert got.shape == (3, 10, 1, 1) and float((got.double() - ref).abs().max()) < 1e-7
+    xb = x.to(torch.bfloat16)
+    vb = ops.View(xb.permute(0, 2, 3, 1).reshape(3 * 49, 10).contiguous().to(dev), 3, 7, 7, 10)
+    assert float((ops.global_avgpool(vb).cpu().double() - xb.double().mean(dim=(2, 3))).abs().max()) < 1e-6
+    # a reweighting net ending in [globalavg]
+    rw = open(os.path.join(GOLD, "mini_reweight.cfg")).read()
+    assert "[globalmax]" in rw
+    path = os.path.join(str(tmp_path), "mini_reweight_avg.cfg")
+    open(path, "w").write(rw.replace("[globalmax]", "[globalavg]"))
+    dyn_cfg = os.path.join(GOLD, "mini_dynamic.cfg")
+    torch.manual_seed(6)
+    ora = OracleDarknet(dyn_cfg, path).train()
+    net = Darknet(dyn_cfg, path)
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train()
+    metax, mask = torch.rand(3, 3, 160, 160, generator=g), (torch.rand(3, 1, 160, 160, generator=g) > 0.5).float()      # 5x5 / 2x2 final map
+    out = net.meta_forward(metax.to(dev), mask.to(dev))[0]
+    want = ora.meta_forward(metax, mask)[0]
+    assert out.shape == want.shape and float((out.detach().cpu() - want.detach()).abs().max()) < 1e-4
+    go = torch.randn(want.shape, generator=g)
+    out.backward(go.to(dev))
+    want.backward(go)
+    named = dict(ora.named_parameters())
+    for name, p in net.named_parameters():
+        if name.startswith("learnet_models"):
+            gr = named[name].grad
+            assert float((p.grad.cpu() - gr).abs().max()) <= 2e-4 * max(1e-3, float(gr.abs().max())), name
 
 
 def test_fused_reweight_head_equals_materialised_path(dev):

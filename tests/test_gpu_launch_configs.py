@@ -1,0 +1,243 @@
+"""End-to-end parity at EVERY launch configuration bench.py times or a SCALE run launches -- not only the B=64 headline.
+
+Tile plans, persistent-workgroup counts, split-K plans and the 8-wave thresholds of the kernels all depend on B*H*W, so a
+shape that is only ever timed runs a composition of kernel variants nobody compared with the oracle.  The cases below are the
+shapes of bench.py's `other_configs()` (BASELINE configs[3] at B=32 / N=20 / neg_ratio=0, configs[4]'s 64 x 608x608 / N=80
+episode), the metric-string episode, and what each rank of a strong-scaling run at 2 / 4 / 8 GPUs launches (B = 32 / 16 / 8
+queries 416x416 + all 20 supports 224x224) -- each as a whole episode against the CPU oracle (reference:
+darknet_meta.py:107-195, region_loss.py:252-366; batch shapes cfg.py:106-115, dataset.py:223-245,348), in fp32 and, for the
+bf16 storage mode, against oracle/net.py::_walk_bf16 (end to end) and block by block on identical inputs at the same batch.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MASKS = ["coord_mask", "conf_mask", "cls_mask", "tx", "ty", "tw", "th", "tconf", "tcls"]
+
+# id, B, N, S, Sm, neg_ratio
+SHAPES = [
+    ("metric_string_B64", 64, 20, 416, 224, 1),
+    ("configs3_C4_B32", 32, 20, 416, 416, 0),
+    ("configs4_C5_B64_608", 64, 80, 608, 416, 1),
+    ("strong_rank_of_2_B32", 32, 20, 416, 224, 1),
+    ("strong_rank_of_4_B16", 16, 20, 416, 224, 1),
+    ("strong_rank_of_8_B8", 8, 20, 416, 224, 1),
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cfg_paths(tmp_path_factory):
+    from fewshot_detection_amd import cfgs
+    return cfgs.write_standard_cfgs(str(tmp_path_factory.mktemp("cfgs")))
+
+
+def _host_gib():
+    try:
+        return os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
+    except (ValueError, OSError):
+        return 64.0
+
+
+def _episode(seed, B, N, S, Sm):
+    """bench.py's synth_episode: uniform images, one rectangle per support mask, 1-5 boxes per image."""
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    x = torch.rand(B, 3, S, S, generator=g)
+    metax = torch.rand(N, 3, Sm, Sm, generator=g)
+    mask = torch.zeros(N, 1, Sm, Sm)
+    for n in range(N):
+        y0, x0 = rng.randint(0, Sm // 2, 2)
+        h, w = rng.randint(Sm // 8, Sm // 2, 2)
+        mask[n, 0, y0:y0 + h, x0:x0 + w] = 1
+    tgt = np.zeros((B, N, 250), np.float64)
+    fill = np.zeros((B, N), np.int64)
+    for b in range(B):
+        for _ in range(rng.randint(1, 6)):
+            n = rng.randint(0, N)
+            w, h = rng.uniform(0.05, 0.5, 2)
+            cx = float(np.clip(rng.uniform(0.1, 0.9), w / 2, 0.999 - w / 2))
+            cy = float(np.clip(rng.uniform(0.1, 0.9), h / 2, 0.999 - h / 2))
+            t = fill[b, n]
+            tgt[b, n, 5 * t:5 * t + 5] = [n, cx, cy, w, h]
+            fill[b, n] += 1
+    return x, metax, mask, torch.from_numpy(tgt)
+
+
+def _models(cfg_paths, dev, dtype, seed):
+    from fewshot_detection_amd.darknet_meta import Darknet
+    from oracle.net import OracleDarknet
+    torch.manual_seed(seed)
+    ora = OracleDarknet(cfg_paths[0], cfg_paths[1]).train()
+    net = Darknet(cfg_paths[0], cfg_paths[1])
+    net.load_state_dict(ora.state_dict())
+    net = net.to(dev).train().set_compute_dtype(dtype)
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    region.debug_targets = True
+    region.seen = 20000
+    return ora, net, region
+
+
+def _loss_on_identical_inputs(region, out_cpu, tgt, anchors, neg, loss_hip, stats, got_t, keep_hip):
+    """RegionLossV2 of the HIP network's OWN output through the oracle: selection, statistics and every build_targets tensor
+    bit-exact, loss within fp32 round-off."""
+    from oracle.region import region_loss_v2
+    random.seed(5)
+    r2 = region_loss_v2(out_cpu.clone(), tgt, anchors, seen=20000, neg_ratio=neg)
+    assert list(keep_hip) == list(r2["keep"])
+    assert (stats["nGT"], stats["nCorrect"], stats["nProposals"]) == (r2["nGT"], r2["nCorrect"], r2["nProposals"])
+    for i, k in enumerate(MASKS):
+        want = r2["targets"][k]
+        if k in ("coord_mask", "conf_mask", "cls_mask", "tcls", "tx", "ty"):
+            assert np.array_equal(got_t[i], want), k
+        else:
+            assert np.allclose(got_t[i], want, rtol=1e-5, atol=1e-6), k
+    l2 = float(r2["loss"].detach())
+    assert abs(loss_hip - l2) <= 1e-4 * max(1.0, abs(l2)), (loss_hip, l2)
+
+
+@pytest.mark.parametrize("name,B,N,S,Sm,neg", SHAPES, ids=[s[0] for s in SHAPES])
+def test_fp32_episode_vs_oracle_at_every_timed_launch_configuration(dev, cfg_paths, name, B, N, S, Sm, neg):
+    from fewshot_detection_amd.cfg import cfg
+    from oracle.region import region_loss_v2
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    if S == 608 and _host_gib() < 96:       # the oracle's autograd graph of 64 x 608x608 needs ~40 GiB of host memory
+        B = 16
+    ora, net, region = _models(cfg_paths, dev, "f32", 50 + B)
+    x, metax, mask, tgt = _episode(2000 + N + B, B, N, S, Sm)
+    keep_neg = cfg.neg_ratio
+    cfg.neg_ratio = neg
+    try:
+        random.seed(5)
+        out = net(x.to(dev), metax.to(dev), mask.to(dev))
+        loss = region(out, tgt)
+        loss.backward()
+        out_cpu, loss_hip = out.detach().cpu(), float(loss.detach())
+        got_t, stats, keep_hip = region.last_targets.cpu().numpy(), region.stats(), list(region.last_keep)
+        # (1) the whole network against the oracle's fp32 forward, the loss end to end, the surviving rows
+        ref = ora(x, metax, mask)
+        random.seed(5)
+        r = region_loss_v2(ref, tgt, ora.region.anchors, seen=20000, neg_ratio=neg)
+        r["loss"].backward()
+        ref_loss = float(r["loss"].detach())
+        fwd_err = float((out_cpu - ref.detach()).abs().max())
+        print("%s (B=%d N=%d %dx%d, supports %dx%d, neg=%s): forward max|diff| %.3e (max|out| %.2f), loss %.4f vs oracle %.4f, "
+              "%d of %d rows kept" % (name, B, N, S, S, Sm, Sm, neg, fwd_err, float(ref.detach().abs().max()), loss_hip, ref_loss,
+                                      len(keep_hip), B * N))
+        assert out.shape == (B * N, 30, S // 32, S // 32)
+        assert fwd_err < 1e-3
+        assert abs(loss_hip - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
+        assert keep_hip == list(r["keep"])
+        # (2) the loss kernel on identical inputs
+        _loss_on_identical_inputs(region, out_cpu, tgt, ora.region.anchors, neg, loss_hip, stats, got_t, keep_hip)
+        # (3) the tensors right below the loss carry no flipped leaky / pooling winners: 1e-4 of their largest element
+        named, mine = dict(ora.named_parameters()), dict(net.named_parameters())
+        for pname in ("models.31.conv24.weight", "models.31.conv24.bias", "models.29.bn22.weight"):
+            gm, gr = mine[pname].grad.cpu(), named[pname].grad
+            assert float((gm - gr).abs().max()) / float(gr.abs().max()) < 1e-4, pname
+        # every other parameter: direction and size (the element-wise statement is the teacher-forced per-block test)
+        worst = min(float(torch.dot(p.grad.cpu().double().flatten(), named[n_].grad.double().flatten())
+                          / (p.grad.double().norm().cpu() * named[n_].grad.double().norm() + 1e-300)) for n_, p in mine.items())
+        assert worst > 0.999, worst
+    finally:
+        cfg.neg_ratio = keep_neg
+        del net, ora
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,B,N,S,Sm,neg", SHAPES, ids=[s[0] for s in SHAPES])
+def test_bf16_mode_episode_vs_its_restatement_at_every_timed_launch_configuration(dev, cfg_paths, name, B, N, S, Sm, neg):
+    """The bf16 twins: the whole episode against oracle/net.py::_walk_bf16 (this repository's definition of the storage
+    mode; bounds from profiles/r06_bf16_error_growth.md), every layer on the bf16 kernels, and the fp32 loss kernel on
+    identical inputs bit-exact."""
+    from fewshot_detection_amd.cfg import cfg
+    from oracle.region import region_loss_v2
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ora, net, region = _models(cfg_paths, dev, "bf16", 70 + B)
+    x, metax, mask, tgt = _episode(3000 + N + B, B, N, S, Sm)
+    keep_neg = cfg.neg_ratio
+    cfg.neg_ratio = neg
+    try:
+        random.seed(5)
+        out = net(x.to(dev), metax.to(dev), mask.to(dev))
+        assert net._det.fallback_convs == 0 and net._meta.fallback_convs == 0
+        loss = region(out, tgt)
+        loss.backward()
+        out_cpu, loss_hip = out.detach().cpu(), float(loss.detach())
+        got_t, stats, keep_hip = region.last_targets.cpu().numpy(), region.stats(), list(region.last_keep)
+        with torch.no_grad():
+            ref, _ = ora.forward_bf16(x, metax, mask)
+        random.seed(5)
+        r = region_loss_v2(ref, tgt, ora.region.anchors, seen=20000, neg_ratio=neg)
+        rel = float((out_cpu - ref).norm() / ref.norm())
+        ref_loss = float(r["loss"].detach())
+        print("%s bf16 (B=%d N=%d %dx%d): forward rel-L2 vs _walk_bf16 %.3e, loss %.4f vs %.4f"
+              % (name, B, N, S, S, rel, loss_hip, ref_loss))
+        assert out.shape == ref.shape and rel < 0.15
+        assert abs(loss_hip - ref_loss) < 1e-2 * max(1.0, abs(ref_loss))
+        assert keep_hip == list(r["keep"])
+        _loss_on_identical_inputs(region, out_cpu, tgt, ora.region.anchors, neg, loss_hip, stats, got_t, keep_hip)
+        for p in net.parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all())
+    finally:
+        cfg.neg_ratio = keep_neg
+        del net, ora
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B,S", [(64, 416), (32, 416), (16, 416), (8, 416), (64, 608)])
+def test_bf16_blocks_on_identical_inputs_at_the_timed_batches(dev, cfg_paths, B, S):
+    """Every conv + BatchNorm + leaky (+ pool) block of darknet_dynamic.cfg in bf16 storage mode at the batch sizes that are
+    timed, each fed the oracle's (bf16-valued) input of that block (the B=2 form of this check is in test_gpu_bf16.py): the
+    persistent halo kernels, the 8-wave tiles and the split plans these batches select against _conv_block_bf16, one bf16 ulp."""
+    from fewshot_detection_amd import ops
+    from oracle import net as onet
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    ora, net, _ = _models(cfg_paths, dev, "bf16", 90 + B)
+    eng = net._det
+    eng._record = False
+    xx = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(91 + B))
+    outs = {}
+    worst = 0.0
+    with torch.no_grad():
+        for idx, blk in enumerate(ora.blocks[1:]):
+            kind = blk["type"]
+            if kind == "route":
+                src = [int(v) if int(v) > 0 else int(v) + idx for v in blk["layers"].split(",")]
+                xx = outs[src[0]] if len(src) == 1 else torch.cat([outs[s] for s in src], 1)
+            elif kind == "convolutional" and onet.is_dynamic(blk):
+                break
+            elif kind == "convolutional":
+                ref = onet._conv_block_bf16(ora.models[idx], xx, True)
+                if xx.shape[1] <= 4:
+                    xin = ops.nchw_to_nhwc(xx.to(dev))
+                else:                           # (B,C,H,W) float, bf16-representable -> bf16 NHWC view on the device
+                    b_, c_, h_, w_ = xx.shape
+                    xin = ops.View(xx.permute(0, 2, 3, 1).reshape(b_ * h_ * w_, c_).contiguous().to(dev).to(torch.bfloat16),
+                                   b_, h_, w_, c_)
+                z, _ = eng._conv(idx, blk, xin, True, 0, {}, [])
+                got = z.t[:, z.c0:z.c0 + z.C].float().reshape(z.B, z.H, z.W, z.C).permute(0, 3, 1, 2).contiguous().cpu()
+                d = (got - ref).abs()
+                rel = float((got - ref).norm() / ref.norm())
+                assert float(d.max()) <= 2.0 ** -7 * float(ref.abs().max()) * 1.5, (idx, float(d.max()), float(ref.abs().max()))
+                assert rel < 3e-4, (idx, rel)
+                worst = max(worst, rel)
+                xx = ref
+                del got, d, z, xin
+            else:
+                xx = ora.models[idx](xx)
+            outs = {k: v for k, v in outs.items() if k >= idx - 12}       # the routes reach back 9 layers at most
+            outs[idx] = xx
+    print("bf16 blocks on identical inputs, B=%d %dx%d: worst relative L2 %.2e" % (B, S, S, worst))
+    del net, ora
+    torch.cuda.empty_cache()

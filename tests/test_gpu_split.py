@@ -196,51 +196,3 @@ def test_positions_of_at_most_32_rows_take_the_32x128_tile(dev):
     assert plan(2, 13, 13, 1024, 64) == (64, 64, 1)
     ops.f32_gemm_mode("native")
     assert plan(2, 13, 13, 1024, 1024) == (64, 64, 1)
-
-
-@pytest.mark.parametrize("shape", [
-    (2, 40, 40, 64, 128),      # 200 tiles: BatchNorm partial rows of 8 tiles, four per workgroup
-    (5, 100, 96, 64, 128),     # 3000 tiles: rows of 16 tiles, ragged last workgroup
-    (10, 176, 160, 64, 32),    # 17600 tiles: rows of 64 tiles = one workgroup in two halves
-    (3, 28, 52, 128, 64),      # 128-channel reduction (two 64-k stages per position), ragged maps (7 x 13 tiles)
-])
-def test_experimental_fused_winograd_pipeline_matches_the_three_launches(dev, shape):
-    """fsd_wino_fused_mode(1): input transform -> bf16 operand planes -> one kernel for the 36 position GEMMs and the output
-    transform (csrc/winograd.hip, wino4_gemm_out_kernel; off by default).  Same contract as the three-launch pipeline: output
-    (+ bias, leaky), the kept V of the weight gradient, the BatchNorm partial sums."""
-    from fewshot_detection_amd import ops
-    if not ops.experiments_built():
-        pytest.skip("libfsdet_hip.so built without -DFSD_EXPERIMENTS (the default): the fused kernels are not in it")
-    B, H, W, cin, cout = shape
-    ops.f32_gemm_mode("split")
-    torch.manual_seed(sum(shape))
-    xn = torch.randn(B, cin, H, W, device=dev)
-    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
-    bias = torch.randn(cout, device=dev)
-    ref = F.conv2d(xn.double(), w.double(), None, 1, 1)
-    x = ops.nchw_to_nhwc(xn)
-    u = ops.pack_weight_wino(w, 0, 4)
-    res = {}
-    before = ops.wino_fused_mode()
-    try:
-        for fused in (0, 1, 2):
-            ops.wino_fused_mode(fused)
-            assert ops.wino_fused_mode() == fused
-            if fused == 2 and cout % 64:
-                continue
-            keep = []
-            y, part = ops.conv3x3_wino(x, u, cout, bn_partial=True, keep_v=keep, tile=4)
-            ya, _ = ops.conv3x3_wino(x, u, cout, bias=bias, tile=4, slope=0.1)
-            res[fused] = (ops.nhwc_to_nchw(y), part.double().sum(0), keep[0].clone(), ops.nhwc_to_nchw(ya))
-    finally:
-        ops.wino_fused_mode(before)
-    for fused in sorted(res):
-        y, p, _, ya = res[fused]
-        assert _rel(y, ref) < 5e-5, (fused, _rel(y, ref))
-        flat = y.double().permute(1, 0, 2, 3).reshape(cout, -1)
-        assert torch.allclose(p[:, 0], flat.sum(1), rtol=1e-5, atol=1e-3)          # the sums are of the values written
-        assert torch.allclose(p[:, 1], (flat ** 2).sum(1), rtol=1e-5, atol=1e-3)
-        assert _rel(ya, F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.1)) < 5e-5
-    for fused in sorted(res)[1:]:
-        assert torch.equal(res[fused][2], res[0][2])                               # the kept V: the same transform, bit for bit
-        assert _rel(res[fused][0], res[0][0].double()) < 2e-6                      # two summation orders of the same products

@@ -19,17 +19,13 @@ import ref_shim  # noqa: E402
 def test_library_exports_every_declared_symbol():
     from fewshot_detection_amd import _lib
     header = open(os.path.join(ROOT, "include", "fsdet.h")).read()
-    default_part = re.sub(r"#ifdef FSD_EXPERIMENTS.*?#endif", "", header, flags=re.S)     # what the default build declares
-    declared = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", default_part))
-    experimental = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", header)) - declared
-    assert len(declared) >= 29 and experimental == set(_lib.EXPERIMENTAL_PROTOTYPES)
+    assert "#ifdef" not in header.replace("#ifdef __cplusplus", "")      # one ABI: no conditionally declared entry points
+    declared = set(re.findall(r"\b(fsd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 29
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     lib = _lib.lib()                                   # loads without a GPU (no compute calls here)
     for name in declared:
         assert hasattr(lib, name), name
-    from fewshot_detection_amd import ops
-    for name in experimental:                          # all of them or none (one build flag)
-        assert hasattr(lib, name) == ops.experiments_built(), name
     assert lib.fsd_version().startswith(b"fsdet-hip")
     assert lib.fsd_conv_row_tiles(1, 25, 40, 256, 64, 3) == 16 and lib.fsd_packed_weight_elems(30, 1024, 1) == 128 * 1024
 
@@ -349,41 +345,24 @@ def test_inference_can_pick_the_smaller_winograd_form_when_the_weights_are_the_t
     assert ops.wino_tile_inference(1024, 1024, 1, 13, 13, 2) == 0
 
 
-def test_winograd_workspace_follows_the_arithmetic_and_the_experimental_pipeline_switch():
-    """fsd_wino_workspace_bytes is host logic (no GPU): V + M of the three-launch pipeline; with the experimental fused pipeline
-    on (fsd_wino_fused_mode, split arithmetic, 64 / 128 input channels) at least the bf16 operand planes of V and U as well.
-    The switch reports the previous setting and only changes on 0 / 1."""
-    from fewshot_detection_amd import _lib, ops
+def test_winograd_workspace_is_the_three_launch_pipelines_in_both_arithmetics():
+    """fsd_wino_workspace_bytes is host logic (no GPU): V + M of the transform -> position GEMMs -> transform pipeline, the same
+    size under both arithmetics of the fp32 GEMMs.  (The fused-pipeline experiment of round 4 and its switch left the tree:
+    tools/experiments_r04/wino_fused.patch.)"""
+    from fewshot_detection_amd import _lib
     lib = _lib.lib()
     B, H, W, cin, cout = 64, 104, 104, 64, 128
     T = B * 26 * 26
     plain = 36 * T * (cin + cout) * 4
-    if not ops.experiments_built():                    # the default library: one pipeline, one size, in both arithmetics
-        split_before = lib.fsd_f32_gemm_mode(-1)
-        try:
-            for mode in (0, 1):
-                lib.fsd_f32_gemm_mode(mode)
-                assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
-        finally:
-            lib.fsd_f32_gemm_mode(split_before)
-        with pytest.raises(RuntimeError, match="FSD_EXPERIMENTS"):
-            ops.wino_fused_mode()
-        return
     split_before = lib.fsd_f32_gemm_mode(-1)
-    fused_before = lib.fsd_wino_fused_mode(-1)
     try:
-        lib.fsd_f32_gemm_mode(1)
-        assert lib.fsd_wino_fused_mode(0) == fused_before and lib.fsd_wino_fused_mode(7) == 0 and lib.fsd_wino_fused_mode(-1) == 0
-        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
-        assert lib.fsd_wino_fused_mode(1) == 0 and lib.fsd_wino_fused_mode(-1) == 1
-        planes = 36 * 3 * 2 * (T + 128) * cin                              # T is a multiple of 32; U rows padded to 128
-        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == max(plain, planes)
-        assert lib.fsd_wino_workspace_bytes(B, 13, 13, 1024, 1024, 4) == 36 * B * 16 * 2048 * 4     # not a fused shape
-        lib.fsd_f32_gemm_mode(0)                                           # the fused kernels are split-arithmetic kernels
-        assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
+        for mode in (0, 1):
+            lib.fsd_f32_gemm_mode(mode)
+            assert lib.fsd_wino_workspace_bytes(B, H, W, cin, cout, 4) == plain
+            assert lib.fsd_wino_workspace_bytes(B, 13, 13, 1024, 1024, 4) == 36 * B * 16 * 2048 * 4
     finally:
-        lib.fsd_wino_fused_mode(fused_before)
         lib.fsd_f32_gemm_mode(split_before)
+    assert not hasattr(lib, "fsd_wino_fused_mode")
 
 
 def test_a_constructed_model_pickles(tmp_path):

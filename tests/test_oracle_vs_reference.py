@@ -227,3 +227,13 @@ def test_region_loss_v2_live_sweep(seed):
         assert np.array_equal(r["targets"][k], ref[k]), k
     assert abs(float(r["loss"].detach()) - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
     assert np.allclose(o.grad.numpy(), ref["grad"], rtol=1e-5, atol=1e-6)
+
+
+@needs_ref
+def test_global_pools_match_live_reference_pooling():
+    """pooling.py:8-45: the oracle's [globalmax] / [globalavg] layers are the reference's GlobalMaxPool2d / GlobalAvgPool2d."""
+    from oracle.net import _GlobalAvg, _GlobalMax
+    ref = ref_shim.load("pooling")
+    x = torch.randn(3, 16, 6, 6, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(_GlobalMax()(x), ref.GlobalMaxPool2d()(x))
+    assert torch.equal(_GlobalAvg()(x), ref.GlobalAvgPool2d()(x))
