@@ -379,10 +379,18 @@ class Leg(object):
             self.fence()
         # untimed: let the caching allocator reach its steady state (tensors that cross streams are re-used only after the
         # GPU has passed them, so the pool keeps growing for some steps; a hipMalloc inside the timed region drains the
-        # device: one 39 ms step among 25 ms ones).  Extra steps until three in a row allocated nothing, at most 12.
+        # device: one 39 ms step among 25 ms ones).  Extra steps until a burst of them allocated nothing (below).
         self.settle_steps = 0
+        # The timed region runs with python's cyclic collector off (a full-heap pass in the middle of it stops the host for
+        # tens of ms).  The tape of a step holds reference cycles, so WITHOUT the collector the tensors of a finished step are
+        # released a little later than with it -- a different steady state of the caching allocator.  Round 5 switched the
+        # collector off AFTER the settle phase and paid 10-20 hipMallocs inside the timed region for it (tools/alloc_trace.py:
+        # all of them in the first steps after the switch).  Now the settle phase already runs in the timed region's regime.
+        gc.collect()
+        gc.disable()
         if warmup > 0 and self.dev.type == "cuda":
-            if prof_steps:                    # one step in the form of the profiled ones (one stream, per-launch events)
+            def prof_form_step():             # one step in the form of the profiled ones (one stream, per-launch events)
+                torch.cuda.synchronize()
                 ops.PROFILE = []
                 ops.kernel_profile(True)
                 streams.ENABLED = False
@@ -390,17 +398,27 @@ class Leg(object):
                 ops.PROFILE = None
                 ops.kernel_profile(False)
                 streams.ENABLED = streams_on
+                torch.cuda.synchronize()
                 ops.kernel_profile_collect()
                 self.settle_steps += 1
-            quiet, last = 0, torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            last = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            # Bursts of 4 free-running steps (the host as far ahead of the GPU as in the timed region -- a memory_stats() call
+            # per step would hold it back and settle a DIFFERENT regime), until a whole burst allocated nothing; at most 6.
             # (several ranks: a FIXED number of steps -- every step holds collectives, and the ranks' allocators need not
             # go quiet after the same number of them)
-            while (quiet < 3 and self.settle_steps < 12) if self.dist is None else self.settle_steps < 5:
-                step()
-                self.settle_steps += 1
+            bursts = 0
+            while bursts < (6 if self.dist is None else 2):
+                if prof_steps:                # (every burst follows one: the timed region's transition one-stream -> streams
+                    prof_form_step()          # is part of the regime being settled)
+                for _ in range(4):
+                    step()
+                self.settle_steps += 4
+                bursts += 1
                 now = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
-                quiet = quiet + 1 if now == last else 0
+                quiet = now == last
                 last = now
+                if quiet and self.dist is None:
+                    break
             self.fence()
         if self.opt is not None:
             self.opt.allreduce_wait_ms = [0.0] * len(self.opt.buckets)
@@ -411,10 +429,6 @@ class Leg(object):
         prof = []
         t_a = t_b = None
         ops.kernel_profile_collect()          # drop whatever an earlier leg left
-        # the per-launch event records create python objects: keep the cyclic collector from stopping the host for a
-        # full-heap pass in the middle of the timed region
-        gc.collect()
-        gc.disable()
         step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # per-step GPU time (diagnostic)
         step_ev[0].record()
         t0 = time.perf_counter()

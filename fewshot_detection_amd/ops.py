@@ -152,17 +152,26 @@ def nhwc_to_nchw(v):
     return out
 
 
-def pack_weight(w, mode=0, dtype="f32"):
-    """(Cout,Cin,k,k) -> packed K-major operand of fsd_conv2d_fwd[_bf16] (mode 0) / its data gradient (mode 1)."""
+def _reuse(out, numel, dtype, device):
+    """`out` if it is a buffer of exactly this size / type / device (a packed copy from an earlier step, rewritten in place:
+    the weights' readers are stream-ordered behind the optimizer step that precedes a re-pack), else a fresh one."""
+    if out is not None and out.numel() == numel and out.dtype == dtype and out.device == device:
+        return out
+    return torch.empty(numel, dtype=dtype, device=device)
+
+
+def pack_weight(w, mode=0, dtype="f32", out=None):
+    """(Cout,Cin,k,k) -> packed K-major operand of fsd_conv2d_fwd[_bf16] (mode 0) / its data gradient (mode 1).
+    out: the packed buffer of an earlier call for the same weight (rewritten in place: no allocator traffic per step)."""
     require_device(w)
     cout, cin, k, _ = w.shape
     rows, red = (cout, cin) if mode == 0 else (cin, cout)
     if dtype == "bf16":
-        out = torch.empty(lib().fsd_packed_weight_elems_bf16(rows, red, k), dtype=torch.bfloat16, device=w.device)
+        out = _reuse(out, lib().fsd_packed_weight_elems_bf16(rows, red, k), torch.bfloat16, w.device)
         check(lib().fsd_pack_conv_weight_bf16(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()),
               "fsd_pack_conv_weight_bf16")
         return out
-    out = torch.empty(lib().fsd_packed_weight_elems(rows, red, k), dtype=torch.float32, device=w.device)
+    out = _reuse(out, lib().fsd_packed_weight_elems(rows, red, k), torch.float32, w.device)
     check(lib().fsd_pack_conv_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()),
           "fsd_pack_conv_weight")
     return out
@@ -181,13 +190,14 @@ def pack_weight_bf16_pair(w, out=None):
     return out
 
 
-def pack_weight_wino(w, mode=0, tile=2):
-    """(Cout,Cin,3,3) -> the (tile+2)^2 transformed (G g G^T) matrices in the GEMM kernel's packed layout."""
+def pack_weight_wino(w, mode=0, tile=2, out=None):
+    """(Cout,Cin,3,3) -> the (tile+2)^2 transformed (G g G^T) matrices in the GEMM kernel's packed layout.
+    out: the buffer of an earlier call for the same weight (rewritten in place)."""
     require_device(w)
     cout, cin, k, _ = w.shape
     assert k == 3
     rows, red = (cout, cin) if mode == 0 else (cin, cout)
-    out = torch.empty(lib().fsd_wino_packed_weight_elems(rows, red, tile), dtype=torch.float32, device=w.device)
+    out = _reuse(out, lib().fsd_wino_packed_weight_elems(rows, red, tile), torch.float32, w.device)
     check(lib().fsd_wino_pack_weight(w.contiguous().data_ptr(), out.data_ptr(), cout, cin, mode, tile, _stream()),
           "fsd_wino_pack_weight")
     return out
@@ -789,6 +799,17 @@ def head_unfold_bwd(dweff, head_w, dyn, param=None):
 def sgd_step(w, g, buf, lr, momentum, weight_decay, first):
     check(lib().fsd_sgd_step(w.data_ptr(), g.data_ptr(), buf.data_ptr(), lr, momentum, weight_decay,
                              1 if first else 0, w.numel(), _stream()), "fsd_sgd_step")
+
+
+def sgd_multi_blocks(count, cout=0, cin=0, taps=0):
+    return int(lib().fsd_sgd_multi_blocks(int(count), int(cout), int(cin), int(taps)))
+
+
+def sgd_step_multi(w, g, buf, table, n_entries, total_blocks, elements, lr, momentum, weight_decay, first):
+    """One launch of SGD(momentum, weight decay) over the tensors `table` lists inside the flat buffers, the bf16 operand copies
+    of the conv weights re-packed from the updated values in the same pass (include/fsdet.h fsd_sgd_step_multi)."""
+    check(lib().fsd_sgd_step_multi(w.data_ptr(), g.data_ptr(), buf.data_ptr(), table.data_ptr(), int(n_entries), int(total_blocks),
+                                   int(elements), lr, momentum, weight_decay, 1 if first else 0, _stream()), "fsd_sgd_step_multi")
 
 
 PROFILE_CLASSES = ("gemm_fwd", "gemm_wgrad", "wino_transform", "act_bwd", "act_fwd", "region", "sgd", "first_layer",

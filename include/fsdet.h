@@ -379,6 +379,17 @@ int fsd_head_unfold_bwd(const float* dweff, const float* head_w, const float* dy
  * torch.optim.SGD): d = g + wd*w; buf = first ? d : momentum*buf + d; w -= lr*buf. */
 int fsd_sgd_step(float* w, const float* grad, float* momentum_buf, float lr, float momentum,
                  float weight_decay, int first_step, long long count, hipStream_t stream);
+/* The same step over MANY tensors of one flat parameter buffer in ONE launch, with the bf16 storage mode's per-step
+ * re-packing of the conv operands folded in (train_meta.py:143-147 + what fsd_pack_conv_weight_bf16_pair does afterwards).
+ * table_dev: device array [n_entries][8] of int64: {element offset of the tensor in the three flat buffers, element count,
+ * cout, cin, taps (9 / 1: an OIHW conv weight with packed copies; 0: a plain range), first workgroup block of the entry
+ * (prefix sum of fsd_sgd_multi_blocks), address of the bf16 forward operand, address of the bf16 data-gradient operand (both
+ * as laid out by fsd_pack_conv_weight_bf16_pair; zero-filled once by the caller)}.  Entries must not overlap.  elements = sum
+ * of the counts (profiling only). */
+long long fsd_sgd_multi_blocks(long long count, int cout, int cin, int taps);
+int fsd_sgd_step_multi(float* w_flat, const float* grad_flat, float* momentum_flat, const long long* table_dev,
+                       int n_entries, long long total_blocks, long long elements, float lr, float momentum,
+                       float weight_decay, int first_step, hipStream_t stream);
 
 /* ---- bf16 storage mode (BASELINE configs[2] / [4]) --------------------------------------------------------------
  * The `_h` entry points are the bfloat16-storage twins of the functions above: every activation / activation-gradient

@@ -122,7 +122,11 @@ def test_bench_two_ranks_one_json_line():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
     assert res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 8
-    assert res["value"] > 0 and "roofline" in res and "cpu_baseline" not in res
+    # VERDICT r5 #7b: a line from several ranks carries the CPU baseline too (rank 0 times it after the ranks left the process
+    # group) and the in-line parity of what a rank launches, incl. the strong form's slice
+    assert res["value"] > 0 and "roofline" in res
+    assert res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["cores"] >= 1
+    assert res["parity"]["ok"] and res["parity"]["other_shapes_ok"]
 
 
 def test_plain_bench_command_launches_its_own_ranks():
