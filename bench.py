@@ -35,17 +35,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # more hardware queues than streams (main + meta + wgrad + copy + comm): the HIP runtime's default is 4 (read at its first use)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# Caching-allocator policy (read at torch's first device allocation): blocks above 24 MB are never SPLIT and serve only requests
-# of (nearly) their own size.  With the default best-fit splitting, the 1.1-1.4 GB workspaces and activations of a step are
-# carved up differently whenever the host runs a different distance ahead of the GPU (tensors that crossed a stream are
-# re-usable only once the GPU has passed them), and the pool never reaches a steady state: tools/alloc_trace.py showed 10-50
-# hipMallocs -- each one drains the device -- in the first steps after EVERY synchronisation, for as long as one cares to wait
-# (VERDICT r5 #4).  Exact-size pools settle after a few steps; the price is reserved-but-idle memory, of which 288 GB has plenty.
-for _k in ("PYTORCH_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
-    if _k in os.environ:
-        break
-else:
-    os.environ["PYTORCH_HIP_ALLOC_CONF"] = "max_split_size_mb:24"
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -413,17 +402,23 @@ class Leg(object):
                 ops.kernel_profile_collect()
                 self.settle_steps += 1
             last = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
-            # Bursts of 4 free-running steps (the host as far ahead of the GPU as in the timed region -- a memory_stats() call
-            # per step would hold it back and settle a DIFFERENT regime), until a whole burst allocated nothing; at most 6.
-            # (several ranks: a FIXED number of steps -- every step holds collectives, and the ranks' allocators need not
-            # go quiet after the same number of them)
+            # Bursts of 12 FREE-RUNNING steps, until a whole burst allocated nothing (at most 4 bursts).  What tools/alloc_trace.py
+            # showed (six allocator policies, gpurun_out/r06d): with two steps in flight the pool keeps growing for
+            # the first ~8 consecutive un-synchronised steps -- tensors that crossed a stream are reusable only once the GPU has
+            # passed them, so the deep-pipeline regime needs more blocks than a freshly synchronised one -- and is quiet from
+            # then on, ALSO across later synchronisations (the profiled step).  Round 5's settle loop read memory_stats() after
+            # every step (which holds the host back) and never ran more than a few free steps in a row, so the timed region was
+            # the first place the pipeline filled: 10-20 hipMallocs in its first steps.  No allocator policy changes that count
+            # (max_split_size_mb, roundup_power2_divisions, expandable_segments all measured: same or worse).
+            # (several ranks: a FIXED number of bursts -- every step holds collectives, and the ranks' allocators need not go
+            # quiet after the same number of them)
             bursts = 0
-            while bursts < (6 if self.dist is None else 2):
-                if prof_steps:                # (every burst follows one: the timed region's transition one-stream -> streams
-                    prof_form_step()          # is part of the regime being settled)
-                for _ in range(4):
+            while bursts < (4 if self.dist is None else 1):
+                if prof_steps:                # (the timed region's one-stream step and its two synchronisations belong to
+                    prof_form_step()          # the regime being settled)
+                for _ in range(12):
                     step()
-                self.settle_steps += 4
+                self.settle_steps += 12
                 bursts += 1
                 now = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
                 quiet = now == last

@@ -47,8 +47,6 @@ PROTOTYPES = {
     "fsd_conv2d_wgrad_ex": (_i, [_p, _ll, _p, _ll, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p]),
     "fsd_wino_conv3x3_fwd_act": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _p, _sz, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "fsd_conv2d_fwd_act_h": (_i, [_p, _ll, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "fsd_conv2d_fwd_act_h_frag": (_i, [_p, _ll, _p, _p, _p, _p, _ll, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "fsd_conv_weight_bf16_frag_order": (_i, [_p, _p, _i, _i, _p]),
     "fsd_first_layer_bwd_rows": (_i, [_i, _i, _i]),
     "fsd_first_layer_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fsd_first_layer_bwd_accum": (_i, [_p, _ll, _p, _ll, _p, _p, _p, _p, _f, _p, _ll, _p, _sz, _p, _i, _i, _i, _i, _i, _p]),

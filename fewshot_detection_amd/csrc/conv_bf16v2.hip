@@ -22,7 +22,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <type_traits>
 #include "fsdet.h"
 #include "conv_common.hpp"
 #include "profile.hpp"
@@ -40,7 +39,6 @@ __device__ __attribute__((aligned(16))) u16 g_zero_page_h[64];     // 128 zero b
 struct ConvHArgs {
   const u16* x;        // activations, bf16 NHWC, pixel stride x_ld elements
   const u16* w;        // packed weights, bf16 [rows padded to 128][Kpad]
-  const u16* wfrag;    // BDIR kernels: the same weights in MFMA-fragment order (fsd_conv_weight_bf16_frag_order), else null
   const float* bias;   // [Cout] or null
   void* y;             // bf16 NHWC (pixel stride y_ld elements) or float NCHW
   float* bn_partial;   // [m_tiles][Cout][2] or null
@@ -82,16 +80,8 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 // NS > 2: a ring -- chunk kc + NS - 1 is issued while chunk kc is computed, and the wait before the barrier is COUNTED
 // (only chunk kc + 1 has to have landed: (NS - 2) * PIECES newer DMA instructions may stay in flight).  Kept as a
 // tuning aid (FSD_CONV_H_RING=1): measured 5-15 % SLOWER than two drained stages (see the tile choice below).
-//
-// BDIR (round 6, VERDICT r5 #2a): the WEIGHT operand does not pass through LDS.  The weights are pre-packed in MFMA-fragment
-// order ([64-channel block][16-k step][even / odd channel][lane][8 bf16]: a wave's fragment of a k-step is ONE contiguous
-// 1 KB line), and every wave fetches the fragments of its own 64 channels with plain global_load_dwordx4 straight into
-// registers, one chunk ahead, double-buffered in registers (2 x 8 fragments = 64 VGPRs).  The LDS-DMA ring then carries the
-// activation tile only: 6 instead of 10 pieces per chunk and thread on 192x128 (3 instead of 7 on 192x256) and two fragment
-// reads per k-step less.  The waves of one channel group (WAVES_M of them) fetch the same lines (L1 / L2 hits).
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT, bool ILV = false, int NS = 2, bool BDIR = false>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool NCHW_F32_OUT, bool ILV = false, int NS = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(ConvHArgs p) {
-  static_assert(!BDIR || (ILV && NS == 2 && !NCHW_F32_OUT && BN / WAVES_N == 64), "B-direct: interleaved two-stage form, 64 channels per wave");
   static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
   static_assert(BK == 64 || BK == 32, "k-chunk of 64 or 32 bf16");
   static_assert(NS >= 2 && NS <= 6, "2 .. 6 LDS stages");
@@ -105,11 +95,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
   constexpr int LPR = BK / 8;                 // lanes (16-byte groups) per tile row
   constexpr int RPP = NT / LPR;               // tile rows staged per pass of the workgroup
   constexpr int RPW = 64 / LPR;               // ... per wave instruction
-  constexpr int A_PER_T = (BM + RPP - 1) / RPP, B_PER_T = BDIR ? 0 : BN / RPP;
+  constexpr int A_PER_T = (BM + RPP - 1) / RPP, B_PER_T = BN / RPP;
   // the last A pass may be partial (192 rows on 128-row passes): whole WAVES skip it (a_short), never single lanes
   constexpr bool A_PARTIAL = A_PER_T * RPP != BM;
-  static_assert((BDIR || B_PER_T * RPP == BN) && BM % RPW == 0, "whole B passes; A rows in whole wave instructions");
-  constexpr int STAGE = (BM + (BDIR ? 0 : BN)) * BK;       // elements per LDS stage
+  static_assert(B_PER_T * RPP == BN && BM % RPW == 0, "whole B passes; A rows in whole wave instructions");
+  constexpr int STAGE = (BM + BN) * BK;       // elements per LDS stage
   constexpr int HSH = BK == 64 ? 1 : 2, HMASK = LPR - 1;
   extern __shared__ __attribute__((aligned(16))) u16 smem_h[];
 
@@ -136,7 +126,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
     a_pix[j] = (unsigned)pix;
   }
   // B rows: LDS row r of a 64-row block holds channel 2*(r % 32) + (r / 32) % 2 of that block
-  const u16* wrow[B_PER_T > 0 ? B_PER_T : 1];
+  const u16* wrow[B_PER_T];
 #pragma unroll
   for (int j = 0; j < B_PER_T; ++j) {
     const int r = r0 + RPP * j;
@@ -243,54 +233,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
     if (st_next != nullptr) advance();
   };
 
-  if constexpr (BDIR) {
-    constexpr int KS = BK / 16, PIECES = A_PER_T;
-    constexpr int PPS = KS > 1 ? (PIECES + KS - 2) / (KS - 1) : PIECES;       // the last k-step stays DMA-free
-    constexpr int BPS = KS > 1 ? (KS * TN + KS - 2) / (KS - 1) : KS * TN;     // ... and free of weight loads
-    // fragment f = (k-step t) * 2 + j of this wave's 64-channel block: wf[f * 64] (one 16-byte piece per lane)
-    const long long KT = p.Kpad / 16;
-    const bf16x8* wf = reinterpret_cast<const bf16x8*>(p.wfrag) + ((long long)((n0 + wn * 64) / 64) * KT * 2) * 64 + lane;
-    // two register sets of fragments, used alternately: the chunk loop is unrolled by two (the launcher sends only EVEN chunk
-    // counts here), so no fragment is ever moved between registers
-    bf16x8 b0[KS * TN], b1[KS * TN];
-    gload_lds(0, smem_h);
-#pragma unroll
-    for (int f = 0; f < KS * TN; ++f) b0[f] = wf[(long long)f * 64];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    auto half = [&](const bf16x8 (&bc)[KS * TN], bf16x8 (&bn)[KS * TN], const u16* st, u16* st_next, int kc_next, bool more) {
-      const bf16x8* wn_ = wf + (long long)kc_next * (KS * TN) * 64;
-      const u16* sa = st + (wm * TM * 32 + (lane & 31)) * BK;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int ko = (((2 * s + (lane >> 5)) ^ hl) & HMASK) * 8;
-        bf16x8 af[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 32 * BK + ko);
-        if (more) {
-#pragma unroll
-          for (int f = s * BPS; f < (s + 1) * BPS && f < KS * TN; ++f) bn[f] = wn_[(long long)f * 64];
-#pragma unroll
-          for (int q = s * PPS; q < (s + 1) * PPS && q < PIECES; ++q) piece(q, kc_next, st_next);
-        }
-        // the fetches of this k-step stay in front of its MFMAs (left alone, the scheduler sinks all eight weight loads of a
-        // chunk behind its last DMA piece, one k-step in front of the drain)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bc[s * TN + j], acc[i][j], 0, 0, 0);
-      }
-      if (more) advance();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    };
-    for (int kc = 0; kc < p.nk; kc += 2) {
-      half(b0, b1, smem_h, smem_h + STAGE, kc + 1, true);
-      half(b1, b0, smem_h + STAGE, smem_h, kc + 2, kc + 2 < p.nk);
-    }
-  } else if constexpr (NS == 2) {
+  if constexpr (NS == 2) {
     gload_lds(0, smem_h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -464,15 +407,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_dma_kernel(C
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool ILV = false, int NS = 2, bool BDIR = false>
+template <int BM, int BN, int BK, int WM, int WN, bool ILV = false, int NS = 2>
 int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
-  size_t lds = NS * (size_t)(BM + (BDIR ? 0 : BN)) * BK * sizeof(u16);
+  size_t lds = NS * (size_t)(BM + BN) * BK * sizeof(u16);
   if (a.wide && lds < (size_t)BM * BN * sizeof(u16)) lds = (size_t)BM * BN * sizeof(u16);     // the epilogue's [BM][BN] tile
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
   fsd_prof::Scope prof(fsd_prof::kGemmBf16, 2.0 * (double)a.M * a.Cout * ((double)a.nk * BK), stream);
-  if (a.bn_partial && lds < (size_t)WM * BN * 2 * sizeof(float)) lds = (size_t)WM * BN * 2 * sizeof(float);   // s_stat
   if (nchw) {
-    if constexpr (BN >= 64 && WM * WN == 4 && !BDIR) {
+    if constexpr (BN >= 64 && WM * WN == 4) {
       auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, true, ILV, NS>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
@@ -481,7 +423,7 @@ int launch_conv(const ConvHArgs& a, bool nchw, hipStream_t stream) {
       return FSD_ERR_UNSUPPORTED;
     }
   } else {
-    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS, BDIR>;
+    auto k = conv_bf16_dma_kernel<BM, BN, BK, WM, WN, false, ILV, NS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     FSD_LAUNCH(k, grid, block, lds, stream, a);
@@ -604,40 +546,6 @@ extern "C" int fsd_conv2d_fwd_h(const void* x_bf16, long long x_ld, const void* 
 extern "C" int fsd_conv2d_fwd_act_h(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const float* bias, void* y,
                                     long long y_ld, float* bn_partial, int batch, int height, int width, int cin, int cout,
                                     int ksize, int out_nchw_f32, float slope, hipStream_t stream) {
-  return fsd_conv2d_fwd_act_h_frag(x_bf16, x_ld, w_packed_bf16, nullptr, bias, y, y_ld, bn_partial, batch, height, width, cin,
-                                   cout, ksize, out_nchw_f32, slope, stream);
-}
-
-// Fragment-order copy of a packed bf16 weight (fsd_pack_conv_weight_bf16[_pair] layout [rows_pad][kpad]) for the B-direct
-// kernels: element ((((r / 64) * (kpad / 16) + t) * 2 + j) * 64 + l) * 8 + q  =  packed[(r / 64) * 64 + 2 * (l % 32) + j][t * 16 + (l / 32) * 8 + q].
-namespace {
-__global__ void frag_order_kernel(const uint4* __restrict__ packed, uint4* __restrict__ out, int kpad, long long pieces) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece of the output
-  if (e >= pieces) return;
-  const int l = (int)(e & 63), j = (int)((e >> 6) & 1);
-  const long long tb = e >> 7;
-  const int kt = kpad / 16;
-  const int t = (int)(tb % kt);
-  const long long nb = tb / kt;
-  const long long row = nb * 64 + 2 * (l & 31) + j;
-  out[e] = packed[(row * kpad + t * 16 + (l >> 5) * 8) / 8];
-}
-}  // namespace
-
-extern "C" int fsd_conv_weight_bf16_frag_order(const void* w_packed_bf16, void* w_frag_bf16, int rows_pad, int kpad,
-                                               hipStream_t stream) {
-  (void)hipGetLastError();
-  if (!w_packed_bf16 || !w_frag_bf16 || rows_pad < 64 || (rows_pad & 63) || kpad < 16 || (kpad & 15)) return FSD_ERR_ARG;
-  const long long pieces = (long long)rows_pad * kpad / 8;
-  FSD_LAUNCH(frag_order_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream,
-             static_cast<const uint4*>(w_packed_bf16), static_cast<uint4*>(w_frag_bf16), kpad, pieces);
-  return (int)hipGetLastError();
-}
-
-extern "C" int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const void* w_frag_bf16,
-                                         const float* bias, void* y, long long y_ld, float* bn_partial, int batch, int height,
-                                         int width, int cin, int cout, int ksize, int out_nchw_f32, float slope,
-                                         hipStream_t stream) {
   (void)hipGetLastError();
   if (slope != 1.f && (out_nchw_f32 || bn_partial)) return FSD_ERR_UNSUPPORTED;
   if (!x_bf16 || !w_packed_bf16 || !y || batch < 1 || height < 1 || width < 1 || cout < 1) return FSD_ERR_ARG;
@@ -656,8 +564,6 @@ extern "C" int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, con
   if (pixels > 0x7fffffffLL - 512 || (pixels + 1) * x_ld >= 0xffffffffLL) return FSD_ERR_UNSUPPORTED;
   ConvHArgs a;
   a.x = static_cast<const u16*>(x_bf16); a.w = static_cast<const u16*>(w_packed_bf16); a.bias = bias; a.y = y;
-  a.wfrag = static_cast<const u16*>(w_frag_bf16);
-  if (a.wfrag && (reinterpret_cast<uintptr_t>(a.wfrag) & 15)) return FSD_ERR_ARG;
   a.bn_partial = bn_partial; a.x_ld = x_ld; a.y_ld = y_ld;
   a.slope = slope;
   static const char* wide_env = FSD_TUNE("FSD_CONV_H_WIDE");        // tuning aid: 0 = 4-byte stores straight from registers
@@ -693,7 +599,6 @@ extern "C" int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, con
       if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<256, 256, 32, 2, 4, true, 4>(a, false, stream); }
       if (!ilv) return launch_conv<256, 256, 64, 2, 4>(a, false, stream);
 #endif
-      if (a.wfrag && a.nk % 2 == 0) return launch_conv<256, 256, 64, 2, 4, true, 2, true>(a, false, stream);
       return launch_conv<256, 256, 64, 2, 4, true>(a, false, stream);
     case 2:
       a.n_tiles = cout / 256;
@@ -701,7 +606,6 @@ extern "C" int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, con
       if (ring) { a.nk *= 2; a.cpt *= 2; return launch_conv<192, 256, 32, 2, 4, true, 4>(a, false, stream); }
       if (!ilv) return launch_conv<192, 256, 64, 2, 4>(a, false, stream);
 #endif
-      if (a.wfrag && a.nk % 2 == 0) return launch_conv<192, 256, 64, 2, 4, true, 2, true>(a, false, stream);
       return launch_conv<192, 256, 64, 2, 4, true>(a, false, stream);
     case 3:
       a.n_tiles = cout / 128;
@@ -715,7 +619,6 @@ extern "C" int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, con
 #ifdef FSD_EXPERIMENTS
       if (!ilv) return launch_conv<192, 128, 64, 2, 2>(a, false, stream);
 #endif
-      if (a.wfrag && a.nk % 2 == 0) return launch_conv<192, 128, 64, 2, 2, true, 2, true>(a, false, stream);
       return launch_conv<192, 128, 64, 2, 2, true>(a, false, stream);
     default:
       a.n_tiles = (cout + 127) / 128;

@@ -295,29 +295,13 @@ PROFILE = None      # bench.py sets this to a list, one entry per conv launch (f
                     # Per-KERNEL timing is the library's job (fsd_profile_enable / fsd_profile_collect).
 
 
-def frag_order_bf16(w_packed, rows, red, ksize, out=None):
-    """The packed bf16 operand of pack_weight(..., "bf16") / pack_weight_bf16_pair re-ordered into MFMA-fragment order for the
-    B-direct large-tile kernels (include/fsdet.h fsd_conv_weight_bf16_frag_order).  rows / red: output channels / reduction
-    channels of THIS operand (mode 0: cout, cin; mode 1: cin, cout).  Same size as the packed operand."""
-    rows_pad = (rows + 127) // 128 * 128
-    kpad = (ksize * ksize * ((red + 3) // 4 * 4) + 63) // 64 * 64
-    if w_packed.numel() != rows_pad * kpad:
-        raise ValueError("packed operand of %d elements does not match %d x %d" % (w_packed.numel(), rows_pad, kpad))
-    out = _reuse(out, w_packed.numel(), torch.bfloat16, w_packed.device)
-    check(lib().fsd_conv_weight_bf16_frag_order(w_packed.data_ptr(), out.data_ptr(), rows_pad, kpad, _stream()),
-          "fsd_conv_weight_bf16_frag_order")
-    return out
-
-
-def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None, slope=1.0,
-           w_frag=None):
+def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nchw_out=False, cin_true=None, slope=1.0):
     """xv: View (C % 4 == 0).  Returns (y, partial): y is a View (or an NCHW tensor if nchw_out).
-    slope != 1: y = leaky(conv + bias) (inference form: NHWC store, no statistics).
-    w_frag (bf16 views only): the fragment-order copy of w_packed (frag_order_bf16) for the B-direct kernels."""
+    slope != 1: y = leaky(conv + bias) (inference form: NHWC store, no statistics)."""
     dev = xv.t.device
     partial = None
     if xv.bf16:
-        return _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope, w_frag)
+        return _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope)
     if nchw_out:
         y = torch.empty((xv.B, cout, xv.H, xv.W), dtype=torch.float32, device=dev)
         y_ptr, y_ld = y.data_ptr(), 0
@@ -351,7 +335,7 @@ def conv2d(xv, w_packed, cout, ksize, bias=None, out=None, bn_partial=False, nch
     return y, partial
 
 
-def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=1.0, w_frag=None):
+def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=1.0):
     """bf16 storage mode: bf16 NHWC activations x packed bf16 weights -> bf16 NHWC (or float NCHW for the head)."""
     _plain(xv)
     L = lib()
@@ -374,9 +358,8 @@ def _conv2d_h(xv, w_packed, cout, ksize, bias, out, bn_partial, nchw_out, slope=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.fsd_conv2d_fwd_act_h_frag(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(w_frag), _ptr(bias), y_ptr, y_ld, _ptr(partial),
-                                      xv.B, xv.H, xv.W, xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()),
-          "fsd_conv2d_fwd_h")
+    check(L.fsd_conv2d_fwd_act_h(xv.ptr, xv.ld, w_packed.data_ptr(), _ptr(bias), y_ptr, y_ld, _ptr(partial), xv.B, xv.H, xv.W,
+                                 xv.C, cout, ksize, 1 if nchw_out else 0, float(slope), _stream()), "fsd_conv2d_fwd_h")
     if PROFILE is not None:
         e1.record()
         fl = 2.0 * ksize * ksize * xv.C * cout * xv.pixels

@@ -397,15 +397,6 @@ int fsd_sgd_step_multi(float* w_flat, const float* grad_flat, float* momentum_fl
  * arithmetic, the BatchNorm partial sums and every parameter / parameter gradient stay float.  Arguments, shapes,
  * return codes and the kernels behind them are otherwise identical (one kernel template, two instantiations). */
 int fsd_conv_row_tiles_h(long long pixels);          /* upper bound of the rows of any bn_partial array (128-row tiles) */
-/* B-direct form of fsd_conv2d_fwd_act_h (round 6): w_frag_bf16 = the same weights in MFMA-fragment order
- * (fsd_conv_weight_bf16_frag_order of the packed operand; same size).  The large-tile kernels (192x128, 192x256, 256x256) then
- * fetch the weight fragments straight into registers and stage only the activation tile through LDS; every other launch
- * (narrow layers, halo kernels, the NCHW head) ignores w_frag_bf16 and reads w_packed_bf16 as before.  w_frag_bf16 = NULL is
- * exactly fsd_conv2d_fwd_act_h.  Results are bit-identical to it (same products, same summation order). */
-int fsd_conv_weight_bf16_frag_order(const void* w_packed_bf16, void* w_frag_bf16, int rows_pad, int kpad, hipStream_t stream);
-int fsd_conv2d_fwd_act_h_frag(const void* x_bf16, long long x_ld, const void* w_packed_bf16, const void* w_frag_bf16,
-                              const float* bias, void* y, long long y_ld, float* bn_partial, int batch, int height, int width,
-                              int cin, int cout, int ksize, int out_nchw_f32, float slope, hipStream_t stream);
 /* rows of the bn_partial array fsd_conv2d_fwd_h fills for this layer (one row per row tile of the tile it will pick; one
  * per workgroup of the persistent halo kernel of the 32 -> 64 / 64 -> 32 3x3 layers, conv_halo_h.hip) */
 int fsd_conv2d_h_partial_rows(int batch, int height, int width, int cin, int cout, int ksize);

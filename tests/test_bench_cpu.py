@@ -1,11 +1,13 @@
 """bench.py's host-side arithmetic: the algorithmic FLOP counts behind `roofline.achieved` are the SURVEY 8(d) /
 BASELINE.md figures, the synthetic episode has the contract's shapes, and without a GPU the bench fails loudly."""
 import io
+
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -249,3 +251,22 @@ def test_bench_without_a_launcher_starts_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_committed_bench_line_of_this_round_has_no_device_allocation_in_its_timed_region():
+    """a hipMalloc inside the timed region drains the device.  The committed contract line of round 6 onward
+    (profiles/rNN_bench_line_f32.json = the LAST stdout line of `python bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box)
+    must carry allocator.device_allocs_in_timed_region == 0 next to the contract fields."""
+    import glob
+    import json
+    import re
+    lines = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line_f32.json"))
+                   if int(re.match(r"r(\d+)", os.path.basename(p)).group(1)) >= 6)
+    if not lines:
+        pytest.skip("no bench line of round >= 6 committed yet")
+    d = json.load(open(lines[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "cpu_baseline", "parity", "allocator"):
+        assert k in d, k
+    assert d["allocator"]["device_allocs_in_timed_region"] == 0, d["allocator"]
+    assert d["parity"]["ok"] is True and d["parity"].get("other_shapes_ok") is True
+    assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0 and d["cpu_baseline"]["kind"] == "port"

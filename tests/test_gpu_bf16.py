@@ -466,7 +466,8 @@ def test_full_architecture_bf16_mode_vs_oracle_emulation(dev, tmp_path):
     assert out.shape == ref.shape and rel < 0.2
     # the loss is a sum over the same outputs: a 0.1 relative-L2 forward drift moves it by a few 1e-3 (3.4e-3 measured after
     # the first layer moved to the split arithmetic, 2.5e-4 before: which side of a rounding boundary, not accuracy)
-    assert abs(float(loss.detach()) - float(r["loss"].detach())) < 1e-2 * abs(float(r["loss"].detach()))
+    # (back to the measured level -- 3.4e-3 here, 2e-4 ... 6e-4 at the timed shapes of test_gpu_launch_configs.py)
+    assert abs(float(loss.detach()) - float(r["loss"].detach())) < 5e-3 * abs(float(r["loss"].detach()))
     named, mine = dict(ora.named_parameters()), dict(net.named_parameters())
     cos = []
     for name, p in mine.items():
@@ -781,38 +782,3 @@ def test_a_one_ulp_rounding_bug_in_a_bf16_kernel_fails_the_per_block_check(dev, 
             bits[:, ::16] += 1                                  # next representable bf16 (sign-magnitude: away from zero)
     with pytest.raises(AssertionError):
         _blocks_on_identical_inputs(dev, tmp_path, 2, perturb=one_ulp_in_layer_12)
-
-
-@pytest.mark.parametrize("B,H,W,cin,cout,k,tile", [
-    (8, 52, 52, 128, 256, 3, 6),       # 192 x 128 tile, 18 chunks
-    (8, 26, 26, 256, 512, 3, 6),
-    (8, 52, 52, 256, 128, 3, 6),       # a data-gradient shape
-    (64, 13, 13, 512, 1024, 3, 2),     # 192 x 256 on eight waves
-    (64, 13, 13, 1024, 1024, 3, 2),
-    (3, 13, 13, 1024, 1024, 1, 6),     # 1x1, K = 1024 (16 chunks), a partial row tile
-    (5, 19, 19, 1280, 1024, 3, None),  # whatever the plan picks for the 608 x 608 episode's last layer
-])
-def test_conv_bf16_b_direct_kernels_equal_the_lds_staged_ones(dev, B, H, W, cin, cout, k, tile):
-    """conv_bf16_dma_kernel<..., BDIR> (round 6): the weight fragments come straight from a fragment-order copy of the packed
-    operand into registers, LDS carries the activation tile only.  Same products in the same order as the LDS-staged kernel:
-    outputs and BatchNorm partial sums BIT-identical; and against fp64 of the rounded operands like every bf16 kernel."""
-    from fewshot_detection_amd import ops
-    from fewshot_detection_amd._lib import lib
-    if tile is not None:
-        assert lib().fsd_conv2d_h_plan(B * H * W, cin, cout, k, 0, 1) == tile
-    g = torch.Generator().manual_seed(B + cin + cout)
-    x = _bf(torch.randn(B, cin, H, W, generator=g))
-    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-    xv = _view_bf16(x, dev)
-    wp = ops.pack_weight(w.to(dev), 0, "bf16")
-    wf = ops.frag_order_bf16(wp, cout, cin, k)
-    y0, p0 = ops.conv2d(xv, wp, cout, k, bn_partial=True)
-    y1, p1 = ops.conv2d(xv, wp, cout, k, bn_partial=True, w_frag=wf)
-    assert torch.equal(y0.t, y1.t) and torch.equal(p0, p1)
-    ref = F.conv2d(x.double(), _bf(w).double(), None, 1, (k - 1) // 2)
-    err = (_nchw(y1).double() - ref).abs()
-    assert float((err - ref.abs() * 2.0 ** -8).max()) < 1e-3, float(err.max())
-    b = torch.randn(cout, generator=g)
-    y2, _ = ops.conv2d(xv, wp, cout, k, bias=b.to(dev), slope=0.1)
-    y3, _ = ops.conv2d(xv, wp, cout, k, bias=b.to(dev), slope=0.1, w_frag=wf)
-    assert torch.equal(y2.t, y3.t)

@@ -184,7 +184,8 @@ def test_bf16_mode_episode_vs_its_restatement_at_every_timed_launch_configuratio
         print("%s bf16 (B=%d N=%d %dx%d): forward rel-L2 vs _walk_bf16 %.3e, loss %.4f vs %.4f"
               % (name, B, N, S, S, rel, loss_hip, ref_loss))
         assert out.shape == ref.shape and rel < 0.15
-        assert abs(loss_hip - ref_loss) < 1e-2 * max(1.0, abs(ref_loss))
+        # (measured 2e-4 ... 6e-4 over the six shapes; VERDICT r5 #3: not looser than 5e-3)
+        assert abs(loss_hip - ref_loss) < 5e-3 * max(1.0, abs(ref_loss))
         assert keep_hip == list(r["keep"])
         _loss_on_identical_inputs(region, out_cpu, tgt, ora.region.anchors, neg, loss_hip, stats, got_t, keep_hip)
         for p in net.parameters():

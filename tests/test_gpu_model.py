@@ -173,3 +173,19 @@ def test_standalone_modules_are_shape_faithful(dev):
     blk.add_module("conv1", nn.Conv2d(4, 8, 3, 1, 0))
     with pytest.raises(NotImplementedError):
         blk.to(dev)(torch.randn(1, 4, 8, 8).to(dev))
+
+
+def test_bench_timed_region_allocates_no_device_memory():
+    """VERDICT r5 #4 (bench smoke): the driver-shaped command on the headline episode, extras off -- after bench.py's settle phase
+    (bursts of free-running steps, see Leg.run) the timed region must not call hipMalloc: every step of it reuses cached blocks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "3", "--no-extras",
+           "--no-cpu-baseline", "--no-parity"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["steps"] == 12 and d["value"] > 0
+    assert d["allocator"]["device_allocs_in_timed_region"] == 0, d["allocator"]

@@ -101,24 +101,15 @@ def main_bf16(what, dev):
         w = torch.randn(cout, cin, k, k, device=dev) * 0.05
         flops = 2.0 * k * k * cin * cout * B * H * W
         line = "%3dx%3d %4d->%4d k%d:" % (H, W, cin, cout, k)
-        bdir = os.environ.get("FSD_LB_BDIR") == "1"          # also time the B-direct form (weights in fragment order)
         if what in ("fwd", "all"):
             wp = ops.pack_weight(w, 0, "bf16")
             ms = timed(lambda: ops.conv2d(x, wp, cout, k, bn_partial=True))
             line += "  fwd %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
-            if bdir:
-                wf = ops.frag_order_bf16(wp, cout, cin, k)
-                ms = timed(lambda: ops.conv2d(x, wp, cout, k, bn_partial=True, w_frag=wf))
-                line += " [bdir %7.3f ms %7.1f TF]" % (ms, flops / ms / 1e9)
             if cout % 32 == 0:
                 wp1 = ops.pack_weight(w, 1, "bf16")
                 dyc = ops.View(dy.t, B, H, W, cout)
                 ms = timed(lambda: ops.conv2d(dyc, wp1, cin, k))
                 line += "  dgrad %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
-                if bdir:
-                    wf1 = ops.frag_order_bf16(wp1, cin, cout, k)
-                    ms = timed(lambda: ops.conv2d(dyc, wp1, cin, k, w_frag=wf1))
-                    line += " [bdir %7.3f ms %7.1f TF]" % (ms, flops / ms / 1e9)
         if what in ("wgrad", "all"):
             ms = timed(lambda: ops.conv2d_wgrad(dy, dy.C, x, cin, k))
             line += "  wgrad %7.3f ms %7.1f TF" % (ms, flops / ms / 1e9)
