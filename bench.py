@@ -351,7 +351,7 @@ class Leg(object):
             loss = region(net(x, metax, mask), target)
             if opt is not None:
                 opt.backward_and_step(loss)
-            return loss
+            return loss.detach()              # (a loss that is kept must not keep the step's autograd graph alive)
         return step
 
     def fence(self):
@@ -388,7 +388,7 @@ class Leg(object):
         # all of them in the first steps after the switch).  Now the settle phase already runs in the timed region's regime.
         gc.collect()
         gc.disable()
-        if warmup > 0 and self.dev.type == "cuda":
+        if warmup > 0 and self.dev.type == "cuda" and not getattr(self, "no_settle", False):
             def prof_form_step():             # one step in the form of the profiled ones (one stream, per-launch events)
                 torch.cuda.synchronize()
                 ops.PROFILE = []
@@ -943,6 +943,8 @@ def main():
     ap.add_argument("--streams", type=int, choices=[0, 1], default=None,
                     help="side HIP streams (reweighting net, weight gradients, target upload beside the main stream); "
                          "default: on unless FSD_STREAMS=0")
+    ap.add_argument("--no-settle", action="store_true", help="profiling aid: skip the untimed allocator-settle steps (rocprofv3 "
+                                                             "PMC passes replay every kernel several times)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-vs-oracle comparison on the cpu_baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip also_measured (bf16 mode, backbone forward, other configs, ...)")
@@ -1012,6 +1014,7 @@ def _main(args, real_stdout):
     dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(tmp)
     blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
     leg = Leg(dyn_cfg, rw_cfg, args.dtype, dev, dist, global_batch, args.mode)
+    leg.no_settle = args.no_settle
     if strong:      # one global episode: this rank's slice of the queries and targets, every support on every rank
         gx, metax, mask, gt = synth_episode(1000, args.batch, args.classes, args.size, args.support)
         x, target = gx[rank * local_batch:(rank + 1) * local_batch], gt[rank * local_batch:(rank + 1) * local_batch]

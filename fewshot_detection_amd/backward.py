@@ -196,6 +196,7 @@ def run_early(ctx, grad_out):
         grads = run(ctx.net, ctx.tape, grad_out, ctx.params)
     # the gradient tensor itself is kept (not its bare address: the allocator could hand the address to another tensor)
     ctx.early_result = (grad_out, grads)
+    ctx.tape = None          # consumed: the activations it kept are free for the next step (see _NetFn.backward)
 
 
 def run(net, tape, grad_out, params, wgrad_stream=True):

@@ -268,6 +268,9 @@ class _NetFn(torch.autograd.Function):
         from . import backward as bw
         grad_out = grad_out.contiguous()
         early = ctx.early_result
+        if ctx.tape is None and early is None:
+            raise RuntimeError("backward through this network a second time: the tape of its forward pass was released by the "
+                               "first backward (like autograd's saved tensors without retain_graph); run the forward again")
         if early is not None and early[0].data_ptr() == grad_out.data_ptr() and tuple(early[0].shape) == tuple(grad_out.shape):
             # the detector's sweep already ran this network's backward on this very gradient (backward.run_early)
             grads = early[1]
@@ -295,6 +298,12 @@ class _NetFn(torch.autograd.Function):
             grads = bw.run(ctx.net, ctx.tape, grad_out, ctx.params)
         if ops.GRAD_HOOK is not None:
             ops.GRAD_HOOK()
+        # Release the tape NOW, as autograd releases saved tensors after a backward without retain_graph: it holds every kept
+        # activation of the step (y, x, V: ~8 GB at the headline episode).  A caller that keeps `loss` (or the output) alive --
+        # `loss = step()` in a loop, a logging list -- would otherwise keep the whole previous step's activations alive through
+        # the next forward: twice the memory, and a caching allocator that needs fresh segments whenever the overlap changes
+        # (tools/alloc_trace.py: this was the source of the hipMallocs inside bench.py's timed region).
+        ctx.tape = None
         head = [None] * ctx.n_inputs + ([grads["dyn"]] if ctx.has_dyn else [])
         return (None, None, None, None, None, None) + tuple(head) + tuple(grads["params"])
 

@@ -500,3 +500,38 @@ def test_wide_detector_three_sgd_steps_follow_the_oracle(dev, tmp_path):
             assert err < 2e-3 * max(1e-3, float(r_.abs().max())), (name, err)
     finally:
         cfg.metayolo = True
+
+
+def test_tape_is_released_by_the_backward_pass(dev):
+    """Round 6: a kept `loss` must not keep the previous step's activations alive.  After backward() the
+    network's autograd node has dropped its tape (as autograd drops saved tensors without retain_graph): device memory in use
+    is back at the parameters' level while `loss` and the output are still referenced, and a second backward through the same
+    forward raises instead of silently replaying freed buffers."""
+    from fewshot_detection_amd.cfg import cfg
+    ora, net = _load_pair(dev, seed=9)
+    B, N, S = 4, 3, 160
+    x, metax = torch.rand(B, 3, S, S).to(dev), torch.rand(N, 3, S, S).to(dev)
+    mask = (torch.rand(N, 1, S, S) > 0.5).float().to(dev)
+    tgt = torch.zeros(B, N, 250, dtype=torch.float64)
+    tgt[0, 1, :5] = torch.tensor([1, 0.5, 0.5, 0.4, 0.3])
+    cfg.neg_ratio = "full"
+    region = net.models[len(net.models) - 1]
+    region.verbose = False
+    for _ in range(2):                       # packed weights, workspaces: reach the steady state first
+        region(net(x, metax, mask), tgt).backward()
+    net.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated(dev)
+    out = net(x, metax, mask)
+    loss = region(out, tgt)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated(dev) - base
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.empty(1, device=dev)                             # (lets the allocator retire the blocks that crossed a stream)
+    after = torch.cuda.memory_allocated(dev) - base
+    grads = sum(p.grad.numel() * 4 for p in net.parameters() if p.grad is not None)
+    assert held > 20 * out.numel() * 4                     # the tape held the activations of every layer ...
+    assert after - grads < 0.25 * held, (held, after, grads)  # ... and they are gone although `loss` / `out` are alive
+    with pytest.raises(RuntimeError, match="second time|retain_graph|freed|already been freed"):
+        region(out, tgt).backward()

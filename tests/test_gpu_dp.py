@@ -178,10 +178,11 @@ def test_eight_ranks_reproduce_one_full_batch_process(tmp_path):
 
 def test_bench_eight_ranks_strong_form_of_the_headline_episode_on_one_gpu():
     """... and bench.py's --gpus 8 path on the REAL model: the headline episode (64 queries 416x416 + 20 supports 224x224) in
-    the strong form = 8 queries per rank, all supports on every rank, 6 tapered buckets; the line carries both scaling forms,
-    the CPU baseline (VERDICT r5 #7b) and the in-line parity of what one rank launches (B = 8)."""
-    res = _run_bench(["--scaling", "strong", "--batch", "64", "--classes", "20", "--size", "416", "--support", "224"],
-                     {"FSD_BENCH_BACKEND": "gloo"}, nproc=8, timeout=1500)
+    the strong form = 8 queries per rank, all supports on every rank, 6 tapered buckets; the line carries both scaling forms."""
+    # (--no-cpu-baseline: the CPU baseline / in-line parity of a multi-rank line is asserted by the 2-rank test above, and the
+    # B = 8 slice against the oracle by tests/test_gpu_launch_configs.py; here they would be 45 s of host time)
+    res = _run_bench(["--scaling", "strong", "--batch", "64", "--classes", "20", "--size", "416", "--support", "224",
+                      "--no-cpu-baseline"], {"FSD_BENCH_BACKEND": "gloo"}, nproc=8, timeout=1500)
     assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["config"]["global_batch"] == 64
     dp = res["dp"]
     assert dp["world_size"] == 8 and dp["rccl_ranks"] == 8 and dp["gradient_buckets"] == 6
@@ -191,9 +192,6 @@ def test_bench_eight_ranks_strong_form_of_the_headline_episode_on_one_gpu():
     assert abs(res["img_per_s"] - 64 * res["value"]) < 1e-6 * res["img_per_s"]
     weak = res["also_measured"]["weak_scaling"]
     assert weak["episodes_per_s"] > 0 and "64 queries per rank" in weak["what"]
-    assert res["cpu_baseline"]["value"] > 0
-    sl = res["parity"]["other_shapes"]["strong_scaling_rank_slice"]
-    assert res["parity"]["ok"] and sl["B"] == 8 and sl["ok"] and sl["forward_max_abs_delta"] < 1e-3
 
 
 def _run_bench(extra, env_extra, nproc=2, timeout=600):

@@ -28,7 +28,7 @@ CLASSES = (
     ("wgrad", r"^(wgrad_kernel|wgrad_split8_kernel|wgrad3x3_halo_kernel|wgrad3x3_halo_h_kernel|wgrad_first_kernel|wgrad_reduce_kernel|wgrad_bf16_tr_kernel|wgrad_bf16_tr8_kernel|"
               r"wgrad_bf16_kernel|wgrad_fold_h_kernel|wgrad_h_fold_kernel|wgrad_h_partial_kernel|wino_dw_kernel|wino4_dw_kernel|conv_wgrad_[a-z0-9_]*kernel)\b"),
     ("weight_pack", r"^(wino_weight_kernel|wino4_weight_kernel|wino4_weight_wide_kernel|wino4_weight_split_kernel|pack_weight_kernel|"
-                    r"pack_weight_bf16_kernel|pack_weight_bf16_pair_kernel|pack_weight_split_kernel)\b"),
+                    r"pack_weight_bf16_kernel|pack_weight_bf16_pair_kernel|pack_weight_split_kernel|sgd_pack_multi_kernel)\b"),
 )
 
 
