@@ -68,7 +68,7 @@ def test_bench_quotes_the_newest_committed_traffic_summary():
     newest rNN[letter]_<name> by round number, and the committed round-3 summary was measured on the headline episode."""
     import bench
     data, src = bench.newest_profile("conv_traffic.json")
-    assert data is not None and "r05" in src, src
+    assert data is not None and "r06" in src, src
     assert data["episode"] == "metric_string" and 5e8 < data["hbm_bytes_per_launch"] < 2e9
     assert any(k.startswith("conv_gemm_split8_kernel") for k in data["kernels"])      # the round-4 kernels are counted
     assert bench.newest_profile("no_such_summary.json") == (None, None)
