@@ -134,7 +134,7 @@ class EpisodeTrainer(object):
         from .region_loss import _RegionBase
         mods = [m for m in self.net.modules() if isinstance(m, _RegionBase)]
         for m in mods:
-            if m.neg_counts is not None:
+            if getattr(m, "neg_counts", None) is not None:
                 raise RuntimeError("this model's loss module already belongs to a live EpisodeTrainer (close() it first): two "
                                    "trainers would pair their neg_filter collectives with each other")
         group, err = None, None
@@ -170,7 +170,7 @@ class EpisodeTrainer(object):
         """Give the model back: remove the whole-batch neg_filter reducer from its loss modules (they use the local ratio
         again) and drop the host-side group.  Idempotent; call it on every rank before destroy_process_group()."""
         for m in self._loss_modules:
-            if m.neg_counts is self.neg_counts:
+            if getattr(m, "neg_counts", None) is self.neg_counts:
                 m.neg_counts = None
         self._loss_modules = []
         self.neg_counts = None

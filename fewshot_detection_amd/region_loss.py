@@ -176,6 +176,12 @@ class _RegionBase(nn.Module):
         self.last_keep = None
         self.neg_counts = None          # data parallelism: whole-batch (n_pos, n_rows) reducer, owned by dp.EpisodeTrainer
 
+    def __getstate__(self):
+        # a trainer's collective reducer is process state, not model state: a pickled / deep-copied model comes back local
+        state = dict(self.__dict__)
+        state["neg_counts"] = None
+        return state
+
     def stats(self):
         """(dict) loss parts + nGT / nCorrect / nProposals of the last call (synchronises)."""
         s = self._stats.tolist()
@@ -192,7 +198,7 @@ class _RegionBase(nn.Module):
             raise ValueError("target has %d rows, output has %d" % (tr.shape[0], rows))
         _validate_targets(tr, None if zero_tcls else (rows_per_image if softmax_over_rows else self.num_classes))
         # the whole-batch ratio is a collective: only the training step's call takes part in it (see the note at the top)
-        counts = self.neg_counts if (self.training and torch.is_grad_enabled()) else None
+        counts = getattr(self, "neg_counts", None) if (self.training and torch.is_grad_enabled()) else None
         keep = neg_filter_indices(tr, counts)
         keep_map = np.full(rows, -1, np.int32)
         keep_map[keep] = np.arange(len(keep), dtype=np.int32)

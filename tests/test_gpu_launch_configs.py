@@ -196,7 +196,7 @@ def test_bf16_mode_episode_vs_its_restatement_at_every_timed_launch_configuratio
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("B,S", [(64, 416), (16, 416), (8, 416), (64, 608)])
+@pytest.mark.parametrize("B,S", [(64, 416), (16, 416), (8, 416), (16, 608)])      # (64 x 608x608 end to end: the episode test above)
 def test_bf16_blocks_on_identical_inputs_at_the_timed_batches(dev, cfg_paths, B, S):
     """Every conv + BatchNorm + leaky (+ pool) block of darknet_dynamic.cfg in bf16 storage mode at the batch sizes that are
     timed, each fed the oracle's (bf16-valued) input of that block (the B=2 form of this check is in test_gpu_bf16.py): the
