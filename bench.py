@@ -402,14 +402,11 @@ class Leg(object):
                 ops.kernel_profile_collect()
                 self.settle_steps += 1
             last = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
-            # Bursts of 12 FREE-RUNNING steps, until a whole burst allocated nothing (at most 4 bursts).  What tools/alloc_trace.py
-            # showed (six allocator policies, gpurun_out/r06d): with two steps in flight the pool keeps growing for
-            # the first ~8 consecutive un-synchronised steps -- tensors that crossed a stream are reusable only once the GPU has
-            # passed them, so the deep-pipeline regime needs more blocks than a freshly synchronised one -- and is quiet from
-            # then on, ALSO across later synchronisations (the profiled step).  Round 5's settle loop read memory_stats() after
-            # every step (which holds the host back) and never ran more than a few free steps in a row, so the timed region was
-            # the first place the pipeline filled: 10-20 hipMallocs in its first steps.  No allocator policy changes that count
-            # (max_split_size_mb, roundup_power2_divisions, expandable_segments all measured: same or worse).
+            # Bursts of 12 FREE-RUNNING steps (the host as far ahead of the GPU as in the timed region; a memory_stats() call per
+            # step would hold it back), until a whole burst allocated nothing; at most 4.  (The hipMallocs round 5 saw INSIDE the
+            # timed region were not a settling problem: the timed loop kept each step's loss -- and through it the network's
+            # tape, ~8 GB of activations -- alive during the next forward, a peak the settle loop never produced.  The tape is
+            # released by the backward pass now, darknet_meta._NetFn.backward; tools/alloc_trace.py, VERDICT r5 #4.)
             # (several ranks: a FIXED number of bursts -- every step holds collectives, and the ranks' allocators need not go
             # quiet after the same number of them)
             bursts = 0
