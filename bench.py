@@ -323,7 +323,7 @@ def newest_profile(name):
 class Leg(object):
     """One model replica in one storage mode (+ its trainer), and what bench.py measures on it."""
 
-    def __init__(self, dyn_cfg, rw_cfg, dtype, dev, dist, global_batch, mode):
+    def __init__(self, dyn_cfg, rw_cfg, dtype, dev, dist, global_batch, mode, single_rank_collectives=False):
         from fewshot_detection_amd.darknet_meta import Darknet
         self.dtype, self.dev, self.dist, self.global_batch = dtype, dev, dist, global_batch
         torch.manual_seed(0)
@@ -340,7 +340,8 @@ class Leg(object):
             # two steps, so the bench shrinks lr by 1e-4; the work per step is unchanged.
             self.opt = EpisodeTrainer(self.net, lr=1e-4 * 0.001 / 3 / global_batch, momentum=0.9,
                                       weight_decay=0.0005 * global_batch * 3, process_group=dist,
-                                      grad_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+                                      grad_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32,
+                                      single_rank_collectives=single_rank_collectives)
             self.opt.time_allreduce = dist is not None
 
     def stepper(self, x, metax, mask, target, batch=None):
@@ -371,10 +372,11 @@ class Leg(object):
             step()
         self.fence()
         self.stream_tuning = None
-        if streams_on and self.dist is None and self.opt is not None:
+        if streams_on and self.opt is not None:
             # untimed: make sure the side streams pay in THIS process (streams.autotune: an unlucky stream -> hardware-queue
             # mapping makes a step 40 % slower for the life of the streams; it re-draws them or falls back to one stream)
-            self.stream_tuning = streams.autotune(step)
+            # (several ranks: a FIXED number of probing steps on every rank -- each step holds the gradient collectives)
+            self.stream_tuning = streams.autotune(step, fixed_schedule=self.dist is not None)
             streams_on = streams.ENABLED
             self.fence()
         # untimed: let the caching allocator reach its steady state (tensors that cross streams are re-used only after the
@@ -979,9 +981,14 @@ def _main(args, real_stdout):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # FSD_BENCH_SINGLE_RANK_RCCL=1: a ONE-rank run still builds the RCCL process group and issues every collective of the
+    # data-parallel step (sums over one rank: the identity).  It is how the transport itself -- communicator, launching stream,
+    # work.wait() stream semantics, bf16 wire format -- runs on a one-GPU box; the line says so in dp.single_rank_collectives.
+    single_rank = world == 1 and os.environ.get("FSD_BENCH_SINGLE_RANK_RCCL", "0") == "1"
+    if world > 1 or single_rank:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -1010,7 +1017,7 @@ def _main(args, real_stdout):
     tmp = tempfile.mkdtemp()
     dyn_cfg, rw_cfg, _ = cfgs.write_standard_cfgs(tmp)
     blocks, lblocks = parse_cfg(dyn_cfg), parse_cfg(rw_cfg)
-    leg = Leg(dyn_cfg, rw_cfg, args.dtype, dev, dist, global_batch, args.mode)
+    leg = Leg(dyn_cfg, rw_cfg, args.dtype, dev, dist, global_batch, args.mode, single_rank_collectives=single_rank)
     leg.no_settle = args.no_settle
     if strong:      # one global episode: this rank's slice of the queries and targets, every support on every rank
         gx, metax, mask, gt = synth_episode(1000, args.batch, args.classes, args.size, args.support)
@@ -1119,13 +1126,14 @@ def _main(args, real_stdout):
                           "device_allocs_in_timed_region": r.get("device_allocs_in_timed_region")},
             "streams": {"enabled": bool(r.get("streams_on", streams_on)), "tuning": r.get("stream_tuning"),
                         "what": "reweighting net on its own stream beside the detector, weight gradients beside the data-gradient "
-                                "chain, target upload on a copy stream (fewshot_detection_amd/streams.py); bit-identical results",
+                                "chain, target upload through pinned staging (fewshot_detection_amd/streams.py); bit-identical results",
                         "profiled_steps_on_one_stream": r["prof_steps"], "profiled_step_index": r["prof_index"],
                         "ms_per_step_unprofiled": r["ms_unprofiled"], "ms_per_step_profiled": r["ms_profiled"]},
         }
         if leg.opt is not None:
             o = leg.opt
-            res["dp"] = {"world_size": o.world_size, "backend": backend if world > 1 else None, "scaling": args.scaling,
+            res["dp"] = {"world_size": o.world_size, "backend": backend if (world > 1 or single_rank) else None,
+                         "single_rank_collectives": bool(single_rank), "scaling": args.scaling,
                          "rccl_ranks": dist_world, "backend_reported": dist_backend,
                          "gradient_buckets": len(o.buckets), "allreduce_dtype": str(o.grad_dtype).replace("torch.", ""),
                          "bucket_mb": [4e-6 * (hi - lo) for lo, hi in o.buckets], "bucket_launch_order": list(o.launch_order_last),

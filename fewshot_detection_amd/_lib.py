@@ -70,6 +70,7 @@ PROTOTYPES = {
     "fsd_fill": (_i, [_p, _f, _ll, _p]),
     "fsd_reorg_fwd": (_i, [_p, _ll, _p, _ll, _i, _i, _i, _i, _i, _p]),
     "fsd_global_maxpool_fwd": (_i, [_p, _ll, _p, _p, _i, _i, _i, _i, _p]),
+    "fsd_upload_words": (_i, [_p, _p, _ll, _p]),
     "fsd_global_avgpool_fwd": (_i, [_p, _i, _ll, _p, _i, _i, _i, _i, _p]),
     "fsd_global_avgpool_bwd": (_i, [_p, _p, _i, _ll, _i, _i, _i, _i, _p]),
     "fsd_dynamic_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -558,4 +558,26 @@ extern "C" int fsd_fold_reweight_head(const float* head_w, const float* head_b, 
   return (int)hipGetLastError();
 }
 
+namespace {
+// 4-byte words; src may be PINNED HOST memory (the GPU reads it over the host link): the per-step upload of the RegionLoss
+// targets as a kernel.  A hipMemcpyAsync on a stream with work pending makes the HOST wait for that work on this runtime.
+__global__ __launch_bounds__(256) void upload_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                            long long words) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += stride)
+    dst[i] = __builtin_nontemporal_load(src + i);
+}
+}  // namespace
+
+extern "C" int fsd_upload_words(const void* src, void* dst, long long words, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!src || !dst || words < 0) return FSD_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) return FSD_ERR_ARG;
+  if (words == 0) return 0;
+  const long long want = (words + 255) / 256;
+  FSD_LAUNCH(upload_words_kernel, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, stream,
+             static_cast<const unsigned*>(src), static_cast<unsigned*>(dst), words);
+  return (int)hipGetLastError();
+}
+
 extern "C" const char* fsd_version(void) { return "fsdet-hip 0.1 (gfx950)"; }

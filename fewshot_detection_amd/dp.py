@@ -16,8 +16,8 @@ buffer is laid out in the order in which the backward pass FINISHES the gradient
 backward starts as soon as the head's backward has produced d(vectors) and is a few ms long), then the detector from
 its last layer down to layer 0 -- the 47 / 38 / 38 MB tensors of L29 / L24 / L23 come first, the small early layers last.
 Buckets are contiguous ranges of that order, the last one small.  The backward sweep calls the trainer after EVERY layer
-(ops.GRAD_HOOK); a bucket whose last gradient kernel has just been queued gets a "comm" stream that waits for the
-streams those kernels run on, and its all-reduce is started there -- while the sweep is still queueing (and the GPU still
+(ops.GRAD_HOOK); for a bucket whose last gradient kernel has just been queued the "meta" side stream (idle by then) waits for
+the streams those kernels run on, and its all-reduce is started there -- while the sweep is still queueing (and the GPU still
 running) the layers below.  Buckets start in ascending index on every rank (enforced), which is their readiness order.
 """
 import os
@@ -77,8 +77,12 @@ class EpisodeTrainer(object):
     """SGD(momentum, weight decay) + gradient all-reduce for one Darknet replica."""
 
     def __init__(self, net, lr, momentum=0.9, weight_decay=0.0, process_group=None, n_buckets=6, step_fn=None,
-                 grad_dtype=torch.float32):
-        """grad_dtype: wire format of the gradient all-reduce.  torch.bfloat16 (BASELINE configs[2] / [4]) halves the
+                 grad_dtype=torch.float32, single_rank_collectives=False):
+        """single_rank_collectives: with a process group of ONE rank, issue every collective anyway (broadcasts, the
+        bucketed all-reduce launched from a side stream, the host-side neg_filter reduction).  The sums over one rank are the
+        identity, so the result must equal the group-less trainer's bit for bit -- this is how the RCCL transport, its
+        stream semantics and the bf16 wire format are exercised on a one-GPU box (tests/test_gpu_dp.py).
+        grad_dtype: wire format of the gradient all-reduce.  torch.bfloat16 (BASELINE configs[2] / [4]) halves the
         xGMI payload (133 MB instead of 265 MB per step): each bucket is rounded to bf16 right before its
         collective and widened back before the fp32 optimizer step; master weights, momentum and the local gradient
         stay fp32."""
@@ -110,8 +114,10 @@ class EpisodeTrainer(object):
         self.steps = 0
         self._step_fn = step_fn or self._hip_step
         self.world_size = 1 if self.dist is None else int(self.dist.get_world_size())
+        # True when this trainer exchanges gradients at all (several ranks, or one rank asked to run its collectives)
+        self.collective = self.dist is not None and (self.world_size > 1 or bool(single_rank_collectives))
         self.grad_lp = None
-        if self.grad_dtype != torch.float32 and self.world_size > 1:
+        if self.grad_dtype != torch.float32 and self.collective:
             self.grad_lp = torch.empty_like(self.grad, dtype=self.grad_dtype)
         # per-bucket time the optimizer loop spent blocked in work.wait() (exposed all-reduce), accumulated over steps
         self.allreduce_wait_ms = [0.0] * len(self.buckets)
@@ -119,7 +125,7 @@ class EpisodeTrainer(object):
         self._neg_group = None
         self.neg_counts = None               # (n_pos, n_rows) -> sums over the ranks; None: the local counts are the batch's
         self._loss_modules = []
-        if self.world_size > 1:
+        if self.collective:
             self._install_global_neg_counts()
         self.sync_replicas()
 
@@ -193,7 +199,7 @@ class EpisodeTrainer(object):
         nn.DataParallel re-broadcasts module 0's state every step, train_meta.py:137-141; DDP does this once at
         construction).  Without it, ranks that seeded or loaded differently would apply the SUM of their gradients to
         different weights and silently diverge."""
-        if self.world_size <= 1:
+        if not self.collective:
             return
         self.dist.broadcast(self.flat, 0)
         self.dist.broadcast(self.mom, 0)
@@ -297,9 +303,9 @@ class EpisodeTrainer(object):
         """Start the all-reduce of every bucket whose gradients are complete (all of its parameters were written by
         the backward kernels, or -- `final` -- everything has been gathered).  Called by the backward sweep after every
         layer (ops.GRAD_HOOK) with the streams its gradient kernels were queued on: the collective is started on a
-        "comm" stream that waits for exactly those, so it runs under the rest of the sweep.  Every rank launches the
+        side stream that waits for exactly those, so it runs under the rest of the sweep.  Every rank launches the
         same buckets in the same (ascending = readiness) order."""
-        if self.dist is None or self.world_size <= 1:
+        if not self.collective:
             return
         if self.grad.is_cuda:
             for s_ in (torch.cuda.current_stream(),) + tuple(wait_streams):
@@ -317,13 +323,17 @@ class EpisodeTrainer(object):
             self._launch_host_ms[i] = (time.perf_counter() - self._t_backward0) * 1e3
             if self.grad.is_cuda:
                 from . import streams
-                comm = streams.side(self.grad.device, "comm")
+                # launched from the "meta" stream: it is idle by now (the reweighting net's sweep is the first thing a backward
+                # pass queues, and its gradients are the first bucket), and a stream of the collectives' own is one stream
+                # more than the four hardware queues carry without sharing (streams.py)
+                comm = streams.side(self.grad.device, self.collective_stream)
                 # A bucket can hold gradients queued on several streams at different times (the tail of the reweighting
                 # net's share, queued on the "meta" stream by the early sweep, shares a bucket with the detector's head):
                 # wait for EVERY stream this backward pass has reported so far, not only the reporting call's.  Streams are
                 # FIFO, so this waits for nothing that is not already due.
                 for s_ in self._streams_seen:
-                    comm.wait_stream(s_)
+                    if s_ != comm:
+                        comm.wait_stream(s_)
                 with torch.cuda.stream(comm):
                     if self.time_allreduce:
                         self._ready_events[i] = comm.record_event(torch.cuda.Event(enable_timing=True))
@@ -355,9 +365,9 @@ class EpisodeTrainer(object):
     def reduce_and_step(self):
         """Bucketed SUM all-reduce overlapped with the per-bucket optimizer kernel."""
         self._launch_ready((), final=True)
-        if self.world_size > 1 and self._launch_order != list(range(len(self.buckets))):
+        if self.collective and self._launch_order != list(range(len(self.buckets))):
             raise RuntimeError("all-reduce launch order %r is not 0..%d ascending" % (self._launch_order, len(self.buckets) - 1))
-        if self.time_allreduce and self.world_size > 1:
+        if self.time_allreduce and self.collective:
             self._overlap = {"order": list(self._launch_order), "host_ms": list(self._launch_host_ms),
                              "ready": list(self._ready_events), "bw_end": self._bw_end_event,
                              "bw_host_ms": self._bw_host_ms}
@@ -396,7 +406,7 @@ class EpisodeTrainer(object):
         finally:
             ops.GRAD_SINK, ops.GRAD_SUNK, ops.GRAD_HOOK = None, set(), None
         self._bw_host_ms = (time.perf_counter() - self._t_backward0) * 1e3
-        if self.time_allreduce and self.grad.is_cuda and self.world_size > 1:
+        if self.time_allreduce and self.grad.is_cuda and self.collective:
             self._bw_end_event = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
         # a bucket that is already being reduced had all of its parameters sunk: nothing of it is left to gather
         self.gather_grads(sunk)
@@ -410,6 +420,9 @@ class EpisodeTrainer(object):
     # allocator then synchronises and frees its cache mid-run (36-43 ms per step instead of 26).  Two steps in flight keep the
     # GPU fed (the next step's ~8 ms of enqueue hide behind the current one) and the footprint at ~2 steps' worth.
     max_steps_in_flight = 2
+
+    # the side stream the collectives are launched from (see _launch_ready)
+    collective_stream = os.environ.get("FSD_COLLECTIVE_STREAM", "meta")
 
     def _throttle(self):
         if not self.grad.is_cuda or self.max_steps_in_flight is None:

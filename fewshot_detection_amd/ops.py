@@ -15,6 +15,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def upload_words(src_pinned, dst, words):
+    """dst (device) <- `words` 4-byte words of src_pinned (page-locked host tensor), by a kernel on the current stream."""
+    if dst is None or not dst.is_cuda:
+        raise RuntimeError("upload_words: the destination must be a HIP device tensor")
+    if src_pinned.is_cuda or not src_pinned.is_pinned():
+        raise RuntimeError("upload_words: the source must be a page-locked host tensor")
+    check(lib().fsd_upload_words(src_pinned.data_ptr(), dst.data_ptr(), int(words), _stream()), "fsd_upload_words")
+
+
 def require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

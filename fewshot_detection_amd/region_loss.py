@@ -203,21 +203,10 @@ class _RegionBase(nn.Module):
         keep_map = np.full(rows, -1, np.int32)
         keep_map[keep] = np.arange(len(keep), dtype=np.int32)
         dev = output.device
-        # Pageable host->device copies block the host until the stream they are queued on has drained.  On the main stream
-        # that means "until the forward pass has run" (the host then queues loss + backward against an idle GPU); on the
-        # "copy" side stream it means "until this copy is done", so the host keeps queueing the step ahead of the GPU.
-        # (Pinned staging through torch's caching host allocator was tried and cost 3 ms per step in allocator
-        # synchronisation.)
-        if streams.ENABLED and dev.type == "cuda":
-            main, cs = torch.cuda.current_stream(), streams.side(dev, "copy")
-            with torch.cuda.stream(cs):
-                target_dev = torch.from_numpy(tr).to(dev)
-                keep_dev = torch.from_numpy(keep_map).to(dev)
-            main.wait_stream(cs)
-            streams.keep_alive(main, target_dev, keep_dev)
-        else:
-            target_dev = torch.from_numpy(tr).to(dev, non_blocking=True)
-            keep_dev = torch.from_numpy(keep_map).to(dev, non_blocking=True)
+        # Asynchronous copies out of pinned staging slots on the current stream (streams.upload): a pageable copy would block
+        # the host until the forward pass has run (it then queues loss + backward against an idle GPU).
+        target_dev = streams.upload(tr, dev)
+        keep_dev = streams.upload(keep_map, dev)
         dbg = None
         if self.debug_targets:
             dbg = torch.zeros((9, rows, self.num_anchors, output.shape[2], output.shape[3]),

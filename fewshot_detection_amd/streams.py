@@ -9,7 +9,13 @@ The step has three independent strands (train_meta.py:201-226 runs them back to 
   "wgrad" the detector's weight gradients: off the critical path (nothing in the backward sweep reads a dW),
           MFMA-bound, so they fill the matrix cores while the main stream runs its HBM-bound passes
           (activation backward, Winograd transforms) and the tails of its own GEMM launches
-  "copy"  the per-step target upload (so the pageable copy does not make the host wait for the forward)
+
+The per-step host data (RegionLoss targets) goes up through a small ring of PINNED staging buffers (upload() below), as an
+asynchronous copy on the current stream: a pageable copy blocks the host until its stream has drained, and the side
+stream that used to hide that ("copy", rounds 3-5) was one stream too many -- HIP maps streams onto four hardware queues,
+and with a collective backend's own stream in the process the copy stream landed on the main stream's queue: every step
+of a one-rank RCCL run took 34 ms instead of 25 (round 6, tools/experiments_r06/rccl_stream_probes.patch).  For the same
+reason the trainer's collectives are launched from the "meta" stream (dp.py) instead of a stream of their own.
 
 Kernels are unchanged and deterministic, so results are bit-identical with and without the side streams;
 only the order in which independent launches reach the GPU differs.  Ordering is by events; tensors that cross a
@@ -42,6 +48,53 @@ def side(device, name):
     return s
 
 
+_PINNED = {}      # device index -> [slot, ...]; slot = [pinned uint8 buffer, event of the last copy out of it]
+_PIN_NEXT = {}
+_PIN_SLOTS = 6    # more than the steps a trainer keeps in flight (dp.EpisodeTrainer.max_steps_in_flight = 2) x uploads per step
+
+
+def upload(array, device):
+    """Host numpy array -> new device tensor without ever blocking the host: the array is written into a pinned staging
+    slot and a KERNEL on the current stream reads it from there (fsd_upload_words; on this runtime a hipMemcpyAsync --
+    pageable or pinned -- queued behind pending work makes the host wait for that work).  A slot is re-used only after the
+    kernel that last read it has completed (its event; by then long past)."""
+    import numpy as np
+    from . import ops
+    dev = torch.device(device)
+    arr = np.ascontiguousarray(array)
+    t = torch.from_numpy(arr)
+    if dev.type != "cuda":
+        raise RuntimeError("fewshot_detection_amd needs a HIP device (got %s); there is no CPU fallback" % dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    nbytes = (arr.nbytes + 3) // 4 * 4
+    with _LOCK:
+        slots = _PINNED.setdefault(idx, [])
+        if len(slots) < _PIN_SLOTS:
+            slots.append([None, None])
+        k = _PIN_NEXT.get(idx, 0) % len(slots)
+        _PIN_NEXT[idx] = k + 1
+        slot = slots[k]
+    if slot[1] is not None:
+        slot[1].synchronize()
+    if slot[0] is None or slot[0].numel() < nbytes:
+        slot[0] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+    out = torch.empty(t.shape, dtype=t.dtype, device=dev)
+    if arr.nbytes:
+        # (numpy's single-threaded memcpy: torch's copy_ fans a 2 MB copy out to the intra-op thread pool, whose wake-up
+        # stalled the host for tens of ms now and then on a shared box)
+        np.copyto(slot[0].numpy()[:arr.nbytes], arr.reshape(-1).view(np.uint8))
+        if out.numel() * out.element_size() % 4:        # (odd byte counts: the kernel moves whole words into a padded twin)
+            pad = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ops.upload_words(slot[0], pad, nbytes // 4)
+            out.view(torch.uint8).reshape(-1).copy_(pad[:arr.nbytes])
+        else:
+            ops.upload_words(slot[0], out, nbytes // 4)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    slot[1] = ev
+    return out
+
+
 def reset():
     """Forget the side streams (new ones are taken from torch's pool on next use) and everything keyed on them.  HIP maps
     streams onto a handful of hardware queues; an unlucky mapping (a side stream sharing the main stream's queue) turns the
@@ -55,7 +108,7 @@ def reset():
         _EARLY.clear()
 
 
-def autotune(step, tries=3, reps=2, slack=1.03, good=0.96):
+def autotune(step, tries=3, reps=2, slack=1.03, good=0.96, fixed_schedule=False):
     """Find side streams that pay on THIS process / GPU: time `reps` synchronised calls of `step` on one stream and with the
     side streams.  A set that brings the step to `good` x the one-stream time or better is kept at once (the overlap is worth
     ~5 % of the step when it works); otherwise the streams are re-created (a new draw of the stream -> hardware-queue mapping)
@@ -64,6 +117,8 @@ def autotune(step, tries=3, reps=2, slack=1.03, good=0.96):
     process in eight starts with a stream set on which a step takes 36-43 ms instead of 26 (the one-stream step: 27.5), and
     now and then with one that overlaps only half as well (28.8 against 25.4 ms), for as long as those streams live.
     -> dict(report).  A no-op when the streams are disabled.
+    fixed_schedule: EVERY timing is run whatever the earlier ones showed (1 + tries timings of 1 + reps steps) -- for steps
+    that hold collectives, where every rank must execute the same number of them; which set a rank keeps stays its own decision.
     NOTE for library users: `step` is EXECUTED (1 + reps calls per timing, up to 2 * (tries + 1) timings) -- if it is a training
     step, the weights, the optimizer state and BatchNorm's running statistics advance by that many steps and stay advanced."""
     import time
@@ -92,7 +147,7 @@ def autotune(step, tries=3, reps=2, slack=1.03, good=0.96):
             if best is None or on < best[0]:
                 with _LOCK:
                     best = (on, dict(_SIDE))
-            if on <= good * off:
+            if on <= good * off and not fixed_schedule:
                 break
             reset()
         if best[0] <= slack * off:

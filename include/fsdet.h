@@ -308,6 +308,11 @@ int fsd_global_avgpool_fwd(const void* x, int x_bf16, long long x_ld, float* out
 int fsd_global_avgpool_bwd(const float* dout, void* dx, int dx_bf16, long long dx_ld, int batch, int height, int width,
                            int channels, hipStream_t stream);
 
+/* Host -> device hand-over of per-step data (the (B, N, 250) float64 target tensor the reference's loss receives on the CPU,
+ * train_meta.py:211 / region_loss.py:252): `words` 4-byte words from src to dst by a KERNEL.  src may be page-locked HOST
+ * memory (hipHostMalloc: device-readable); the launch never blocks the host, unlike a memcpy on a busy stream. */
+int fsd_upload_words(const void* src, void* dst, long long words, hipStream_t stream);
+
 /* ---- channel-wise reweighting (dynamic_conv.py:125-164) ----------------------------------- */
 /* Materialising form, NCHW like the reference module: out[b*N+n, c, hw] = x[b, c, hw] * w[n, c]. */
 int fsd_dynamic_conv_fwd(const float* x, const float* w, float* out, int batch, int n_cls, int channels,

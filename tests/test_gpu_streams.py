@@ -1,5 +1,5 @@
 """Side streams (fewshot_detection_amd/streams.py): the reweighting net beside the detector, the weight gradients beside
-the data-gradient chain, the target upload on a copy stream.  Kernels are unchanged and deterministic, so a step with
+the data-gradient chain (the target upload is an asynchronous copy out of pinned staging, streams.upload).  Kernels are unchanged and deterministic, so a step with
 the side streams must be BIT-identical to the same step on one stream -- any difference is a missing dependency."""
 import random
 
@@ -155,3 +155,32 @@ def test_autotune_keeps_streams_that_pay_and_drops_streams_that_do_not():
     finally:
         streams.reset()
         streams.ENABLED = before
+
+
+def test_upload_through_pinned_staging_is_exact_and_reuses_its_slots():
+    """streams.upload: host array -> device tensor by a kernel that reads a pinned staging slot (no memcpy, no side stream).
+    More uploads than slots, sizes that grow, odd byte counts, float64 targets of the loss's shape; every one bit-exact, also
+    when queued behind pending GPU work."""
+    import numpy as np
+    from fewshot_detection_amd import streams
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    busy = torch.randn(4096, 4096, device=dev)
+    outs, refs = [], []
+    for i in range(20):
+        (busy @ busy).sum()                                  # pending work on the stream the upload is queued on
+        if i % 3 == 0:
+            a = rng.standard_normal((960, 250))              # the (B*N, 250) float64 target
+        elif i % 3 == 1:
+            a = rng.integers(-5, 5, size=(960 + i,), dtype=np.int32)
+        else:
+            a = rng.integers(0, 255, size=(1001 + 2 * i,), dtype=np.uint8)    # odd byte count
+        outs.append(streams.upload(a, dev))
+        refs.append(a.copy())
+        a[...] = 0                                           # the caller may overwrite its array at once
+    e = streams.upload(np.zeros((0, 250)), dev)
+    torch.cuda.synchronize()
+    assert e.shape == (0, 250)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and np.array_equal(o.cpu().numpy(), r)
+    assert len(streams._PINNED[0]) <= streams._PIN_SLOTS
