@@ -14,9 +14,8 @@
 // against 2 x dz/dt + 2 x y + dt before (416x416x32 fp32 at B = 64: 1.9 GB instead of 6.0 GB).
 //
 // MFMA formulation (v_mfma_f32_32x32x2_f32, no LDS staging, as in wgrad_first_kernel): a wave owns a run of pooling
-// cells; a cell is two k-steps of two pixels (its top and its bottom row).  Lane (c, h): A operand = channel c of pixel
-// column h, B operand = (tap, ci) column c of the same pixel.  The pool winner of a cell needs the four activations of
-// the window: two are this lane's (top / bottom of column h), two the partner lane's (lane ^ 32).
+// cells and takes them in pairs; a pair is four k-steps (the four window pixels) of two pixels (one from each cell).
+// Lane (c, h): A operand = channel c of the pixel of cell h, B operand = (tap, ci) column c of the same pixel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -40,26 +39,39 @@ struct FirstBwdArgs {
   unsigned dz_ld, y_ld, x_ld;
   int H, W, OH, OW, Cout;
   long long cells;
-  int cpw;                                 // cells per wave (multiple of 2 * CPG)
+  int cpw;                                 // cells per wave (multiple of 8: a wave works on PAIRS of cells)
   float slope;
 };
 
 // SIDE = false: 3 input channels, the 27 (tap, ci) columns fit one 32-wide MFMA tile.
 // SIDE = true : 4 input channels, taps 0..7 in the tile and the ninth tap as FMA side sums per lane.
-// CPG = cells per load group (one group of loads is in flight ahead of the MFMAs of the previous one).
-template <bool SIDE, typename T, int CPG>
+//
+// Round 6 lane mapping.  A wave walks its run of pooling cells two at a time: lane (c, h) owns the WHOLE 2x2 window of cell
+// 2i + h for channel c (A role) and column c of the same four pixels (B role), so the pool winner is found in the lane (no
+// lane exchange), only the winner carries a gradient (one select chain instead of four), and one MFMA pair per window pixel
+// takes k = h from the two cells.  The B operand -- 27 (36) values around each pixel -- no longer comes from per-lane
+// gathers: the 4 x 6-pixel input patch of the cell pair is fetched by ONE 16-byte load on 24 lanes (out-of-image pixels as
+// zeros), parked in a wave-private LDS slot, and every lane picks its taps with ds_read at constant offsets.  Before: lane
+// (c, h) held pixel COLUMN h of one cell, both lanes of a pair worked out the same winner through two lane exchanges, and
+// five loads per cell -- two of them gathers over ~8 cache lines each -- kept the CU's one texture path busier than its
+// four matrix pipes: 0.75 ms on the 416x416 layer in both storage types, 2.6x the MFMA time; now 0.57 / 0.56 ms (fp32 / bf16
+// storage).  What bounds it now (tools/probes/first_bwd_ablate.sh, B = 64): with the S3 MFMAs compiled out 0.42 ms, with all
+// of them out 0.39 ms fp32 (= the 1.95 GB of dz, y and x at 5 TB/s) / 0.26 ms bf16 -- the fp32-MFMA work (0.29 ms at the
+// peak rate) and the HBM-bound sweep overlap only partly.  The workgroup count does not matter (1024..5120: +-2 %).
+template <bool SIDE, typename T>
 __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
-  constexpr int kCPG = CPG;
   constexpr unsigned ES = sizeof(T);
-  __shared__ float s_out[4][32 * 36 + 36 + 64];       // per wave: a [32][36] tile, then S2[36], then BN sums [32][2]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float s_out[4][32 * 36 + 36 + 64];   // per wave: the input patch while sweeping;
+                                                                                // afterwards a [32][36] tile, S2[36], BN sums [32][2]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int c = lane & 31, h = lane >> 5;
   const int co = blockIdx.y * 32 + c;
   const float sc = p.scale[co], sh = p.shift[co], mu = p.mean[co], is = p.invstd[co];
   const int tap = SIDE ? c >> 2 : c / 3, ci = SIDE ? c & 3 : c - 3 * (c / 3);
   const bool col_ok = SIDE || c < 27;
   const int ky = tap / 3, kx = tap - 3 * ky;
-  const int dyo = ky - 1, dxo = kx - 1;
+  const int dyo = col_ok ? ky - 1 : 0, dxo = col_ok ? kx - 1 : 0;      // (columns 27..31 of the 3-channel tile: the centre tap)
   const long long c_begin = ((long long)blockIdx.x * 4 + wave) * p.cpw;
   const long long c_end = c_begin + p.cpw < p.cells ? c_begin + p.cpw : p.cells;
   const int len = (int)(c_end - c_begin);                    // cells of this wave (may be <= 0)
@@ -69,105 +81,121 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
   float a81[4] = {0.f, 0.f, 0.f, 0.f}, a83[4] = {0.f, 0.f, 0.f, 0.f}, s2c8[4] = {0.f, 0.f, 0.f, 0.f};
   float s1 = 0.f, s2 = 0.f, s2c = 0.f;
   if (len > 0) {
-    // window coordinates of the wave's first cell; afterwards +1 cell per step
-    int cx = (int)(c_begin % p.OW);
-    const long long t0 = c_begin / p.OW;
-    int cy = (int)(t0 % p.OH);
-    const long long b0 = t0 / p.OH;
-    const unsigned pix_top0 = (unsigned)((b0 * p.H + 2 * cy) * p.W + 2 * cx);
+    const int OW = p.OW, OH = p.OH, W = p.W, H = p.H;
+    // UNIFORM position of the pair's first cell: column, row within the image, global cell row (b * OH + cy), cell index
+    int cx0 = (int)(c_begin % OW);
+    const long long t0 = c_begin / OW;
+    int cy0 = (int)(t0 % OH);
+    unsigned r0 = (unsigned)t0, n0 = (unsigned)c_begin;
+    int rel = 0;
     const char* dz_b = reinterpret_cast<const char*>(p.dz);
     const char* y_b = reinterpret_cast<const char*>(p.y);
     const char* x_b = reinterpret_cast<const char*>(p.x);
-    // 32-bit BYTE offsets from the (uniform) base pointers; the launcher guarantees they fit
-    unsigned off_dz = ((unsigned)c_begin * p.dz_ld + co) * ES;
-    unsigned off_y = ((pix_top0 + h) * p.y_ld + co) * ES;          // top pixel of this lane's column
-    unsigned off_x = (pix_top0 + h) * p.x_ld * 4u;
-    const unsigned safe_dz = off_dz, safe_y = off_y;
-    const unsigned row_y = (unsigned)p.W * p.y_ld * ES, row_x = (unsigned)p.W * p.x_ld * 4u;
-    const unsigned step_dz = p.dz_ld * ES, step_y = 2u * p.y_ld * ES, step_x = 8u * p.x_ld;     // one cell = two pixel columns
-    const int kb = ((dyo * p.W + dxo) * (int)p.x_ld + ci) * 4, k8 = (p.W + 1) * (int)p.x_ld * 4;
-    int rel = 0;
-    // Loads are unconditional from clamped (always mapped) offsets and the zero-selects happen at use, so all loads of
-    // a group are in flight together, one group ahead of the MFMAs.
-    struct Group { float yt[kCPG], yb[kCPG], gz[kCPG], bt[kCPG], bb[kCPG]; f32x4 x8t[SIDE ? kCPG : 1], x8b[SIDE ? kCPG : 1]; unsigned mask; };
-    auto load = [&](Group& g) {
-      g.mask = 0;
+    // lane-constant byte offsets of the window pixels j = 2 * row + col from the pair's first pixel (the lane's cell is 2 h
+    // pixels to the right)
+    const unsigned l_dz = ((unsigned)h * p.dz_ld + (unsigned)co) * ES;
+    unsigned l_y[4];
 #pragma unroll
-      for (int s = 0; s < kCPG; ++s) {
-        const bool valid = rel < len;
-        const int yy = 2 * cy, xx = 2 * cx + h;
-        g.yt[s] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + (valid ? off_y : safe_y)));
-        g.yb[s] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + (valid ? off_y + row_y : safe_y)));
-        g.gz[s] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(dz_b + (valid ? off_dz : safe_dz)));
-        const bool x_in = (unsigned)(xx + dxo) < (unsigned)p.W;
-        const bool okt = valid && col_ok && x_in && (unsigned)(yy + dyo) < (unsigned)p.H;
-        const bool okb = valid && col_ok && x_in && (unsigned)(yy + 1 + dyo) < (unsigned)p.H;
-        g.bt[s] = *reinterpret_cast<const float*>(x_b + (okt ? off_x + (unsigned)kb : 0u));
-        g.bb[s] = *reinterpret_cast<const float*>(x_b + (okb ? off_x + row_x + (unsigned)kb : 0u));
-        g.mask |= (valid ? 1u : 0u) << s;
-        g.mask |= (okt ? 1u : 0u) << (4 + s);
-        g.mask |= (okb ? 1u : 0u) << (8 + s);
-        if constexpr (SIDE) {
-          const bool ok8t = valid && xx + 1 < p.W;                        // tap (+1, +1) of the top pixel: row 2cy+1 < H
-          const bool ok8b = valid && xx + 1 < p.W && yy + 2 < p.H;
-          g.x8t[s] = *reinterpret_cast<const f32x4*>(x_b + (ok8t ? off_x + (unsigned)k8 : 0u));
-          g.x8b[s] = *reinterpret_cast<const f32x4*>(x_b + (ok8b ? off_x + row_x + (unsigned)k8 : 0u));
-          g.mask |= (ok8t ? 1u : 0u) << (12 + s);
-          g.mask |= (ok8b ? 1u : 0u) << (16 + s);
-        }
-        ++rel; off_dz += step_dz; off_y += step_y; off_x += step_x;
-        if (++cx == p.OW) {             // next window row: skip the bottom pixel row just covered
-          cx = 0;
-          off_y += row_y; off_x += row_x;
-          if (++cy == p.OH) cy = 0;     // next image follows contiguously (H = 2 OH)
-        }
+    for (int j = 0; j < 4; ++j) l_y[j] = ((2u * h + (j & 1) + (unsigned)(j >> 1) * W) * p.y_ld + (unsigned)co) * ES;
+    // the patch: image rows 2 cy0 - 1 .. + 2, columns 2 cx0 - 1 .. + 4, one 16-byte pixel per lane < 24
+    const int prow = lane / 6, pcol = lane - 6 * prow;
+    const bool p_lane = lane < 24;
+    const int l_p = p_lane ? ((prow - 1) * W + (pcol - 1)) * (int)p.x_ld * 4 : 0;       // from the pair's first pixel, may be < 0
+    float* patch = s_out[wave];
+    // this lane's taps in the patch (float index): pixel j adds ((j >> 1) * 6 + (j & 1)) * 4
+    const int l_b = ((1 + dyo) * 6 + (1 + 2 * h + dxo)) * 4 + ci;
+    const int l_8 = (2 * 6 + (2 + 2 * h)) * 4;
+    // 32-bit byte offsets everywhere (the launcher guarantees they fit)
+    struct Group { float y[4]; float gz; f32x4 px; bool valid; bool in; bool live; };
+    // Loads are unconditional from clamped (always mapped) offsets and the zero-selects happen at use, so the six loads of a
+    // pair are in flight together, one pair ahead of the MFMAs (no branch in here: the compiler counts vmcnt exactly).
+    auto load = [&](Group& g) {
+      g.live = rel < len;
+      const bool wrap = cx0 + 1 >= OW;                                     // the pair's second cell starts a new cell row:
+      const bool valid = rel + h < len && !(wrap && h);                    // it is left to the next step
+      const unsigned p00 = 2u * (n0 + r0 * (unsigned)OW);
+      const unsigned o_safe = (unsigned)co * ES;                          // always mapped
+      g.gz = fsd_ew::ld1<T>(reinterpret_cast<const T*>(dz_b + (valid ? n0 * p.dz_ld * ES + l_dz : o_safe)));
+      const unsigned yq = p00 * p.y_ld * ES;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        g.y[j] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + (valid ? yq + l_y[j] : o_safe)));
+      const int yy = 2 * cy0 - 1 + prow, xx = 2 * cx0 - 1 + pcol;
+      const bool in = g.live && p_lane && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      g.px = *reinterpret_cast<const f32x4*>(x_b + (in ? (unsigned)((int)(p00 * p.x_ld * 4u) + l_p) : 0u));
+      g.valid = valid;
+      g.in = in;
+      const int adv = wrap ? 1 : 2;
+      rel += adv; n0 += adv; cx0 += adv;
+      while (cx0 >= OW) {                 // next cell row
+        cx0 -= OW; ++r0;
+        if (++cy0 == OH) cy0 = 0;
       }
     };
     auto compute = [&](const Group& g) {
+      // hand the patch to the wave (wave-private LDS slot; the wave's own LDS operations execute in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (p_lane) *reinterpret_cast<f32x4*>(patch + 4 * lane) = g.in ? g.px : f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const bool valid = g.valid;
+      float b[4];
+      f32x4 x8[SIDE ? 4 : 1];
 #pragma unroll
-      for (int s = 0; s < kCPG; ++s) {
-        const bool valid = (g.mask >> s) & 1u;
-        const float yt = g.yt[s], yb = g.yb[s];
-        const float gz = valid ? g.gz[s] : 0.f;
-        const float tt = __builtin_fmaf(yt, sc, sh), tb = __builtin_fmaf(yb, sc, sh);
-        const float at = tt > 0.f ? tt : tt * p.slope, ab = tb > 0.f ? tb : tb * p.slope;
-        const float pt = __shfl_xor(at, 32, 64), pb = __shfl_xor(ab, 32, 64);
-        // the window in scan order (first maximum wins, like torch and fsd_bn_act_pool_bwd)
-        const float q0 = h ? pt : at, q1 = h ? at : pt, q2 = h ? pb : ab, q3 = h ? ab : pb;
-        int bq = 0;
-        float bv = q0;
-        if (q1 > bv) { bv = q1; bq = 1; }
-        if (q2 > bv) { bv = q2; bq = 2; }
-        if (q3 > bv) { bq = 3; }
-        const float gt = bq == h ? gz : 0.f, gb = bq == 2 + h ? gz : 0.f;
-        const float dtop = tt > 0.f ? gt : gt * p.slope, dbot = tb > 0.f ? gb : gb * p.slope;
-        const float xt = valid ? (yt - mu) * is : 0.f, xb = valid ? (yb - mu) * is : 0.f;
-        s1 += dtop; s1 += dbot;
-        s2 += dtop * xt; s2 += dbot * xb;
-        // the weight gradient sees dt as the unfused path would have STORED it (bf16 mode: rounded)
-        const float dq_t = fsd_ew::stored<T>(dtop), dq_b = fsd_ew::stored<T>(dbot);
-        const float bt = ((g.mask >> (4 + s)) & 1u) ? g.bt[s] : 0.f;
-        const float bb = ((g.mask >> (8 + s)) & 1u) ? g.bb[s] : 0.f;
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dq_t, bt, acc1, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xt, bt, acc3, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dq_b, bb, acc1, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb, bb, acc3, 0, 0, 0);
-        s2c += bt; s2c += bb;
+      for (int j = 0; j < 4; ++j) {
+        const float v = patch[l_b + ((j >> 1) * 6 + (j & 1)) * 4];
+        b[j] = valid ? v : 0.f;
         if constexpr (SIDE) {
-          const bool o8t = (g.mask >> (12 + s)) & 1u, o8b = (g.mask >> (16 + s)) & 1u;
+          const f32x4 w = *reinterpret_cast<const f32x4*>(patch + l_8 + ((j >> 1) * 6 + (j & 1)) * 4);
+          x8[j] = valid ? w : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      float a[4], xh[4];
+      bool pos[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float vt = o8t ? g.x8t[s][j] : 0.f, vb = o8b ? g.x8b[s][j] : 0.f;
-            a81[j] += dq_t * vt; a81[j] += dq_b * vb;
-            a83[j] += xt * vt; a83[j] += xb * vb;
-            s2c8[j] += vt; s2c8[j] += vb;
+      for (int j = 0; j < 4; ++j) {
+        const float t = __builtin_fmaf(g.y[j], sc, sh);
+        pos[j] = t > 0.f;
+        a[j] = pos[j] ? t : t * p.slope;
+        const float v = (g.y[j] - mu) * is;
+        xh[j] = valid ? v : 0.f;
+      }
+      // the window in scan order, first maximum wins (like torch and fsd_bn_act_pool_bwd)
+      const bool w1 = a[1] > a[0];
+      const float m1 = w1 ? a[1] : a[0];
+      const bool w2 = a[2] > m1;
+      const float m2 = w2 ? a[2] : m1;
+      const bool w3 = a[3] > m2;
+      const bool win[4] = {!w1 && !w2 && !w3, w1 && !w2 && !w3, w2 && !w3, w3};
+      const bool posw = (win[0] && pos[0]) || (win[1] && pos[1]) || (win[2] && pos[2]) || (win[3] && pos[3]);
+      const float gz = valid ? g.gz : 0.f;
+      const float dsel = posw ? gz : gz * p.slope;             // the one non-zero dt of the window
+      const float xw = win[3] ? xh[3] : win[2] ? xh[2] : win[1] ? xh[1] : xh[0];
+      s1 += dsel;
+      s2 = __builtin_fmaf(dsel, xw, s2);
+      // the weight gradient sees dt as the unfused path would have STORED it (bf16 mode: rounded)
+      const float dq = fsd_ew::stored<T>(dsel);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dqj = win[j] ? dq : 0.f;
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dqj, b[j], acc1, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xh[j], b[j], acc3, 0, 0, 0);
+        s2c += b[j];
+        if constexpr (SIDE) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a81[i] = __builtin_fmaf(dqj, x8[j][i], a81[i]);
+            a83[i] = __builtin_fmaf(xh[j], x8[j][i], a83[i]);
+            s2c8[i] += x8[j][i];
           }
         }
       }
     };
     Group g0, g1;
     load(g0);
-    for (int done = 0; done < len; done += 2 * kCPG) {
+    while (g0.live) {                     // (a pair past the end of the run loads from the safe offsets and adds zeros)
       load(g1);
       __builtin_amdgcn_sched_barrier(0);
       compute(g0);
@@ -177,6 +205,9 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
       compute(g1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // the epilogue re-uses the patch slot
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   // ---- fold the four waves through LDS and write this workgroup's partials (fixed order: deterministic) ----
   float* so = s_out[wave];
@@ -275,7 +306,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 inline int fb_blocks(long long cells) {
   long long b = (cells + 4 * 64 - 1) / (4 * 64);              // at least 64 cells (256 pixels) per wave
-  return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+  static const char* env = FSD_TUNE("FSD_FB_BLOCKS");         // (tuning aid)
+  const long long cap = env ? atoll(env) : 2048;
+  return (int)(b < 1 ? 1 : b > cap ? cap : b);
 }
 
 template <typename T>
@@ -301,23 +334,12 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   a.partial = partial;
   a.dz_ld = (unsigned)dz_ld; a.y_ld = (unsigned)y_ld; a.x_ld = (unsigned)x_ld;
   a.H = height; a.W = width; a.OH = height / 2; a.OW = width / 2; a.Cout = cout; a.cells = cells;
-  // cells per load group: 1 (92 VGPRs, 5 waves per SIMD) measured fastest on the L0 shape -- 0.91 ms fp32 / 0.94 ms bf16
-  // against 0.92 / 1.03 (2 cells, 108-168 VGPRs) and 0.96 / 1.07 (4 cells); FSD_FB_CPG = 1|2|4 is a tuning aid
-  static const char* env = FSD_TUNE("FSD_FB_CPG");
-  const int cpg = env ? atoi(env) : 1;
   a.cpw = round_up((int)((cells + (long long)blocks * 4 - 1) / ((long long)blocks * 4)), 8);
   a.slope = slope;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (sizeof(T) * cout * 1.25 + 16.0), stream);
   const dim3 grid(blocks, cout / 32);
-  if (cin == 4) {
-    if (cpg == 1) FSD_LAUNCH((first_bwd_kernel<true, T, 1>), grid, dim3(256), 0, stream, a);
-    else if (cpg == 4) FSD_LAUNCH((first_bwd_kernel<true, T, 4>), grid, dim3(256), 0, stream, a);
-    else FSD_LAUNCH((first_bwd_kernel<true, T, 2>), grid, dim3(256), 0, stream, a);
-  } else {
-    if (cpg == 1) FSD_LAUNCH((first_bwd_kernel<false, T, 1>), grid, dim3(256), 0, stream, a);
-    else if (cpg == 4) FSD_LAUNCH((first_bwd_kernel<false, T, 4>), grid, dim3(256), 0, stream, a);
-    else FSD_LAUNCH((first_bwd_kernel<false, T, 2>), grid, dim3(256), 0, stream, a);
-  }
+  if (cin == 4) FSD_LAUNCH((first_bwd_kernel<true, T>), grid, dim3(256), 0, stream, a);
+  else FSD_LAUNCH((first_bwd_kernel<false, T>), grid, dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 
