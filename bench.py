@@ -333,6 +333,8 @@ class Leg(object):
         self.region = self.net.models[len(self.net.models) - 1]
         self.region.verbose = False
         self.opt = None
+        from fewshot_detection_amd import streams as _streams
+        self.streams_requested = bool(_streams.ENABLED)     # the process-wide request (flag / environment), the same on every rank
         if mode == "train":
             from fewshot_detection_amd.dp import EpisodeTrainer
             # train_meta.py:123-147: lr = 0.001/factor/global_batch, wd = decay*global_batch*factor (factor 3 for
@@ -372,10 +374,11 @@ class Leg(object):
             step()
         self.fence()
         self.stream_tuning = None
-        if streams_on and self.opt is not None:
+        if (streams_on or (self.dist is not None and self.streams_requested)) and self.opt is not None:
             # untimed: make sure the side streams pay in THIS process (streams.autotune: an unlucky stream -> hardware-queue
             # mapping makes a step 40 % slower for the life of the streams; it re-draws them or falls back to one stream)
-            # (several ranks: a FIXED number of probing steps on every rank -- each step holds the gradient collectives)
+            # (several ranks: a FIXED number of probing steps on every rank -- each step holds the gradient collectives --
+            # whatever a rank decided in an earlier leg: the condition must be the same on every rank)
             self.stream_tuning = streams.autotune(step, fixed_schedule=self.dist is not None)
             streams_on = streams.ENABLED
             self.fence()

@@ -845,8 +845,15 @@ __global__ __launch_bounds__(256) void wgrad_h_partial_kernel(const float* __res
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int k0 = blockIdx.y * kFoldGroup, k1 = min(splits, k0 + kFoldGroup);
+  // loads four at a time, sums in slice order (the plain loop issued one dependent-latency load per trip)
   float s = 0.f;
-  for (int k = k0; k < k1; ++k) s += ws[(long long)k * total + idx];
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    const float v0 = ws[(long long)k * total + idx], v1 = ws[(long long)(k + 1) * total + idx];
+    const float v2 = ws[(long long)(k + 2) * total + idx], v3 = ws[(long long)(k + 3) * total + idx];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; k < k1; ++k) s += ws[(long long)k * total + idx];
   out[(long long)blockIdx.y * total + idx] = s;
 }
 
@@ -864,7 +871,13 @@ __global__ __launch_bounds__(256) void wgrad_h_fold_kernel(const float* __restri
     if (c < nci) {
       const float* p = base + (long long)tap * cin + c;
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += p[(long long)k * total];
+      int k = 0;
+      for (; k + 4 <= splits; k += 4) {       // four loads in flight, summed in slice order
+        const float v0 = p[(long long)k * total], v1 = p[(long long)(k + 1) * total];
+        const float v2 = p[(long long)(k + 2) * total], v3 = p[(long long)(k + 3) * total];
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; k < splits; ++k) s += p[(long long)k * total];
       stage[c * TAPS + tap] = s;
     }
   }

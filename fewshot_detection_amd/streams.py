@@ -124,7 +124,9 @@ def autotune(step, tries=3, reps=2, slack=1.03, good=0.96, fixed_schedule=False)
     import time
     global ENABLED
     report = {"enabled_before": ENABLED, "tries": []}
-    if not ENABLED or not torch.cuda.is_available():
+    # (fixed_schedule: a rank whose streams were switched off by an earlier call still runs the whole schedule -- the ranks
+    # stay in lockstep -- and may switch them on again)
+    if (not ENABLED and not fixed_schedule) or not torch.cuda.is_available():
         report["enabled_after"] = ENABLED
         return report
 

@@ -525,6 +525,8 @@ def test_plain_decode_vs_reference_golden(dev, k):
 def test_clock_probe_reports_a_plausible_shader_clock(dev):
     """fsd_clock_probe: a dependent fp32-MFMA chain of known length (64 cycles per instruction) timed with HIP events."""
     from fewshot_detection_amd import ops
-    mhz = [ops.clock_probe_mhz(dev) for _ in range(3)]
-    assert all(500.0 < v < 3000.0 for v in mhz), mhz
-    assert max(mhz) / min(mhz) < 1.5, mhz
+    mhz = sorted(ops.clock_probe_mhz(dev) for _ in range(7))
+    # (the boxes are shared: a single reading can catch the chip throttled or time-sliced -- 138 MHz was seen once among
+    # 2208 / 2224; bench.py waits such a phase out.  The median and its neighbours are the property.)
+    assert 500.0 < mhz[3] < 3000.0, mhz
+    assert mhz[4] / mhz[2] < 1.5, mhz
