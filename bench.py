@@ -412,10 +412,9 @@ class Leg(object):
             # timed region were not a settling problem: the timed loop kept each step's loss -- and through it the network's
             # tape, ~8 GB of activations -- alive during the next forward, a peak the settle loop never produced.  The tape is
             # released by the backward pass now, darknet_meta._NetFn.backward; tools/alloc_trace.py, VERDICT r5 #4.)
-            # (several ranks: a FIXED number of bursts -- every step holds collectives, and the ranks' allocators need not go
-            # quiet after the same number of them)
+            # (several ranks: every step holds collectives, so the ranks agree after each burst whether ALL of them were quiet)
             bursts = 0
-            while bursts < (4 if self.dist is None else 1):
+            while bursts < 4:
                 if prof_steps:                # (the timed region's one-stream step and its two synchronisations belong to
                     prof_form_step()          # the regime being settled)
                 for _ in range(12):
@@ -425,7 +424,11 @@ class Leg(object):
                 now = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
                 quiet = now == last
                 last = now
-                if quiet and self.dist is None:
+                if self.dist is not None:     # every step holds collectives: the ranks stop together, when ALL allocators are quiet
+                    q = torch.tensor([1 if quiet else 0], dtype=torch.int32, device=self.dev)
+                    self.dist.all_reduce(q, op=self.dist.ReduceOp.MIN)
+                    quiet = bool(int(q.item()))
+                if quiet:
                     break
             self.fence()
         if self.opt is not None:

@@ -103,6 +103,9 @@ class EpisodeTrainer(object):
                     self._bucket_params[i].append(id(p))
             off += p.numel()
         self._works = [None] * len(self.buckets)
+        self._stepped = [False] * len(self.buckets)              # buckets whose optimizer step was queued during the backward
+        self.early_steps_last = 0                                # ... how many of them in the last step
+        self._conv_by_bucket = None
         self._launch_order = []              # bucket indices in the order their all-reduce was started this step
         self.launch_order_last = []          # ... of the last completed step
         self._t_backward0 = 0.0
@@ -299,30 +302,45 @@ class EpisodeTrainer(object):
                 p.grad = None
             off += n
 
+    # Optimizer step of a bucket as soon as its gradients are final -- DURING the backward pass, on the side stream the
+    # collectives are launched from: the SGD kernel and the re-packing of the bucket's conv operands (weight transforms of the
+    # Winograd layers, K-major copies: ~0.9 ms of HBM-bound kernels per fp32 step, 0.4 ms in bf16 mode) run under the
+    # MFMA-bound layers the sweep still has to do, instead of between the steps.  Same kernels on the same values: results
+    # are bit-identical.  EARLY_STEP = False: every bucket is stepped after the backward pass, on the main stream.
+    EARLY_STEP = os.environ.get("FSD_EARLY_STEP", "1") != "0"
+
+    def _early_ok(self):
+        if not (self.EARLY_STEP and streams.ENABLED and self.grad.is_cuda and self._step_fn == self._hip_step):
+            return False
+        # (gloo's wait() blocks the HOST until the reduction is done: only a stream-ordered backend can be stepped early)
+        return (not self.collective) or str(self.dist.get_backend()) == "nccl"
+
     def _launch_ready(self, sunk, final=False, wait_streams=()):
         """Start the all-reduce of every bucket whose gradients are complete (all of its parameters were written by
         the backward kernels, or -- `final` -- everything has been gathered).  Called by the backward sweep after every
-        layer (ops.GRAD_HOOK) with the streams its gradient kernels were queued on: the collective is started on a
-        side stream that waits for exactly those, so it runs under the rest of the sweep.  Every rank launches the
-        same buckets in the same (ascending = readiness) order."""
-        if not self.collective:
+        layer (ops.GRAD_HOOK) with the streams its gradient kernels were queued on: the collective is started from a
+        side stream that waits for exactly those, so it runs under the rest of the sweep -- and, where the backend allows,
+        the bucket's optimizer step right behind it (EARLY_STEP).  Every rank launches the same buckets in the same
+        (ascending = readiness) order."""
+        early = (not final) and self._early_ok()
+        if not self.collective and not early:
             return
         if self.grad.is_cuda:
             for s_ in (torch.cuda.current_stream(),) + tuple(wait_streams):
                 if s_ is not None and not any(s_ == t for t in self._streams_seen):
                     self._streams_seen.append(s_)
         for i, (lo, hi) in enumerate(self.buckets):
-            if self._works[i] is not None:
+            if self._works[i] is not None or self._stepped[i]:
                 continue
             if not (final or all(pid in sunk for pid in self._bucket_params[i])):
                 break          # strictly ascending bucket order on every rank, whatever order the networks finish in
-            if self._launch_order and self._launch_order[-1] >= i:
-                raise RuntimeError("gradient buckets must be reduced in ascending order on every rank (bucket %d after "
-                                   "%d): ranks would pair different buckets in one collective" % (i, self._launch_order[-1]))
-            self._launch_order.append(i)
-            self._launch_host_ms[i] = (time.perf_counter() - self._t_backward0) * 1e3
+            if self.collective:
+                if self._launch_order and self._launch_order[-1] >= i:
+                    raise RuntimeError("gradient buckets must be reduced in ascending order on every rank (bucket %d after "
+                                       "%d): ranks would pair different buckets in one collective" % (i, self._launch_order[-1]))
+                self._launch_order.append(i)
+                self._launch_host_ms[i] = (time.perf_counter() - self._t_backward0) * 1e3
             if self.grad.is_cuda:
-                from . import streams
                 # launched from the "meta" stream: it is idle by now (the reweighting net's sweep is the first thing a backward
                 # pass queues, and its gradients are the first bucket), and a stream of the collectives' own is one stream
                 # more than the four hardware queues carry without sharing (streams.py)
@@ -335,11 +353,51 @@ class EpisodeTrainer(object):
                     if s_ != comm:
                         comm.wait_stream(s_)
                 with torch.cuda.stream(comm):
-                    if self.time_allreduce:
-                        self._ready_events[i] = comm.record_event(torch.cuda.Event(enable_timing=True))
-                    self._works[i] = self._start(lo, hi)
+                    if self.collective:
+                        if self.time_allreduce:
+                            self._ready_events[i] = comm.record_event(torch.cuda.Event(enable_timing=True))
+                        self._works[i] = self._start(lo, hi)
+                    if early:
+                        self._finish_bucket(i)
             else:
                 self._works[i] = self._start(lo, hi)
+
+    def _finish_bucket(self, i):
+        """Bucket i on the CURRENT stream: wait for its collective, widen a bf16 wire buffer, optimizer kernel, re-pack."""
+        lo, hi = self.buckets[i]
+        if self._works[i] is not None:
+            if self.time_allreduce:
+                t0 = time.perf_counter()
+                self._works[i].wait()
+                self.allreduce_wait_ms[i] += (time.perf_counter() - t0) * 1e3
+            else:
+                self._works[i].wait()
+            if self.grad_lp is not None:
+                self.grad[lo:hi].copy_(self.grad_lp[lo:hi])
+        self._step_fn(lo, hi)
+        self._repack(i)
+        self._stepped[i] = True
+
+    def _repack(self, i):
+        """fp32 modes: rewrite the packed operand copies of the conv weights that bucket i completes (a tensor belongs to the
+        bucket that holds its LAST element), valid from the weight epoch that the end of this step starts."""
+        if self.__dict__.get("_multi_now") is not None:
+            return                           # bf16 mode: the fused optimizer kernel wrote the bf16 copies itself
+        from .engine import _WEIGHT_EPOCH
+        nets = [n for n in (getattr(self.net, "_det", None), getattr(self.net, "_meta", None)) if n is not None]
+        if not nets:
+            return
+        if self._conv_by_bucket is None:
+            by, off = [[] for _ in self.buckets], 0
+            for p in self.params:
+                if p.dim() == 4:
+                    last = off + p.numel() - 1
+                    by[next(k for k, (lo, hi) in enumerate(self.buckets) if lo <= last < hi)].append(p)
+                off += p.numel()
+            self._conv_by_bucket = by
+        for p in self._conv_by_bucket[i]:
+            for n in nets:
+                n.cache.refresh(p, _WEIGHT_EPOCH[0] + 1)
 
     def _start(self, lo, hi):
         buf = self.grad[lo:hi]
@@ -371,19 +429,17 @@ class EpisodeTrainer(object):
             self._overlap = {"order": list(self._launch_order), "host_ms": list(self._launch_host_ms),
                              "ready": list(self._ready_events), "bw_end": self._bw_end_event,
                              "bw_host_ms": self._bw_host_ms}
-        self._multi_now = self._multi_tables()
-        for i, (lo, hi) in enumerate(self.buckets):
-            if self._works[i] is not None:
-                if self.time_allreduce:
-                    import time
-                    t0 = time.perf_counter()
-                    self._works[i].wait()
-                    self.allreduce_wait_ms[i] += (time.perf_counter() - t0) * 1e3
-                else:
-                    self._works[i].wait()
-                if self.grad_lp is not None:
-                    self.grad[lo:hi].copy_(self.grad_lp[lo:hi])
-            self._step_fn(lo, hi)
+        if self.__dict__.get("_multi_now") is None:
+            self._multi_now = self._multi_tables()
+        self.early_steps_last = sum(1 for v in self._stepped if v)
+        if self.early_steps_last and self.grad.is_cuda:
+            # what follows on this stream -- the remaining buckets (a tensor can straddle two of them), then the next forward --
+            # reads the weights and operand copies the side stream has (re)written
+            torch.cuda.current_stream().wait_stream(streams.side(self.grad.device, self.collective_stream))
+        for i in range(len(self.buckets)):
+            if not self._stepped[i]:
+                self._finish_bucket(i)
+        self._stepped = [False] * len(self.buckets)
         self._works = [None] * len(self.buckets)
         self.launch_order_last, self._launch_order = self._launch_order, []
         self._launch_host_ms = [None] * len(self.buckets)
@@ -398,6 +454,7 @@ class EpisodeTrainer(object):
         # buffer (ops.GRAD_SINK); whatever still arrives through autograd is gathered afterwards.
         ops.GRAD_SINK, ops.GRAD_SUNK = self.sink, set()
         ops.GRAD_HOOK = lambda wait_streams=(): self._launch_ready(ops.GRAD_SUNK, wait_streams=wait_streams)
+        self._multi_now = self._multi_tables()       # (bf16 mode: the fused optimizer + re-pack tables, needed by an early step)
         self._t_backward0 = time.perf_counter()
         self._bw_end_event, self._bw_host_ms = None, 0.0
         try:
@@ -422,7 +479,7 @@ class EpisodeTrainer(object):
     max_steps_in_flight = 2
 
     # the side stream the collectives are launched from (see _launch_ready)
-    collective_stream = os.environ.get("FSD_COLLECTIVE_STREAM", "meta")
+    collective_stream = "meta"
 
     def _throttle(self):
         if not self.grad.is_cuda or self.max_steps_in_flight is None:

@@ -71,6 +71,20 @@ class _WeightCache(object):
             return ops.pack_weight_wino(w.detach(), mode, int(dtype[4]), out=old)
         return ops.pack_weight(w.detach(), mode, dtype, out=old)
 
+    def refresh(self, w, epoch):
+        """Rewrite every fp32-family packed copy of `w` (plain, Winograd; forward and data-gradient operand) from its CURRENT
+        value, in place, on the current stream, and tag it valid for weight epoch `epoch` -- the trainer does this right after
+        the optimizer kernel of w's gradient bucket, while the backward pass is still running (dp.EpisodeTrainer).  The bf16
+        copies are written by the fused optimizer kernel itself (mark_fresh).  -> number of copies rewritten."""
+        n = 0
+        for key, ent in self._store.items():
+            if key[0] != id(w) or key[2] == "bf16" or ent[2] is not w:
+                continue
+            ent[1] = self._build(w, key[1], key[2], ent[1])
+            ent[0] = (w.data_ptr(), w._version, epoch)
+            n += 1
+        return n
+
     def bf16_pair(self, w):
         """The kept (forward, data-gradient) bf16 operand buffers of `w`, or None if this network has not packed it yet."""
         a, b = self._store.get((id(w), 0, "bf16")), self._store.get((id(w), 1, "bf16"))

@@ -27,7 +27,7 @@ def _episode(seed, B, N, S, Sm):
     return bench.synth_episode(seed, B, N, S, Sm)
 
 
-def _run_steps(dev, cfg_paths, enabled, dtype, steps, B=8, N=5, S=224, Sm=128, neg="full"):
+def _run_steps(dev, cfg_paths, enabled, dtype, steps, B=8, N=5, S=224, Sm=128, neg="full", lr=1e-9, early=None, info=None):
     """`steps` train steps from a fixed seed -> (outputs of every step, losses, final flat parameters, flat gradient)."""
     from fewshot_detection_amd import streams
     from fewshot_detection_amd.cfg import cfg
@@ -43,7 +43,10 @@ def _run_steps(dev, cfg_paths, enabled, dtype, steps, B=8, N=5, S=224, Sm=128, n
         net.set_compute_dtype(dtype)
         region = net.models[len(net.models) - 1]
         region.verbose = False
-        opt = EpisodeTrainer(net, lr=1e-9, momentum=0.9, weight_decay=5e-4)      # random init: a real step size diverges
+        opt = EpisodeTrainer(net, lr=lr, momentum=0.9, weight_decay=5e-4)        # random init: a real step size diverges
+        if early is not None:
+            opt.EARLY_STEP = early
+        flat0 = opt.flat.detach().clone()
         outs, losses = [], []
         for i in range(steps):
             x, metax, mask, target = _episode(100 + i, B, N, S, Sm)
@@ -55,6 +58,10 @@ def _run_steps(dev, cfg_paths, enabled, dtype, steps, B=8, N=5, S=224, Sm=128, n
             opt.backward_and_step(loss)
         torch.cuda.synchronize()
         assert all(bool(torch.isfinite(v)) for v in losses) and bool(torch.isfinite(opt.flat).all())
+        if info is not None:
+            info["early_steps_last"] = opt.early_steps_last
+            info["buckets"] = len(opt.buckets)
+            info["moved"] = float((opt.flat - flat0).norm() / flat0.norm())
         return outs, losses, opt.flat.detach().clone(), opt.grad.detach().clone()
     finally:
         streams.ENABLED = old
@@ -184,3 +191,21 @@ def test_upload_through_pinned_staging_is_exact_and_reuses_its_slots():
     for o, r in zip(outs, refs):
         assert o.shape == r.shape and np.array_equal(o.cpu().numpy(), r)
     assert len(streams._PINNED[0]) <= streams._PIN_SLOTS
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_early_optimizer_step_is_bit_identical(dev, cfg_paths, dtype):
+    """EpisodeTrainer.EARLY_STEP: the optimizer kernel of a gradient bucket and the in-place re-packing of its conv operands
+    are queued on the side stream while the backward pass still runs.  With a step size that really moves the weights, four
+    steps (each forward reads the operands the previous step re-packed) must equal the after-the-backward form bit for bit:
+    a re-pack ordered before its optimizer kernel, or under a reader of the old copy, shows up in the next head output."""
+    ia, ib = {}, {}
+    ref = _run_steps(dev, cfg_paths, True, dtype, 4, lr=2e-7, early=False, info=ia)
+    assert ia["early_steps_last"] == 0
+    for attempt in range(2):
+        got = _run_steps(dev, cfg_paths, True, dtype, 4, lr=2e-7, early=True, info=ib)
+        assert ib["early_steps_last"] >= ib["buckets"] - 2, ib          # every bucket but the last one or two
+        for k, (a, b) in enumerate(zip(ref[0], got[0])):
+            assert torch.equal(a, b), "head output of step %d differs (attempt %d)" % (k, attempt)
+        assert torch.equal(ref[3], got[3]) and torch.equal(ref[2], got[2])
+    assert ia["moved"] > 1e-5, ia           # ... and the weights did move

@@ -1,3 +1,7 @@
+# A/B of the stream the collectives are launched from (EpisodeTrainer.collective_stream) under two gloo ranks on one GPU.
+# The FSD_COLLECTIVE_STREAM variable it sets was a probe-time hook (tools/experiments_r06/rccl_stream_probes.patch); the
+# product keeps the class attribute only.  Recorded result: the readiness timeline of this time-shared harness fluctuates
+# run to run with every choice (meta / comm / wgrad).
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06i
 for cs in meta comm wgrad; do
 for sc in strong; do
