@@ -87,6 +87,14 @@ def test_bucket_bounds_cover_buffer():
             assert all(lo % 1024 == 0 for lo, _ in b)
     b = tapered_bounds(66287742, 6)
     assert len(b) == 6 and (b[-1][1] - b[-1][0]) < 0.08 * 66287742   # the bucket nothing can hide is the small one
+    b = tapered_bounds(66287742, 8)                                  # optional finer tail: five equal buckets, then 5.7 % / 1 % / 0.3 %
+    sizes = [hi - lo for lo, hi in b]
+    assert len(b) == 8 and b[0][0] == 0 and b[-1][1] == 66287742 and all(b[i][1] == b[i + 1][0] for i in range(7))
+    assert sizes[-1] < 0.004 * 66287742 and sizes[-2] < 0.011 * 66287742 and sizes[-3] < 0.06 * 66287742
+    assert max(sizes[:5]) - min(sizes[:5]) <= 1024 * 5
+    for total in (1, 5000, 40000, 66287742):
+        bb = tapered_bounds(total, 8)
+        assert bb[0][0] == 0 and bb[-1][1] == total and all(bb[i][1] == bb[i + 1][0] for i in range(len(bb) - 1))
 
 
 def test_flat_buffer_follows_gradient_readiness_order(tmp_path):

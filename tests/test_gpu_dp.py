@@ -160,7 +160,7 @@ def _worker8(rank, world, port, out_dir):
 
 
 def test_eight_ranks_reproduce_one_full_batch_process(tmp_path):
-    """VERDICT r5 #7c: the strong split, the six tapered buckets and their early launches had only ever run at world 2.  Eight
+    """VERDICT r5 #7c: the strong split, the tapered buckets and their early launches had only ever run at world 2.  Eight
     gloo ranks on one MI355X, one query of a B = 8 episode each: identical replicas after 3 steps, equal to ONE process on the
     whole batch, every bucket reduced in ascending (= readiness) order."""
     try:
@@ -349,7 +349,7 @@ def test_rccl_transport_single_rank_equals_the_groupless_trainer(tmp_path):
 
 def test_bench_single_rank_over_rccl():
     """bench.py's data-parallel step over RCCL with one rank (FSD_BENCH_SINGLE_RANK_RCCL=1): the line is a one-GPU line whose
-    dp record names the nccl backend, six buckets launched in order, and a finite loss equal to the group-less run's."""
+    dp record names the nccl backend, its buckets launched in order, and a finite loss equal to the group-less run's."""
     common = ["--steps", "2", "--warmup", "1", "--batch", "4", "--classes", "3", "--size", "160", "--support", "160",
               "--no-extras", "--no-cpu-baseline", "--no-parity", "--no-settle", "--streams", "0"]   # (same step count both ways)
     res = {}
