@@ -115,14 +115,23 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
       const bool valid = rel + h < len && !(wrap && h);                    // it is left to the next step
       const unsigned p00 = 2u * (n0 + r0 * (unsigned)OW);
       const unsigned o_safe = (unsigned)co * ES;                          // always mapped
-      g.gz = fsd_ew::ld1<T>(reinterpret_cast<const T*>(dz_b + (valid ? n0 * p.dz_ld * ES + l_dz : o_safe)));
+      // (the offsets go through an empty asm: the compiler otherwise merges the loads from the safe offset, turns the selects
+      // into divergent branches around them and waits with vmcnt(0) at every join)
+      unsigned o_gz = valid ? n0 * p.dz_ld * ES + l_dz : o_safe;
+      asm volatile("" : "+v"(o_gz));
+      g.gz = fsd_ew::ld1<T>(reinterpret_cast<const T*>(dz_b + o_gz));
       const unsigned yq = p00 * p.y_ld * ES;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        g.y[j] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + (valid ? yq + l_y[j] : o_safe)));
+      for (int j = 0; j < 4; ++j) {
+        unsigned o = valid ? yq + l_y[j] : o_safe;
+        asm volatile("" : "+v"(o));
+        g.y[j] = fsd_ew::ld1<T>(reinterpret_cast<const T*>(y_b + o));
+      }
       const int yy = 2 * cy0 - 1 + prow, xx = 2 * cx0 - 1 + pcol;
       const bool in = g.live && p_lane && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      g.px = *reinterpret_cast<const f32x4*>(x_b + (in ? (unsigned)((int)(p00 * p.x_ld * 4u) + l_p) : 0u));
+      unsigned o_p = in ? (unsigned)((int)(p00 * p.x_ld * 4u) + l_p) : 0u;
+      asm volatile("" : "+v"(o_p));
+      g.px = *reinterpret_cast<const f32x4*>(x_b + o_p);
       g.valid = valid;
       g.in = in;
       const int adv = wrap ? 1 : 2;
@@ -193,17 +202,25 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
         }
       }
     };
-    Group g0, g1;
-    load(g0);
-    while (g0.live) {                     // (a pair past the end of the run loads from the safe offsets and adds zeros)
-      load(g1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(g0);
-      __builtin_amdgcn_sched_barrier(0);
-      load(g0);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(g1);
-      __builtin_amdgcn_sched_barrier(0);
+    // A ring of kDepth pairs: kDepth - 1 pairs of loads in flight ahead of the MFMAs (9 registers each).  One pair ahead (round 6,
+    // first version) left a wave waiting ~1.5 us of HBM latency per pair behind 0.4 us of its own work: the matrix pipe idled half
+    // of the time with five waves per SIMD.
+    constexpr int kDepth = 4;
+    Group g[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load(g[d]);
+    while (g[0].live) {                   // (a pair past the end of the run loads from the safe offsets and adds zeros)
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        load(g[(d + kDepth - 1) % kDepth]);
+#ifndef FB_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        compute(g[d]);
+#ifndef FB_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
     }
     // the epilogue re-uses the patch slot
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
