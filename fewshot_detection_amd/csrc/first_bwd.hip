@@ -202,9 +202,11 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
         }
       }
     };
-    // A ring of kDepth pairs: kDepth - 1 pairs of loads in flight ahead of the MFMAs (9 registers each).  One pair ahead (round 6,
-    // first version) left a wave waiting ~1.5 us of HBM latency per pair behind 0.4 us of its own work: the matrix pipe idled half
-    // of the time with five waves per SIMD.
+    // A ring of kDepth pairs: kDepth - 1 pairs of loads in flight ahead of the MFMAs (9 registers each).  Measured: no faster than
+    // one pair ahead (0.571 / 0.567 against 0.568 / 0.561 ms), nor is the loop without the scheduling barriers -- latency is not
+    // what is left.  With the VALU work cut to nothing the sequence takes 0.55 / 0.50 ms against 0.62 / 0.61: the kernel runs at
+    // the rate the fp32 MFMA sustains in this chip's power envelope (0.29 ms of it at the nominal peak; the native-fp32 GEMMs
+    // reach 0.68 of that peak), plus a VALU residue of ~0.07 ms.  Only fewer MFMAs would make it faster (open items).
     constexpr int kDepth = 4;
     Group g[kDepth];
 #pragma unroll
@@ -213,13 +215,9 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
 #pragma unroll
       for (int d = 0; d < kDepth; ++d) {
         load(g[(d + kDepth - 1) % kDepth]);
-#ifndef FB_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
-#endif
         compute(g[d]);
-#ifndef FB_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     }
     // the epilogue re-uses the patch slot
