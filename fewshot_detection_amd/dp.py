@@ -468,6 +468,13 @@ class EpisodeTrainer(object):
         try:
             loss.backward()
             sunk = ops.GRAD_SUNK
+        except BaseException:
+            # a backward pass that died half-way: with EARLY_STEP the buckets finished so far are already stepped (their
+            # gradients were final); forget the step's bookkeeping so that the next call starts clean
+            self._stepped = [False] * len(self.buckets)
+            self._works = [None] * len(self.buckets)
+            self._launch_order, self._streams_seen, self._multi_now = [], [], None
+            raise
         finally:
             ops.GRAD_SINK, ops.GRAD_SUNK, ops.GRAD_HOOK = None, set(), None
         self._bw_host_ms = (time.perf_counter() - self._t_backward0) * 1e3
