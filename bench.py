@@ -395,17 +395,14 @@ class Leg(object):
         gc.collect()
         gc.disable()
         if warmup > 0 and self.dev.type == "cuda" and not getattr(self, "no_settle", False):
-            def prof_form_step():             # one step in the form of the profiled ones (one stream, per-launch events)
-                torch.cuda.synchronize()
-                ops.PROFILE = []
+            def prof_form_step():             # one step in the form of the profiled ones (one stream, per-launch events,
+                ops.PROFILE = []              # no host synchronisation around it)
                 ops.kernel_profile(True)
                 streams.ENABLED = False
                 step()
                 ops.PROFILE = None
                 ops.kernel_profile(False)
                 streams.ENABLED = streams_on
-                torch.cuda.synchronize()
-                ops.kernel_profile_collect()
                 self.settle_steps += 1
             last = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
             # Bursts of 12 FREE-RUNNING steps (the host as far ahead of the GPU as in the timed region; a memory_stats() call per
@@ -439,15 +436,15 @@ class Leg(object):
         lo = (steps - prof_steps) // 2
         hi = lo + prof_steps
         prof = []
-        t_a = t_b = None
         ops.kernel_profile_collect()          # drop whatever an earlier leg left
         step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # per-step GPU time (diagnostic)
         step_ev[0].record()
         t0 = time.perf_counter()
         for i in range(steps):
+            # (no host synchronisation around the profiled steps: every step ends with the main stream waiting for the side
+            # streams, so a one-stream step is alone on the GPU anyway, and the host keeps queueing ahead as in every other step;
+            # with the two synchronisations the profiled step took 29 ms instead of 26.5 and the step behind it started cold)
             if i == lo and prof_steps:
-                torch.cuda.synchronize()
-                t_a = time.perf_counter()
                 ops.PROFILE = prof
                 ops.kernel_profile(True)
                 streams.ENABLED = False
@@ -455,8 +452,6 @@ class Leg(object):
                 ops.PROFILE = None
                 ops.kernel_profile(False)
                 streams.ENABLED = streams_on
-                torch.cuda.synchronize()
-                t_b = time.perf_counter()
             loss = step()
             step_ev[i + 1].record()
         ops.PROFILE = None
@@ -467,8 +462,6 @@ class Leg(object):
         step_gpu_ms = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)]
         gc.enable()
         allocs = (torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0) if self.dev.type == "cuda" else 0
-        if prof_steps and t_b is None:        # the profiled steps were the last ones
-            t_b = t_end
         elapsed = t_end - t0
         if self.dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
@@ -480,9 +473,10 @@ class Leg(object):
                 "stream_tuning": self.stream_tuning, "streams_on": streams_on, "step_gpu_ms": step_gpu_ms,
                 "settle_steps": self.settle_steps, "device_allocs_in_timed_region": allocs,
                 "prof_index": [lo, hi] if prof_steps else None, "kp": ops.kernel_profile_collect(),
-                "ms_unprofiled": (((t_a - t0) + (t_end - t_b)) / (steps - prof_steps) * 1e3
-                                  if t_a is not None and steps > prof_steps else None),
-                "ms_profiled": ((t_b - t_a) / prof_steps * 1e3 if t_a is not None else None)}
+                # GPU time of the steps (events on the main stream, step end to step end)
+                "ms_unprofiled": ((sum(step_gpu_ms) - sum(step_gpu_ms[lo:hi])) / (steps - prof_steps)
+                                  if prof_steps and steps > prof_steps else None),
+                "ms_profiled": (sum(step_gpu_ms[lo:hi]) / prof_steps if prof_steps else None)}
 
 
 F32_GEMM_WHAT = {
