@@ -23,10 +23,46 @@
 #include "profile.hpp"
 #include "ew_types.hpp"
 
+namespace fsd_conv { bool f32_split_on(); }     // conv.hip: the arithmetic of the fp32 GEMMs (fsd_f32_gemm_mode)
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// pairs of fp32 values -> packed bf16 planes v = v1 + v2 + v3 (round-to-nearest, exact residuals; one v_cvt_pk_bf16_f32 per
+// pair and plane -- the idiom of conv.hip's in-kernel split).  PLANES = how many are wanted.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+template <int PLANES>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = cvt2(a, b);
+  p2 = p3 = 0u;
+  if constexpr (PLANES >= 2) {
+    const float ra = a - lo_f(p1), rb = b - hi_f(p1);
+    p2 = cvt2(ra, rb);
+    if constexpr (PLANES >= 3) p3 = cvt2(ra - lo_f(p2), rb - hi_f(p2));
+  }
+}
+// eight values (the 4 + 4 window pixels of a lane's two cells) -> PLANES operand registers of v_mfma_f32_32x32x16_bf16
+template <int PLANES>
+__device__ __forceinline__ void split8(const float (&a)[4], const float (&b)[4], bf16x8_t& o1, bf16x8_t& o2, bf16x8_t& o3) {
+  unsigned w1[4], w2[4], w3[4];
+  split_pair<PLANES>(a[0], a[1], w1[0], w2[0], w3[0]);
+  split_pair<PLANES>(a[2], a[3], w1[1], w2[1], w3[1]);
+  split_pair<PLANES>(b[0], b[1], w1[2], w2[2], w3[2]);
+  split_pair<PLANES>(b[2], b[3], w1[3], w2[3], w3[3]);
+  o1 = __builtin_bit_cast(bf16x8_t, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+  o2 = __builtin_bit_cast(bf16x8_t, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+  o3 = __builtin_bit_cast(bf16x8_t, make_uint4(w3[0], w3[1], w3[2], w3[3]));
+}
 using fsd_ew::bf16_t;
 
 
@@ -58,8 +94,11 @@ struct FirstBwdArgs {
 // storage).  What bounds it now (tools/probes/first_bwd_ablate.sh, B = 64): with the S3 MFMAs compiled out 0.42 ms, with all
 // of them out 0.39 ms fp32 (= the 1.95 GB of dz, y and x at 5 TB/s) / 0.26 ms bf16 -- the fp32-MFMA work (0.29 ms at the
 // peak rate) and the HBM-bound sweep overlap only partly.  The workgroup count does not matter (1024..5120: +-2 %).
-template <bool SIDE, typename T>
-__global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
+// SPLIT (fp32 storage): the products of both sums as the six bf16-MFMA terms of three-way split operands -- the arithmetic of
+// the library's fp32 GEMMs (conv.hip; error against fp64 at or below the fp32 MFMA's) -- instead of v_mfma_f32_32x32x2_f32,
+// which stays for fsd_f32_gemm_mode(0).  bf16 storage always runs on the bf16 MFMA.
+template <bool SIDE, typename T, bool SPLIT>
+__device__ __forceinline__ void first_bwd_body(const FirstBwdArgs& p) {
   constexpr unsigned ES = sizeof(T);
   __shared__ __attribute__((aligned(16))) float s_out[4][32 * 36 + 36 + 64];   // per wave: the input patch while sweeping;
                                                                                 // afterwards a [32][36] tile, S2[36], BN sums [32][2]
@@ -141,7 +180,9 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
         if (++cy0 == OH) cy0 = 0;
       }
     };
-    auto compute = [&](const Group& g) {
+    // everything of a pair but its MFMAs: patch through LDS, pool winner, BatchNorm algebra, the per-lane sums; hands back the
+    // operands of the four k-steps: dq[j] (A of S1), xh[j] (A of S3), b[j] (B of both)
+    auto prep = [&](const Group& g, float (&dqv)[4], float (&xh)[4], float (&b)[4]) {
       // hand the patch to the wave (wave-private LDS slot; the wave's own LDS operations execute in order)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -150,7 +191,6 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const bool valid = g.valid;
-      float b[4];
       f32x4 x8[SIDE ? 4 : 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -161,7 +201,7 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
           x8[j] = valid ? w : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      float a[4], xh[4];
+      float a[4];
       bool pos[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -188,36 +228,88 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
       const float dq = fsd_ew::stored<T>(dsel);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dqj = win[j] ? dq : 0.f;
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dqj, b[j], acc1, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xh[j], b[j], acc3, 0, 0, 0);
+        dqv[j] = win[j] ? dq : 0.f;
         s2c += b[j];
         if constexpr (SIDE) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            a81[i] = __builtin_fmaf(dqj, x8[j][i], a81[i]);
+            a81[i] = __builtin_fmaf(dqv[j], x8[j][i], a81[i]);
             a83[i] = __builtin_fmaf(xh[j], x8[j][i], a83[i]);
             s2c8[i] += x8[j][i];
           }
         }
       }
     };
-    // A ring of kDepth pairs: kDepth - 1 pairs of loads in flight ahead of the MFMAs (9 registers each).  Measured: no faster than
-    // one pair ahead (0.571 / 0.567 against 0.568 / 0.561 ms), nor is the loop without the scheduling barriers -- latency is not
-    // what is left.  With the VALU work cut to nothing the sequence takes 0.55 / 0.50 ms against 0.62 / 0.61: the kernel runs at
-    // the rate the fp32 MFMA sustains in this chip's power envelope (0.29 ms of it at the nominal peak; the native-fp32 GEMMs
-    // reach 0.68 of that peak), plus a VALU residue of ~0.07 ms.  Only fewer MFMAs would make it faster (open items).
+    // fp32 storage: the products stay on the fp32 MFMA (one pair = four k-steps of two pixels)
+    auto compute = [&](const Group& g) {
+      float dqv[4], xh[4], b[4];
+      prep(g, dqv, xh, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dqv[j], b[j], acc1, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(xh[j], b[j], acc3, 0, 0, 0);
+      }
+    };
+    // bf16 storage: dt is a bf16 value there, so S1 = dt x (x1 + x2 + x3) is three terms of v_mfma_f32_32x32x16_bf16 -- exact
+    // products, fp32 accumulate -- and S3 = xhat x x takes the five terms down to 2^-16 of the three-way / two-way split
+    // (xhat is formed from a bf16 activation: its own rounding is 2^-9).  TWO pairs fill the 16 k-slots of an instruction
+    // (lane (c, h) brings the 4 + 4 window pixels of its two cells): 8 MFMAs of 32 cycles per four cells instead of 16 of 64.
+    auto compute2 = [&](const Group& ga, const Group& gb) {
+      float dqa[4], xha[4], ba[4], dqb[4], xhb[4], bb[4];
+      prep(ga, dqa, xha, ba);
+      prep(gb, dqb, xhb, bb);
+      bf16x8_t b1, b2, b3, dq1, dq2, dq3, x1, x2, x3;
+      split8<3>(ba, bb, b1, b2, b3);
+      if constexpr (sizeof(T) == 2) {
+        split8<1>(dqa, dqb, dq1, dq2, dq3);                      // (dq is a bf16 value: one plane holds it exactly)
+        split8<2>(xha, xhb, x1, x2, x3);
+      } else {
+        split8<3>(dqa, dqb, dq1, dq2, dq3);
+        split8<3>(xha, xhb, x1, x2, x3);
+      }
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq1, b1, acc1, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b1, acc3, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq1, b2, acc1, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b2, acc3, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq1, b3, acc1, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b1, acc3, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b2, acc3, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b3, acc3, 0, 0, 0);
+      if constexpr (sizeof(T) == 4) {                            // fp32 storage: the remaining terms of the six-term product
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq2, b1, acc1, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, b1, acc3, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq2, b2, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dq3, b1, acc1, 0, 0, 0);
+      }
+    };
     constexpr int kDepth = 4;
     Group g[kDepth];
-#pragma unroll
-    for (int d = 0; d < kDepth - 1; ++d) load(g[d]);
-    while (g[0].live) {                   // (a pair past the end of the run loads from the safe offsets and adds zeros)
-#pragma unroll
-      for (int d = 0; d < kDepth; ++d) {
-        load(g[(d + kDepth - 1) % kDepth]);
+    if constexpr (sizeof(T) == 2 || SPLIT) {
+      load(g[0]);
+      load(g[1]);
+      while (g[0].live) {                 // (a pair past the end of the run loads from the safe offsets and adds zeros)
+        load(g[2]);
+        load(g[3]);
         __builtin_amdgcn_sched_barrier(0);
-        compute(g[d]);
+        compute2(g[0], g[1]);
         __builtin_amdgcn_sched_barrier(0);
+        load(g[0]);
+        load(g[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute2(g[2], g[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < kDepth - 1; ++d) load(g[d]);
+      while (g[0].live) {                 // (a pair past the end of the run loads from the safe offsets and adds zeros)
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+          load(g[(d + kDepth - 1) % kDepth]);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(g[d]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     // the epilogue re-uses the patch slot
@@ -287,6 +379,24 @@ __global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) {
   }
 }
 
+template <bool SIDE>
+__global__ __launch_bounds__(256) void first_bwd_kernel(FirstBwdArgs p) { first_bwd_body<SIDE, float, false>(p); }
+
+// fp32 storage, split arithmetic (the default): 0.568 -> 0.51 ms on the 416x416 layer at B = 64 -- 12 MFMAs of 32 cycles per
+// four cells instead of 16 of 64, paid for with ~50 more VALU instructions per cell pair for the three-way splits.
+template <bool SIDE>
+__global__ __launch_bounds__(256) void first_bwd_s_kernel(FirstBwdArgs p) { first_bwd_body<SIDE, float, true>(p); }
+
+// (A branch to a select-free variant of the sweep for pairs that need no operand zeroed -- 97 % of them -- was measured: the
+// compiler loses the counted vmcnt across it and spills, 0.40 -> 1.09 ms.  The selects stay.)
+// bf16 storage.  Three waves per SIMD: left to itself the compiler takes 188 registers (two waves) and parks 32 values in
+// accumulator registers, 96 moves per loop trip (0.465 ms); held to three waves it needs 157 and none (0.39 ms); four waves
+// spill to scratch.  The fp32 kernel is slower with the same hint (0.57 -> 0.59 ms) and keeps the default.
+template <bool SIDE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void first_bwd_h_kernel(FirstBwdArgs p) {
+  first_bwd_body<SIDE, bf16_t, true>(p);
+}
+
 // dW[co][ci][ky][kx] = c1 (sum_b S1 - c2 sum_b S2 - c3 sum_b S3): one workgroup per (output channel, 9 of the 36 columns),
 // 28 block lanes x 9 columns, fp64 sums in a fixed order.  (One workgroup per channel with 4 block lanes was a chain of
 // 512 dependent-latency iterations on 32 workgroups: 141 us for 19 MB.)
@@ -353,8 +463,16 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   a.slope = slope;
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (sizeof(T) * cout * 1.25 + 16.0), stream);
   const dim3 grid(blocks, cout / 32);
-  if (cin == 4) FSD_LAUNCH((first_bwd_kernel<true, T>), grid, dim3(256), 0, stream, a);
-  else FSD_LAUNCH((first_bwd_kernel<false, T>), grid, dim3(256), 0, stream, a);
+  if constexpr (sizeof(T) == 2) {
+    if (cin == 4) FSD_LAUNCH((first_bwd_h_kernel<true>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((first_bwd_h_kernel<false>), grid, dim3(256), 0, stream, a);
+  } else if (fsd_conv::f32_split_on()) {
+    if (cin == 4) FSD_LAUNCH((first_bwd_s_kernel<true>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((first_bwd_s_kernel<false>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (cin == 4) FSD_LAUNCH((first_bwd_kernel<true>), grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH((first_bwd_kernel<false>), grid, dim3(256), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 

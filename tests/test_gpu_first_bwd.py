@@ -37,8 +37,21 @@ def _unfused(ops, dzv, yv, scale, shift, mean, invstd, slope, xv, cin, cout, bn)
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 32, 48, 3, 32), (3, 20, 12, 4, 64), (5, 6, 2, 3, 32), (1, 2, 2, 4, 32),
                                             (4, 64, 64, 3, 32)])
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", [False, True, "native"])
 def test_first_block_backward_one_sweep(dev, B, H, W, cin, cout, bf16):
+    """bf16 = False: fp32 storage, the default arithmetic (six bf16-MFMA terms of split operands); "native": fp32 storage with
+    fsd_f32_gemm_mode(0), the sums on v_mfma_f32_32x32x2_f32; True: bf16 storage (bf16 MFMA)."""
+    from fewshot_detection_amd import ops
+    if bf16 == "native":
+        prev = ops.f32_gemm_mode("native")
+        try:
+            return _one_sweep(dev, B, H, W, cin, cout, False)
+        finally:
+            ops.f32_gemm_mode(prev)
+    return _one_sweep(dev, B, H, W, cin, cout, bf16)
+
+
+def _one_sweep(dev, B, H, W, cin, cout, bf16):
     from fewshot_detection_amd import ops
     x, w, gamma, beta, dz, xv = _block_inputs(dev, B, H, W, cin, cout, 11 + H + cin, bf16)
     bn = torch.nn.BatchNorm2d(cout).to(dev)
