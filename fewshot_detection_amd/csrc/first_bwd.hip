@@ -392,10 +392,13 @@ __global__ __launch_bounds__(256) void first_bwd_s_kernel(FirstBwdArgs p) { firs
 // bf16 storage.  Three waves per SIMD: left to itself the compiler takes 188 registers (two waves) and parks 32 values in
 // accumulator registers, 96 moves per loop trip (0.465 ms); held to three waves it needs 157 and none (0.39 ms); four waves
 // spill to scratch.  The fp32 kernel is slower with the same hint (0.57 -> 0.59 ms) and keeps the default.
-template <bool SIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void first_bwd_h_kernel(FirstBwdArgs p) {
-  first_bwd_body<SIDE, bf16_t, true>(p);
+  first_bwd_body<false, bf16_t, true>(p);
 }
+// (the 4-channel variant carries the ninth tap's side sums: held to three waves it spills 240 bytes to scratch -- the 80 x
+// 416x416 supports of the COCO-shaped episode took 2 ms longer; it keeps the compiler's own allocation: 0.74 ms for those 80
+// supports, 0.84 with fp32 storage, against 0.92 / 0.92 on the fp32 MFMA)
+__global__ __launch_bounds__(256) void first_bwd_h4_kernel(FirstBwdArgs p) { first_bwd_body<true, bf16_t, true>(p); }
 
 // dW[co][ci][ky][kx] = c1 (sum_b S1 - c2 sum_b S2 - c3 sum_b S3): one workgroup per (output channel, 9 of the 36 columns),
 // 28 block lanes x 9 columns, fp64 sums in a fixed order.  (One workgroup per channel with 4 block lanes was a chain of
@@ -464,8 +467,8 @@ int accum_impl(const T* dz, long long dz_ld, const T* y, long long y_ld, const f
   fsd_prof::Scope prof(fsd_prof::kFirst, (double)pixels * (sizeof(T) * cout * 1.25 + 16.0), stream);
   const dim3 grid(blocks, cout / 32);
   if constexpr (sizeof(T) == 2) {
-    if (cin == 4) FSD_LAUNCH((first_bwd_h_kernel<true>), grid, dim3(256), 0, stream, a);
-    else FSD_LAUNCH((first_bwd_h_kernel<false>), grid, dim3(256), 0, stream, a);
+    if (cin == 4) FSD_LAUNCH(first_bwd_h4_kernel, grid, dim3(256), 0, stream, a);
+    else FSD_LAUNCH(first_bwd_h_kernel, grid, dim3(256), 0, stream, a);
   } else if (fsd_conv::f32_split_on()) {
     if (cin == 4) FSD_LAUNCH((first_bwd_s_kernel<true>), grid, dim3(256), 0, stream, a);
     else FSD_LAUNCH((first_bwd_s_kernel<false>), grid, dim3(256), 0, stream, a);

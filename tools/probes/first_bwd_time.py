@@ -5,6 +5,8 @@ sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from fewshot_detection_amd import ops
 dev = torch.device("cuda:0")
 B, H, W, cin, cout = 64, 416, 416, 3, 32
+if len(sys.argv) > 5:
+    B, H, W, cin, cout = (int(v) for v in sys.argv[1:6])
 for bf16 in (False, True):
     dt = torch.bfloat16 if bf16 else torch.float32
     x = torch.rand(B, cin, H, W, device=dev)
