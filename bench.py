@@ -375,7 +375,10 @@ class Leg(object):
             step()
         self.fence()
         self.stream_tuning = None
-        if (streams_on or (self.dist is not None and self.streams_requested)) and self.opt is not None:
+        # (a process group on another backend than RCCL is the functional harness -- several gloo ranks time-slicing ONE GPU:
+        # there the synchronised probing steps were seen to take 20-40 s each, and there is no queue mapping to protect)
+        tune = self.dist is None or str(self.dist.get_backend()) == "nccl"
+        if tune and (streams_on or (self.dist is not None and self.streams_requested)) and self.opt is not None:
             # untimed: make sure the side streams pay in THIS process (streams.autotune: an unlucky stream -> hardware-queue
             # mapping makes a step 40 % slower for the life of the streams; it re-draws them or falls back to one stream)
             # (several ranks: a FIXED number of probing steps on every rank -- each step holds the gradient collectives --
