@@ -247,3 +247,44 @@ def test_neg_filter_ratio_is_the_gathered_batchs_under_data_parallelism(tmp_path
     port = _free_port()
     mp.spawn(_neg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "neg%d.ok" % r)) for r in (0, 1))
+
+
+def _single_rank_worker(rank, port, out_dir):
+    from fewshot_detection_amd.dp import EpisodeTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    data = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(1))
+    out = {}
+    for name, group, force in (("plain", None, False), ("group_idle", dist, False), ("group_forced", dist, True)):
+        torch.manual_seed(0)
+        net = _Tiny()
+        holder = {}
+
+        def torch_step(lo, hi):
+            t = holder["t"]
+            buf = t.grad[lo:hi] if t.steps == 0 else 0.9 * t.mom[lo:hi] + t.grad[lo:hi]
+            t.mom[lo:hi] = buf
+            t.flat[lo:hi] -= 0.001 * buf
+
+        tr = EpisodeTrainer(net, 0.001, 0.9, 0.0, process_group=group, n_buckets=3, step_fn=torch_step,
+                            single_rank_collectives=force)
+        holder["t"] = tr
+        for _ in range(3):
+            tr.backward_and_step((net(data) ** 2).sum())
+        out[name] = (tr.flat.detach().clone(), tr.collective, list(tr.launch_order_last), len(tr.buckets))
+        tr.close()
+    torch.save(out, os.path.join(out_dir, "single.pt"))
+    dist.destroy_process_group()
+
+
+def test_single_rank_collectives_run_every_collective_and_change_nothing(tmp_path):
+    """EpisodeTrainer(single_rank_collectives=True): with a process group of ONE rank the trainer still launches its bucketed
+    all-reduces (in ascending order) -- the switch behind the one-rank RCCL runs of the GPU box -- and the parameters equal the
+    group-less trainer's bit for bit; without the switch a one-rank group issues nothing."""
+    mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(os.path.join(str(tmp_path), "single.pt"))
+    assert out["plain"][1] is False and out["group_idle"][1] is False and out["group_forced"][1] is True
+    assert out["plain"][2] == [] and out["group_idle"][2] == [] and out["group_forced"][2] == list(range(out["group_forced"][3]))
+    assert out["group_forced"][3] >= 1
+    assert torch.equal(out["plain"][0], out["group_idle"][0]) and torch.equal(out["plain"][0], out["group_forced"][0])
